@@ -1,0 +1,211 @@
+/*
+ * scheduler_cycle.c -- a plain-C host (gcc, no HIP headers) that drives the
+ * library exactly the way Mega-KV's GPU scheduler does
+ * (reference src/mega_scheduler.c:273-280 set-up, :393-504 one cycle):
+ *
+ *   per worker stream: H2D search requests, memsetAsync(out), gpu_hash_search,
+ *   D2H results; H2D delete requests, gpu_hash_delete; H2D the 8 insert blocks
+ *   and their counts (device int[8]), gpu_hash_insert; one
+ *   cudaDeviceSynchronize per cycle.
+ *
+ * It is the build's own counterpart of the caller (the reference's .c files
+ * are not copied) and doubles as the link test of lib/libgpuhash.a:
+ *   gcc -Iinclude examples/scheduler_cycle.c -Llib -lgpuhash -lamdhip64 -lstdc++
+ * Self-checking: every key inserted in cycle c is found in cycle c+1 with its
+ * loc (property P1 of libgpuhash/test/insert_test.c:178-195), deleted keys are
+ * gone (P2, :237-244).  Exit code 0 = all checks passed.
+ */
+#include <stdint.h>
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+
+#include "libgpuhash.h"
+
+#define WORKERS 4
+#define MAX_SEARCH 32768	/* config->batch_max_search_job, src/mega.c:136 */
+#define MAX_INSERT 4096		/* per block, src/mega.c:143 */
+#define MAX_DELETE 4096		/* src/mega.c:144 */
+
+static uint64_t mix64(uint64_t x)
+{
+	x += 0x9e3779b97f4a7c15ULL;
+	x = (x ^ (x >> 30)) * 0xbf58476d1ce4e5b9ULL;
+	x = (x ^ (x >> 27)) * 0x94d049bb133111ebULL;
+	return x ^ (x >> 31);
+}
+
+/* key -> (sig, hash): low/high word of a 64-bit digest (src/mega_recv.c:361-362) */
+static void key_elem(uint32_t key, uint32_t *sig, uint32_t *hash)
+{
+	uint64_t z = mix64(key);
+	*sig = (uint32_t)z ? (uint32_t)z : 1;
+	*hash = (uint32_t)(z >> 32);
+}
+
+typedef struct worker_s {
+	cudaStream_t stream;
+	selem_t *search_in, *search_in_d;
+	loc_t *search_out, *search_out_d;
+	delem_t *delete_in, *delete_in_d;
+	ielem_t *insert_in[INSERT_BLOCK];	/* pinned host, one per block */
+	ielem_t *insert_in_d;				/* device, INSERT_BLOCK slices */
+	ielem_t **insert_ptrarray_d;		/* device array of device pointers */
+	int *insert_job_num_d;
+	int insert_job_num[INSERT_BLOCK];
+	int num_search, num_delete, num_gone;
+	uint32_t *search_keys;
+} worker_t;
+
+int main(int argc, char **argv)
+{
+	int cycles = argc > 1 ? atoi(argv[1]) : 20;
+	uint8_t *table;
+	worker_t w[WORKERS];
+	int i, b, c, id, errors = 0;
+
+	CUDA_SAFE_CALL(cudaMalloc((void **)&table, HT_SIZE));
+	CUDA_SAFE_CALL(cudaMemset(table, 0, HT_SIZE));
+
+	for (id = 0; id < WORKERS; id++) {
+		worker_t *k = &w[id];
+		ielem_t *ptrs[INSERT_BLOCK];
+		CUDA_SAFE_CALL(cudaStreamCreate(&k->stream));
+		CUDA_SAFE_CALL(cudaHostAlloc((void **)&k->search_in, MAX_SEARCH * sizeof(selem_t), cudaHostAllocDefault));
+		CUDA_SAFE_CALL(cudaHostAlloc((void **)&k->search_out, 2 * MAX_SEARCH * sizeof(loc_t), cudaHostAllocDefault));
+		CUDA_SAFE_CALL(cudaHostAlloc((void **)&k->delete_in, MAX_DELETE * sizeof(delem_t), cudaHostAllocDefault));
+		CUDA_SAFE_CALL(cudaMalloc((void **)&k->search_in_d, MAX_SEARCH * sizeof(selem_t)));
+		CUDA_SAFE_CALL(cudaMalloc((void **)&k->search_out_d, 2 * MAX_SEARCH * sizeof(loc_t)));
+		CUDA_SAFE_CALL(cudaMalloc((void **)&k->delete_in_d, MAX_DELETE * sizeof(delem_t)));
+		CUDA_SAFE_CALL(cudaMalloc((void **)&k->insert_in_d, INSERT_BLOCK * MAX_INSERT * sizeof(ielem_t)));
+		CUDA_SAFE_CALL(cudaMalloc((void **)&k->insert_ptrarray_d, INSERT_BLOCK * sizeof(ielem_t *)));
+		CUDA_SAFE_CALL(cudaMalloc((void **)&k->insert_job_num_d, INSERT_BLOCK * sizeof(int)));
+		for (b = 0; b < INSERT_BLOCK; b++) {
+			CUDA_SAFE_CALL(cudaHostAlloc((void **)&k->insert_in[b], MAX_INSERT * sizeof(ielem_t), cudaHostAllocDefault));
+			ptrs[b] = k->insert_in_d + (size_t)b * MAX_INSERT;
+		}
+		/* written once at init, like src/mega_recv.c:186-191 */
+		CUDA_SAFE_CALL(cudaMemcpy(k->insert_ptrarray_d, ptrs, sizeof(ptrs), cudaMemcpyHostToDevice));
+		k->search_keys = (uint32_t *)malloc(MAX_SEARCH * sizeof(uint32_t));
+		k->num_search = k->num_delete = k->num_gone = 0;
+	}
+
+	uint32_t next_key = 1;
+	uint64_t total_search = 0, total_insert = 0, total_delete = 0;
+	struct timespec t0, t1;
+	clock_gettime(CLOCK_MONOTONIC, &t0);
+
+	for (c = 0; c < cycles; c++) {
+		/* --- receivers: fill this cycle's batches --- */
+		for (id = 0; id < WORKERS; id++) {
+			worker_t *k = &w[id];
+			/* search what this worker inserted last cycle; delete (then expect a
+			 * miss for) what it inserted two cycles ago */
+			memset(k->insert_job_num, 0, sizeof(k->insert_job_num));
+			for (i = 0; i < 6000; i++) {
+				uint32_t key = next_key++, sig, hash;
+				key_elem(key, &sig, &hash);
+				b = (int)(hash >> (32 - IBLOCK_P));		/* src/mega_recv.c:476-477 */
+				if (k->insert_job_num[b] + 1 >= MAX_INSERT)
+					continue;
+				ielem_t *e = &k->insert_in[b][k->insert_job_num[b]++];
+				e->sig = sig;
+				e->hash = hash;
+				e->loc = key;							/* loc = key: easy to verify */
+			}
+		}
+
+		/* --- scheduler: one cycle --- */
+		for (id = 0; id < WORKERS; id++) {				/* 1. search */
+			worker_t *k = &w[id];
+			if (k->num_search == 0)
+				continue;
+			CUDA_SAFE_CALL(cudaMemcpyAsync(k->search_in_d, k->search_in, k->num_search * sizeof(selem_t),
+						cudaMemcpyHostToDevice, k->stream));
+			CUDA_SAFE_CALL(cudaMemsetAsync(k->search_out_d, 0, 2 * k->num_search * sizeof(loc_t), k->stream));
+			gpu_hash_search(k->search_in_d, k->search_out_d, (bucket_t *)table, k->num_search,
+					24576, 256, k->stream);				/* src/mega.c:163-165 */
+			CUDA_SAFE_CALL(cudaMemcpyAsync(k->search_out, k->search_out_d, 2 * k->num_search * sizeof(loc_t),
+						cudaMemcpyDeviceToHost, k->stream));
+			total_search += k->num_search;
+		}
+		for (id = 0; id < WORKERS; id++) {				/* 2. delete */
+			worker_t *k = &w[id];
+			if (k->num_delete == 0)
+				continue;
+			CUDA_SAFE_CALL(cudaMemcpyAsync(k->delete_in_d, k->delete_in, k->num_delete * sizeof(delem_t),
+						cudaMemcpyHostToDevice, k->stream));
+			gpu_hash_delete(k->delete_in_d, (bucket_t *)table, k->num_delete, 16384, 256, k->stream);
+			total_delete += k->num_delete;
+		}
+		for (id = 0; id < WORKERS; id++) {				/* 3. insert */
+			worker_t *k = &w[id];
+			for (b = 0; b < INSERT_BLOCK; b++) {
+				if (k->insert_job_num[b] == 0)
+					continue;
+				CUDA_SAFE_CALL(cudaMemcpyAsync(k->insert_in_d + (size_t)b * MAX_INSERT, k->insert_in[b],
+							k->insert_job_num[b] * sizeof(ielem_t), cudaMemcpyHostToDevice, k->stream));
+				total_insert += k->insert_job_num[b];
+			}
+			CUDA_SAFE_CALL(cudaMemcpyAsync(k->insert_job_num_d, k->insert_job_num, sizeof(k->insert_job_num),
+						cudaMemcpyHostToDevice, k->stream));
+			gpu_hash_insert((bucket_t *)table, k->insert_ptrarray_d, k->insert_job_num_d, INSERT_BLOCK, k->stream);
+		}
+		CUDA_SAFE_CALL(cudaDeviceSynchronize());
+
+		/* --- senders: consume results (src/mega_send.c:408-414) --- */
+		for (id = 0; id < WORKERS; id++) {
+			worker_t *k = &w[id];
+			for (i = 0; i < k->num_search; i++) {
+				loc_t loc = k->search_out[2 * i];
+				if (loc == 0)
+					loc = k->search_out[2 * i + 1];
+				/* the last num_gone requests repeat keys deleted one cycle ago */
+				int expect_hit = i < k->num_search - k->num_gone;
+				if (expect_hit ? loc != k->search_keys[i] : loc == k->search_keys[i]) {
+					if (errors++ < 10)
+						fprintf(stderr, "cycle %d worker %d key %u: loc %u (%s expected)\n", c, id,
+								k->search_keys[i], loc, expect_hit ? "hit" : "miss");
+				}
+			}
+			/* Next cycle this worker
+			 *   searches every key inserted now (hit expected) and, at the end of
+			 *   the batch, the keys deleted in THIS cycle (miss expected);
+			 *   deletes the first 1000 keys inserted now -- delete runs after
+			 *   search on the same stream, so they are still found next cycle. */
+			int n = 0, gone = 0;
+			for (b = 0; b < INSERT_BLOCK; b++) {
+				for (i = 0; i < k->insert_job_num[b] && n < MAX_SEARCH - 1 - MAX_DELETE; i++) {
+					ielem_t *e = &k->insert_in[b][i];
+					k->search_in[n].sig = e->sig;
+					k->search_in[n].hash = e->hash;
+					k->search_keys[n] = e->loc;
+					n++;
+				}
+			}
+			for (i = 0; i < k->num_delete; i++) {		/* deleted this cycle */
+				k->search_in[n].sig = k->delete_in[i].sig;
+				k->search_in[n].hash = k->delete_in[i].hash;
+				k->search_keys[n] = k->delete_in[i].loc;
+				n++;
+				gone++;
+			}
+			int nd = n - gone < 1000 ? n - gone : 1000;
+			for (i = 0; i < nd; i++) {
+				k->delete_in[i].sig = k->search_in[i].sig;
+				k->delete_in[i].hash = k->search_in[i].hash;
+				k->delete_in[i].loc = k->search_keys[i];
+			}
+			k->num_search = n;
+			k->num_gone = gone;
+			k->num_delete = nd;
+		}
+	}
+	clock_gettime(CLOCK_MONOTONIC, &t1);
+	double us = 1e6 * (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) / 1e3;
+	printf("cycles %d workers %d: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d\n",
+			cycles, WORKERS, (unsigned long long)total_search, (unsigned long long)total_insert,
+			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors);
+	return errors ? 1 : 0;
+}

@@ -1,0 +1,101 @@
+/*
+ * megakv_hip.h -- run-time-geometry entry points of the MI355X hash index.
+ *
+ * libgpuhash.h is the drop-in surface (MEM_P and scheme baked in, exactly as
+ * the reference bakes them into libgpuhash.a).  The functions below are the
+ * same operations with the geometry passed at run time; gpu_hash_search /
+ * gpu_hash_insert / gpu_hash_delete are thin calls of them.  They exist so
+ * that one library build can be parity-tested on small tables and both insert
+ * schemes, and so the multi-GPU sharding (local tables with a different
+ * region split) needs no recompilation.
+ *
+ * Plain C: device pointers, sizes, and the HIP stream as an opaque pointer
+ * (a hipStream_t; NULL = default stream).  Every call is asynchronous on
+ * `stream` and returns 0, or a negative MKV_E* code when nothing was enqueued.
+ */
+#ifndef MEGAKV_HIP_H
+#define MEGAKV_HIP_H
+
+#include <stdint.h>
+#include "gpu_hash.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MKV_SCHEME_CUCKOO  0	/* reference HASH_CUCKOO  (gpu_hash.cu:231-433) */
+#define MKV_SCHEME_2CHOICE 1	/* reference HASH_2CHOICE (gpu_hash.cu:77-229)  */
+
+#define MKV_OK          0
+#define MKV_EINVAL     -1	/* bad geometry / arguments */
+#define MKV_ENOMEM     -2	/* workspace allocation failed */
+#define MKV_ETOOBIG    -3	/* more requests than the reserved workspace holds */
+#define MKV_EHIP       -4	/* a HIP runtime call failed */
+
+typedef struct mkv_geom_s {
+	uint32_t mem_p;			/* log2(table bytes); reference MEM_P (gpu_hash.h:55) */
+	uint32_t iblock_p;		/* log2(closed regions); reference IBLOCK_P (gpu_hash.h:67) */
+	uint32_t scheme;		/* MKV_SCHEME_* */
+	uint32_t max_cuckoo;	/* reference MAX_CUCKOO_NUM = 5 (gpu_hash.h:75) */
+} mkv_geom_t;
+
+/* search flags */
+#define MKV_SEARCH_KEEP_MISS 0u	/* reference behaviour: out untouched on a miss */
+#define MKV_SEARCH_ZERO_MISS 1u	/* write 0 on a miss: caller needs no memset */
+
+int mkv_search(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
+		const bucket_t *table, int64_t num_elem, uint32_t flags, void *stream);
+
+int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, void *stream);
+
+int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
+		int64_t num_elem, void *stream);
+
+/* Insert/delete keep a private device workspace per stream (conflict tables and
+ * request state).  It is created on the first call that needs it; call this
+ * beforehand to size it explicitly (and keep allocation out of a region being
+ * captured into a hipGraph).  max_requests bounds the requests of one
+ * insert/delete call on that stream. */
+int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *stream);
+
+/* Frees every workspace of the calling process (device must be idle). */
+void mkv_release_all(void);
+
+/* Diagnostics of the most recent insert/delete on `stream` (synchronises the
+ * stream).  Not part of the hot path. */
+typedef struct mkv_update_info_s {
+	uint32_t total;			/* requests in the call */
+	uint32_t committed[6];	/* requests finished by parallel round 1..6 */
+	uint32_t drained;		/* requests finished by the in-order tail */
+	uint32_t first_hard;	/* lowest request index that needed an eviction chain, or 0xffffffff */
+	uint32_t rounds;		/* parallel rounds enqueued */
+} mkv_update_info_t;
+
+int mkv_last_update_info(void *stream, mkv_update_info_t *info);
+
+/* ---- request routing for the sharded (multi-GPU) index, SURVEY 8(e) -------
+ * shard(e) = ((e.hash & hash_mask_agg) >> shard_shift); requests are grouped by
+ * shard, stably, on the device.  `perm[j]` = original index of the j-th
+ * routed request; counts[s] = requests of shard s (device int64[nshards]). */
+int mkv_route_requests(const void *in, int elem_words /* 2 = selem, 3 = ielem */,
+		int64_t num_elem, uint32_t hash_mask_agg, uint32_t shard_shift, int nshards,
+		void *routed_out, int32_t *perm, int64_t *counts, void *scratch,
+		int64_t scratch_bytes, void *stream);
+
+/* out[perm[j]] = routed[j] for 8-byte loc pairs (undo of the routing). */
+int mkv_unroute_results(const loc_t *routed, const int32_t *perm, int64_t num_elem,
+		loc_t *out, void *stream);
+
+/* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
+ * "search_nt" (non-temporal table loads), "update_rounds" (1..6 parallel
+ * rounds before the in-order tail), "req_cap" (default requests per update
+ * call).  Results never depend on them; they exist for measurement and tests. */
+int mkv_set_tuning(const char *name, long long value);
+
+const char *mkv_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,52 @@
+// cuda_names.hip -- the host-side CUDA runtime names Mega-KV's C host calls
+// (listed in include/cuda_runtime.h), each a direct call of the HIP runtime.
+// Part of the drop-in boundary only; no kernel in this library is written
+// against these names.
+#include <hip/hip_runtime.h>
+
+#include "cuda_runtime.h"
+
+static hipMemcpyKind kind_of(enum cudaMemcpyKind k)
+{
+	switch (k) {
+	case cudaMemcpyHostToHost: return hipMemcpyHostToHost;
+	case cudaMemcpyHostToDevice: return hipMemcpyHostToDevice;
+	case cudaMemcpyDeviceToHost: return hipMemcpyDeviceToHost;
+	case cudaMemcpyDeviceToDevice: return hipMemcpyDeviceToDevice;
+	default: return hipMemcpyDefault;
+	}
+}
+
+extern "C" {
+
+cudaError_t cudaMalloc(void **p, size_t n) { return (cudaError_t)hipMalloc(p, n); }
+cudaError_t cudaFree(void *p) { return (cudaError_t)hipFree(p); }
+cudaError_t cudaHostAlloc(void **p, size_t n, unsigned int flags)
+{
+	return (cudaError_t)hipHostMalloc(p, n, flags);
+}
+cudaError_t cudaFreeHost(void *p) { return (cudaError_t)hipHostFree(p); }
+cudaError_t cudaMemset(void *p, int v, size_t n) { return (cudaError_t)hipMemset(p, v, n); }
+cudaError_t cudaMemsetAsync(void *p, int v, size_t n, cudaStream_t s)
+{
+	return (cudaError_t)hipMemsetAsync(p, v, n, (hipStream_t)s);
+}
+cudaError_t cudaMemcpy(void *d, const void *s, size_t n, enum cudaMemcpyKind k)
+{
+	return (cudaError_t)hipMemcpy(d, s, n, kind_of(k));
+}
+cudaError_t cudaMemcpyAsync(void *d, const void *s, size_t n, enum cudaMemcpyKind k, cudaStream_t st)
+{
+	return (cudaError_t)hipMemcpyAsync(d, s, n, kind_of(k), (hipStream_t)st);
+}
+cudaError_t cudaStreamCreate(cudaStream_t *s) { return (cudaError_t)hipStreamCreate((hipStream_t *)s); }
+cudaError_t cudaStreamDestroy(cudaStream_t s) { return (cudaError_t)hipStreamDestroy((hipStream_t)s); }
+cudaError_t cudaStreamSynchronize(cudaStream_t s)
+{
+	return (cudaError_t)hipStreamSynchronize((hipStream_t)s);
+}
+cudaError_t cudaDeviceSynchronize(void) { return (cudaError_t)hipDeviceSynchronize(); }
+cudaError_t cudaGetLastError(void) { return (cudaError_t)hipGetLastError(); }
+const char *cudaGetErrorString(cudaError_t e) { return hipGetErrorString((hipError_t)e); }
+
+}

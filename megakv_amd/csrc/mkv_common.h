@@ -1,0 +1,88 @@
+// mkv_common.h -- device-side geometry and bucket helpers shared by the HIP
+// kernels of the MI355X hash index (gfx950 only, wave64).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "megakv_hip.h"
+
+namespace mkv {
+
+constexpr int kWave = 64;
+constexpr uint32_t kSlots = 8;          // ELEM_NUM
+constexpr uint32_t kBucketWords = 16;   // 8 sig + 8 loc dwords
+constexpr uint32_t kNone = 0xffffffffu;
+
+// Geometry as the kernels consume it (derived once on the host).
+struct DevGeom {
+	uint32_t hash_mask;     // HASH_MASK        (ref gpu_hash.h:61)
+	uint32_t blk_mask;      // BLOCK_HASH_MASK  (ref gpu_hash.h:69)
+	uint32_t region_shift;  // bucket >> region_shift = closed region id
+	uint32_t nregions;
+	uint32_t max_cuckoo;
+	uint32_t scheme;
+};
+
+inline bool make_dev_geom(const mkv_geom_t *g, DevGeom *d)
+{
+	if (!g || g->mem_p < 6 + g->iblock_p || g->mem_p > 37 || g->iblock_p > 5)
+		return false;
+	if (g->scheme != MKV_SCHEME_CUCKOO && g->scheme != MKV_SCHEME_2CHOICE)
+		return false;
+	uint32_t bucket_bits = g->mem_p - 6;
+	if (bucket_bits > 31)
+		return false;
+	d->hash_mask = (uint32_t)(((uint64_t)1 << bucket_bits) - 1);
+	d->blk_mask = (uint32_t)(((uint64_t)1 << (bucket_bits - g->iblock_p)) - 1);
+	d->region_shift = bucket_bits - g->iblock_p;
+	d->nregions = 1u << g->iblock_p;
+	d->max_cuckoo = g->max_cuckoo;
+	d->scheme = g->scheme;
+	return true;
+}
+
+// Alternate bucket: the low (region-local) bits are XORed with the signature,
+// the region bits are kept (ref gpu_hash.cu:66-67).
+__device__ __forceinline__ uint32_t alt_bucket(uint32_t hash, uint32_t sig,
+		uint32_t hash_mask, uint32_t blk_mask)
+{
+	return (((hash ^ sig) & blk_mask) | (hash & ~blk_mask)) & hash_mask;
+}
+
+// 8-bit mask of the slots of a signature row equal to `sig`.
+__device__ __forceinline__ uint32_t eq_mask(const uint4 &lo, const uint4 &hi, uint32_t sig)
+{
+	return (uint32_t)(lo.x == sig) | ((uint32_t)(lo.y == sig) << 1) |
+		((uint32_t)(lo.z == sig) << 2) | ((uint32_t)(lo.w == sig) << 3) |
+		((uint32_t)(hi.x == sig) << 4) | ((uint32_t)(hi.y == sig) << 5) |
+		((uint32_t)(hi.z == sig) << 6) | ((uint32_t)(hi.w == sig) << 7);
+}
+
+// Slot an insert takes among the empty slots E: the lowest one at or above
+// (orig_sig & 7), else the lowest (ref gpu_hash.cu:301-309).
+__device__ __forceinline__ uint32_t preferred_slot(uint32_t empties, uint32_t orig_sig)
+{
+	uint32_t ml = (1u << (orig_sig & 7u)) - 1u;
+	uint32_t ballot = ((empties & ml) << 16) | (empties & ~ml);
+	return (uint32_t)(__ffs((int)ballot) - 1) & 7u;
+}
+
+// Process-wide tuning knobs (defaults = measured best on MI355X).
+// Initialised from MKV_SEARCH_U / MKV_SEARCH_NT / MKV_UPDATE_ROUNDS /
+// MKV_REQ_CAP on first use, changeable through mkv_set_tuning().
+struct Tuning {
+	int search_u;        // requests in flight per 4-lane group: 1, 2, 4 or 8
+	int search_nt;       // non-temporal table loads in search
+	int update_rounds;   // parallel reservation rounds before the in-order tail
+	long long req_cap;   // default request capacity of an update workspace
+};
+Tuning &tuning();
+
+#define MKV_HIP_TRY(expr)                                   \
+	do {                                                    \
+		hipError_t e_ = (expr);                             \
+		if (e_ != hipSuccess) return MKV_EHIP;              \
+	} while (0)
+
+}  // namespace mkv

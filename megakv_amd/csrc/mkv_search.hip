@@ -1,0 +1,206 @@
+// mkv_search.hip -- batched search of the bucketed hash index on gfx950.
+//
+// Replaces the reference kernel hash_search (libgpuhash/gpu_hash.cu:28-75):
+// for request i, out[2i] receives the location stored under `sig` in the
+// primary bucket and out[2i+1] the one in the alternate bucket; BOTH buckets
+// are always probed (the early exit is commented out in the reference, :61-63)
+// and a miss leaves the output word untouched (:50-53).
+//
+// MI355X mapping (this is HBM-bound random 64-byte gathering, no MFMA):
+//   * 4 lanes serve one request: lanes 0/1 own the two 32-byte halves of the
+//     primary bucket's slots (4 signatures + their 4 locations each), lanes
+//     2/3 the alternate bucket's.  Every lane issues two independent 16-byte
+//     loads (signature quarter-row and the matching location quarter-row), so
+//     one wave instruction moves 1 KiB with all 16 bytes of every lane used and
+//     a whole 64-byte bucket is fetched by one lane pair -- no dependent second
+//     load for the location on a hit.
+//   * U requests per lane group are in flight together (2*U 16-byte loads per
+//     lane, 16*U requests = 2*16*U random 64-byte lines per wave) to cover HBM
+//     latency with few resident registers.
+//   * the compare is lane-local (4 slots), the pair is merged with one DPP
+//     quad permute; no LDS, no ballot.  If several slots of a bucket hold the
+//     signature the highest slot wins -- the serialised reference order; the
+//     CUDA kernel races there (gpu_hash.cu:56-58).
+#include <string.h>
+
+#include "mkv_common.h"
+
+namespace mkv {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// quad_perm [1,0,3,2]: swap lanes inside each pair.
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+// quad_perm [2,3,0,1]: swap the pairs of a quad.
+__device__ __forceinline__ uint32_t dpp_swap2(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+
+template <int U, bool ZERO_MISS, bool NT>
+__global__ __launch_bounds__(256) void k_search(const uint2 *__restrict__ in,
+		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n,
+		uint32_t hash_mask, uint32_t blk_mask)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t q = lane & 3u;       // 0,1 primary halves; 2,3 alternate halves
+	const uint32_t grp = lane >> 2;     // request slot inside the wave, 0..15
+	const int64_t wave = (int64_t)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int64_t base = wave * (16 * U);
+
+	u32x4 sv[U], lv[U];
+	uint32_t sig[U];
+	bool live[U];
+
+#pragma unroll
+	for (int u = 0; u < U; u++) {
+		const int64_t e = base + u * 16 + grp;
+		live[u] = e < n;
+		uint2 req = live[u] ? in[e] : make_uint2(0u, 0u);    // {sig, hash}
+		sig[u] = req.x;
+		const uint32_t pri = req.y & hash_mask;
+		const uint32_t alt = alt_bucket(req.y, req.x, hash_mask, blk_mask);
+		const uint32_t b = (q & 2u) ? alt : pri;
+		const u32x4 *p = reinterpret_cast<const u32x4 *>(table) + ((uint64_t)b << 2) + (q & 1u);
+		if (live[u]) {
+			if (NT) {
+				sv[u] = __builtin_nontemporal_load(p);
+				lv[u] = __builtin_nontemporal_load(p + 2);
+			} else {
+				sv[u] = p[0];
+				lv[u] = p[2];
+			}
+		} else {
+			sv[u] = (u32x4)(0u);
+			lv[u] = sv[u];
+		}
+	}
+
+#pragma unroll
+	for (int u = 0; u < U; u++) {
+		const int64_t e = base + u * 16 + grp;
+		// highest matching slot of this lane's four
+		uint32_t hit = 0u, val = 0u;
+		if (sv[u].x == sig[u]) { hit = 1u; val = lv[u].x; }
+		if (sv[u].y == sig[u]) { hit = 1u; val = lv[u].y; }
+		if (sv[u].z == sig[u]) { hit = 1u; val = lv[u].z; }
+		if (sv[u].w == sig[u]) { hit = 1u; val = lv[u].w; }
+		// merge the pair: the odd lane holds slots 4..7 and takes precedence
+		const uint32_t phit = dpp_swap1(hit), pval = dpp_swap1(val);
+		if (q & 1u) {
+			// odd lanes do not store; keep their registers consistent anyway
+		} else {
+			if (phit) { hit = 1u; val = pval; }
+		}
+		if (ZERO_MISS) {
+			// lane q==0 gathers the alternate result and stores both words
+			const uint32_t ahit = dpp_swap2(hit), aval = dpp_swap2(val);
+			if (q == 0u && live[u]) {
+				uint2 r = make_uint2(hit ? val : 0u, ahit ? aval : 0u);
+				*reinterpret_cast<uint2 *>(out + 2 * e) = r;
+			}
+		} else {
+			if ((q & 1u) == 0u && hit && live[u])
+				out[2 * e + (q >> 1)] = val;
+		}
+	}
+}
+
+template <int U>
+static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int64_t n,
+		uint32_t hash_mask, uint32_t blk_mask, uint32_t flags, bool nt, hipStream_t stream)
+{
+	const int64_t per_block = 4 * 16 * U;
+	const int64_t blocks = (n + per_block - 1) / per_block;
+	if (blocks > 0x7fffffffLL)
+		return MKV_ETOOBIG;
+	dim3 grid((unsigned)blocks), block(256);
+	const bool zero = (flags & MKV_SEARCH_ZERO_MISS) != 0;
+	if (zero) {
+		if (nt)
+			hipLaunchKernelGGL((k_search<U, true, true>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+		else
+			hipLaunchKernelGGL((k_search<U, true, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+	} else {
+		if (nt)
+			hipLaunchKernelGGL((k_search<U, false, true>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+		else
+			hipLaunchKernelGGL((k_search<U, false, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+	}
+	return MKV_OK;
+}
+
+Tuning &tuning()
+{
+	static Tuning t = [] {
+		Tuning v;
+		const char *s = getenv("MKV_SEARCH_U");
+		v.search_u = s ? atoi(s) : 4;
+		if (v.search_u != 1 && v.search_u != 2 && v.search_u != 4 && v.search_u != 8)
+			v.search_u = 4;
+		s = getenv("MKV_SEARCH_NT");
+		v.search_nt = s ? atoi(s) != 0 : 0;
+		s = getenv("MKV_UPDATE_ROUNDS");
+		v.update_rounds = s ? atoi(s) : 3;
+		if (v.update_rounds < 1) v.update_rounds = 1;
+		if (v.update_rounds > 6) v.update_rounds = 6;
+		s = getenv("MKV_REQ_CAP");
+		v.req_cap = s ? atoll(s) : (1ll << 22);
+		if (v.req_cap < 1024) v.req_cap = 1024;
+		return v;
+	}();
+	return t;
+}
+
+}  // namespace mkv
+
+extern "C" int mkv_search(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
+		const bucket_t *table, int64_t num_elem, uint32_t flags, void *stream)
+{
+	const mkv::Tuning &tune = mkv::tuning();
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || num_elem < 0)
+		return MKV_EINVAL;
+	if (num_elem == 0)
+		return MKV_OK;
+	if (!in || !out || !table)
+		return MKV_EINVAL;
+	const uint2 *in2 = reinterpret_cast<const uint2 *>(in);
+	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
+	hipStream_t s = (hipStream_t)stream;
+	const bool nt = tune.search_nt != 0;
+	switch (tune.search_u) {
+	case 1: return mkv::launch_search<1>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
+	case 2: return mkv::launch_search<2>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
+	case 8: return mkv::launch_search<8>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
+	default: return mkv::launch_search<4>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
+	}
+}
+
+extern "C" int mkv_set_tuning(const char *name, long long value)
+{
+	if (!name)
+		return MKV_EINVAL;
+	mkv::Tuning &t = mkv::tuning();
+	if (!strcmp(name, "search_u")) {
+		if (value != 1 && value != 2 && value != 4 && value != 8)
+			return MKV_EINVAL;
+		t.search_u = (int)value;
+	} else if (!strcmp(name, "search_nt")) {
+		t.search_nt = value != 0;
+	} else if (!strcmp(name, "update_rounds")) {
+		if (value < 1 || value > 6)
+			return MKV_EINVAL;
+		t.update_rounds = (int)value;
+	} else if (!strcmp(name, "req_cap")) {
+		if (value < 1024)
+			return MKV_EINVAL;
+		t.req_cap = value;
+	} else {
+		return MKV_EINVAL;
+	}
+	return MKV_OK;
+}

@@ -1,0 +1,180 @@
+"""Host-side mirror of the reference's libgpuhash interface.
+
+`gpu_hash_search / gpu_hash_insert / gpu_hash_delete` take the same arguments,
+in the same order and with the same meaning as the C entry points
+(reference libgpuhash/libgpuhash.h:29-51), with torch CUDA tensors standing in
+for the device pointers; they call the C ABI of the HIP library and nothing
+else.  `HashIndex` is the run-time-geometry convenience used by the tests and
+the benchmark (table ownership, request staging), mirroring what the
+reference's scheduler does around the three calls
+(src/mega_scheduler.c:273-280, 393-504).
+"""
+import ctypes
+from dataclasses import dataclass
+
+import torch
+
+from .lib import MkvGeom, MkvUpdateInfo, load_library
+
+SCHEME_CUCKOO = 0
+SCHEME_2CHOICE = 1
+
+MKV_SEARCH_KEEP_MISS = 0
+MKV_SEARCH_ZERO_MISS = 1
+
+
+@dataclass(frozen=True)
+class Geometry:
+    """Run-time form of the gpu_hash.h macros (reference gpu_hash.h:54-75)."""
+    mem_p: int = 30
+    scheme: int = SCHEME_CUCKOO
+    iblock_p: int = 3
+    max_cuckoo: int = 5
+
+    @property
+    def nbuckets(self):
+        return 1 << (self.mem_p - 6)
+
+    @property
+    def ht_size(self):
+        return 1 << self.mem_p
+
+    @property
+    def hash_mask(self):
+        return self.nbuckets - 1
+
+    @property
+    def block_hash_mask(self):
+        return (1 << (self.mem_p - 6 - self.iblock_p)) - 1
+
+    @property
+    def insert_blocks(self):
+        return 1 << self.iblock_p
+
+    def c(self):
+        return MkvGeom(self.mem_p, self.iblock_p, self.scheme, self.max_cuckoo)
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        stream = torch.cuda.current_stream()
+    if isinstance(stream, int):
+        return ctypes.c_void_p(stream)
+    return ctypes.c_void_p(stream.cuda_stream)
+
+
+def _dev_ptr(t):
+    assert t.is_cuda and t.is_contiguous(), "contiguous CUDA tensor expected"
+    return ctypes.c_void_p(t.data_ptr())
+
+
+# ---- the reference's three entry points, by name ---------------------------
+def gpu_hash_search(in_, out, hash_table, num_elem, num_thread, threads_per_blk, stream=None):
+    """reference gpu_hash.cu:482-518; geometry/scheme are the library's baked-in
+    MEM_P / HASH_* (like the reference).  `out` must be zeroed by the caller."""
+    load_library().gpu_hash_search(_dev_ptr(in_), _dev_ptr(out), _dev_ptr(hash_table),
+                                   int(num_elem), int(num_thread), int(threads_per_blk),
+                                   _stream_ptr(stream))
+
+
+def gpu_hash_insert(hash_table, blk_input, blk_elem_num, num_blks, stream=None):
+    """reference gpu_hash.cu:521-556.  blk_input: device int64 tensor holding
+    num_blks device pointers; blk_elem_num: device int32 tensor of counts."""
+    load_library().gpu_hash_insert(_dev_ptr(hash_table), _dev_ptr(blk_input),
+                                   _dev_ptr(blk_elem_num), int(num_blks), _stream_ptr(stream))
+
+
+def gpu_hash_delete(in_, hash_table, num_elem, num_thread, threads_per_blk, stream=None):
+    """reference gpu_hash.cu:558-593."""
+    load_library().gpu_hash_delete(_dev_ptr(in_), _dev_ptr(hash_table), int(num_elem),
+                                   int(num_thread), int(threads_per_blk), _stream_ptr(stream))
+
+
+class MkvError(RuntimeError):
+    pass
+
+
+def _check(rc, what):
+    if rc != 0:
+        raise MkvError(f"{what} failed with code {rc}")
+
+
+class HashIndex:
+    """A device-resident table plus the three batched operations.
+
+    Requests and results are torch tensors on the index's device:
+      search:  selem int32/uint32 [n,2] (sig, hash)      -> out [n,2] (loc or 0)
+      insert:  list of ielem [n_b,3] blocks (sig, hash, loc), canonical order =
+               block order then row order
+      delete:  delem [n,3]
+    """
+
+    def __init__(self, geom: Geometry = Geometry(), device=None):
+        self.lib = load_library()   # raises if the HIP library is absent
+        if not torch.cuda.is_available():
+            raise MkvError("no GPU visible: the hash index has no CPU path")
+        self.geom = geom
+        self.device = torch.device(device if device is not None else f"cuda:{torch.cuda.current_device()}")
+        self._g = geom.c()
+        # caller-owned, zero-initialised table (src/mega_scheduler.c:273-274)
+        self.table = torch.zeros(geom.ht_size // 4, dtype=torch.int32, device=self.device)
+        self._keep = []
+
+    # -- search ----------------------------------------------------------------
+    def search(self, selem, out=None, zero_miss=True, stream=None):
+        n = selem.shape[0]
+        assert selem.shape[1] == 2 and selem.element_size() == 4
+        if out is None:
+            out = torch.empty((n, 2), dtype=torch.int32, device=self.device)
+            if not zero_miss:
+                out.zero_()
+        flags = MKV_SEARCH_ZERO_MISS if zero_miss else MKV_SEARCH_KEEP_MISS
+        _check(self.lib.mkv_search(ctypes.byref(self._g), _dev_ptr(selem), _dev_ptr(out),
+                                   _dev_ptr(self.table), n, flags, _stream_ptr(stream)), "mkv_search")
+        return out
+
+    # -- insert ----------------------------------------------------------------
+    def stage_blocks(self, blocks):
+        """Builds the (blk_input, blk_elem_num) device arrays the ABI takes from a
+        list of [n_b,3] device tensors.  Returns (ptr_tensor, count_tensor, keepalive)."""
+        blocks = [b.contiguous() for b in blocks]
+        ptrs = torch.tensor([b.data_ptr() for b in blocks], dtype=torch.int64).to(self.device)
+        cnts = torch.tensor([b.shape[0] for b in blocks], dtype=torch.int32).to(self.device)
+        return ptrs, cnts, blocks
+
+    def insert(self, blocks, stream=None):
+        ptrs, cnts, keep = self.stage_blocks(blocks)
+        self.insert_staged(ptrs, cnts, len(keep), stream)
+        self._keep = [ptrs, cnts, keep]   # alive until the next call (async launch)
+
+    def insert_staged(self, ptrs, cnts, num_blks, stream=None):
+        _check(self.lib.mkv_insert(ctypes.byref(self._g), _dev_ptr(self.table), _dev_ptr(ptrs),
+                                   _dev_ptr(cnts), num_blks, _stream_ptr(stream)), "mkv_insert")
+
+    # -- delete ----------------------------------------------------------------
+    def delete(self, delem, stream=None):
+        assert delem.shape[1] == 3 and delem.element_size() == 4
+        self._keep = [delem]
+        _check(self.lib.mkv_delete(ctypes.byref(self._g), _dev_ptr(delem), _dev_ptr(self.table),
+                                   delem.shape[0], _stream_ptr(stream)), "mkv_delete")
+
+    # -- misc --------------------------------------------------------------------
+    def reserve(self, max_requests, stream=None):
+        _check(self.lib.mkv_reserve(ctypes.byref(self._g), int(max_requests), _stream_ptr(stream)),
+               "mkv_reserve")
+
+    def last_update_info(self, stream=None):
+        info = MkvUpdateInfo()
+        _check(self.lib.mkv_last_update_info(_stream_ptr(stream), ctypes.byref(info)),
+               "mkv_last_update_info")
+        return {"total": info.total, "committed": list(info.committed), "drained": info.drained,
+                "first_hard": info.first_hard, "rounds": info.rounds}
+
+    def table_numpy(self):
+        """Table image as uint32 [nbuckets,16] on the host (sig[8] | loc[8])."""
+        return self.table.cpu().numpy().view("uint32").reshape(-1, 16)
+
+    def load_table(self, image):
+        """image: numpy uint32 [nbuckets,16]."""
+        t = torch.from_numpy(image.reshape(-1).view("int32"))
+        self.table.copy_(t)

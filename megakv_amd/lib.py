@@ -1,0 +1,81 @@
+"""ctypes loader for the HIP library.  There is no fallback: if the shared
+object is missing or does not export the C ABI, importing code fails loudly."""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "_lib", "libmegakv_hip.so")
+WORKLOAD_PATH = os.path.join(_HERE, "_lib", "libmkv_workload.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
+
+class MkvGeom(ctypes.Structure):
+    _fields_ = [("mem_p", ctypes.c_uint32), ("iblock_p", ctypes.c_uint32),
+                ("scheme", ctypes.c_uint32), ("max_cuckoo", ctypes.c_uint32)]
+
+
+class MkvUpdateInfo(ctypes.Structure):
+    _fields_ = [("total", ctypes.c_uint32), ("committed", ctypes.c_uint32 * 6),
+                ("drained", ctypes.c_uint32), ("first_hard", ctypes.c_uint32),
+                ("rounds", ctypes.c_uint32)]
+
+
+# every symbol include/libgpuhash.h, include/megakv_hip.h and
+# include/cuda_runtime.h declare
+ABI_SYMBOLS = [
+    "gpu_hash_search", "gpu_hash_insert", "gpu_hash_delete", "gpu_delete_insert",
+    "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
+    "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
+    "mkv_set_tuning",
+    "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
+    "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
+    "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
+    "cudaGetLastError", "cudaGetErrorString",
+]
+
+_lib = None
+
+
+def load_library():
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise LibraryMissing(
+            f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "or `make -C megakv_amd/csrc`.  There is no CPU fallback.")
+    L = ctypes.CDLL(LIB_PATH)
+    P, I64, U32, INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
+    G = ctypes.POINTER(MkvGeom)
+    for name in ABI_SYMBOLS:
+        if not hasattr(L, name):
+            raise LibraryMissing(f"{LIB_PATH} does not export {name}")
+    L.gpu_hash_search.restype = None
+    L.gpu_hash_search.argtypes = [P, P, P, INT, INT, INT, P]
+    L.gpu_hash_insert.restype = None
+    L.gpu_hash_insert.argtypes = [P, P, P, INT, P]
+    L.gpu_hash_delete.restype = None
+    L.gpu_hash_delete.argtypes = [P, P, INT, INT, INT, P]
+    L.mkv_search.restype = INT
+    L.mkv_search.argtypes = [G, P, P, P, I64, U32, P]
+    L.mkv_insert.restype = INT
+    L.mkv_insert.argtypes = [G, P, P, P, INT, P]
+    L.mkv_delete.restype = INT
+    L.mkv_delete.argtypes = [G, P, P, I64, P]
+    L.mkv_reserve.restype = INT
+    L.mkv_reserve.argtypes = [G, I64, P]
+    L.mkv_release_all.restype = None
+    L.mkv_last_update_info.restype = INT
+    L.mkv_last_update_info.argtypes = [P, ctypes.POINTER(MkvUpdateInfo)]
+    L.mkv_route_requests.restype = INT
+    L.mkv_route_requests.argtypes = [P, INT, I64, U32, U32, INT, P, P, P, P, I64, P]
+    L.mkv_unroute_results.restype = INT
+    L.mkv_unroute_results.argtypes = [P, P, I64, P, P]
+    L.mkv_set_tuning.restype = INT
+    L.mkv_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
+    L.mkv_version.restype = ctypes.c_char_p
+    _lib = L
+    return L

@@ -1,0 +1,68 @@
+/*
+ * gpuhash_oracle.h -- CPU restatement of Mega-KV's libgpuhash kernels.
+ *
+ * TEST INFRASTRUCTURE ONLY.  Nothing under megakv_amd/ (the product) may
+ * include, link or call this; it is used by tests/, __graft_entry__.smoke()
+ * and bench.py's cpu_baseline leg as the checker / CPU yardstick.
+ */
+#ifndef GPUHASH_ORACLE_H
+#define GPUHASH_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define ORC_SCHEME_CUCKOO  0
+#define ORC_SCHEME_2CHOICE 1
+
+/* Table geometry: the reference fixes these at compile time
+ * (libgpuhash/gpu_hash.h:54-69); the oracle takes them at run time so one
+ * build checks every configuration. */
+typedef struct orc_geom_s {
+	uint32_t mem_p;       /* log2(table bytes); bucket count = 2^(mem_p-6) */
+	uint32_t iblock_p;    /* reference IBLOCK_P = 3 */
+	uint32_t scheme;      /* ORC_SCHEME_* */
+	uint32_t max_cuckoo;  /* reference MAX_CUCKOO_NUM = 5 */
+} orc_geom_t;
+
+typedef struct orc_selem_s { uint32_t sig, hash; } orc_selem_t;
+typedef struct orc_ielem_s { uint32_t sig, hash, loc; } orc_ielem_t;
+typedef struct orc_bucket_s { uint32_t sig[8]; uint32_t loc[8]; } orc_bucket_t;
+
+/* Work counters used for the algorithmic-bytes figures:
+ * bytes = 12*elems + 64*buckets_visited + 4*dword_stores. */
+typedef struct orc_stats_s {
+	uint64_t elems;
+	uint64_t buckets_visited;
+	uint64_t dword_stores;
+	uint64_t evictions;     /* cuckoo relocations performed */
+	uint64_t dropped;       /* victims dropped after max_cuckoo relocations */
+	uint64_t skipped_zero;  /* elements with sig==0 && loc==0 */
+} orc_stats_t;
+
+uint32_t orc_hash_mask(const orc_geom_t *g);
+uint32_t orc_block_mask(const orc_geom_t *g);
+uint32_t orc_primary(const orc_geom_t *g, uint32_t hash);
+uint32_t orc_alternate(const orc_geom_t *g, uint32_t hash, uint32_t sig);
+
+void orc_search(const orc_geom_t *g, const orc_bucket_t *table,
+		const orc_selem_t *in, uint32_t *out, int64_t n);
+
+void orc_insert(const orc_geom_t *g, orc_bucket_t *table,
+		const orc_ielem_t *const *blk_input, const int *blk_elem_num,
+		int num_blks, orc_stats_t *stats);
+
+void orc_delete(const orc_geom_t *g, orc_bucket_t *table,
+		const orc_ielem_t *in, int64_t n, orc_stats_t *stats);
+
+/* Multi-threaded search over [0,n) split in nthreads contiguous chunks (search
+ * is read-only, so any split is exact).  Used only for the CPU baseline. */
+void orc_search_mt(const orc_geom_t *g, const orc_bucket_t *table,
+		const orc_selem_t *in, uint32_t *out, int64_t n, int nthreads);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

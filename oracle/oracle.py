@@ -1,0 +1,135 @@
+"""ctypes binding of oracle/gpuhash_oracle.c (numpy in, numpy out).
+
+TEST INFRASTRUCTURE ONLY -- see gpuhash_oracle.c for what is restated and how
+it is pinned.  Arrays use the reference layouts (libgpuhash/gpu_hash.h:79-104):
+  table  uint32[nbuckets, 16]  (sig[8] then loc[8])
+  selem  uint32[n, 2]          (sig, hash)
+  ielem  uint32[n, 3]          (sig, hash, loc)
+"""
+import ctypes
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "_build", "libgpuhash_oracle.so")
+
+SCHEME_CUCKOO = 0
+SCHEME_2CHOICE = 1
+
+
+class Geom(ctypes.Structure):
+    _fields_ = [("mem_p", ctypes.c_uint32), ("iblock_p", ctypes.c_uint32),
+                ("scheme", ctypes.c_uint32), ("max_cuckoo", ctypes.c_uint32)]
+
+
+class Stats(ctypes.Structure):
+    _fields_ = [("elems", ctypes.c_uint64), ("buckets_visited", ctypes.c_uint64),
+                ("dword_stores", ctypes.c_uint64), ("evictions", ctypes.c_uint64),
+                ("dropped", ctypes.c_uint64), ("skipped_zero", ctypes.c_uint64)]
+
+    def as_dict(self):
+        return {k: int(getattr(self, k)) for k, _ in self._fields_}
+
+
+def build(force=False):
+    src = [os.path.join(_HERE, f) for f in ("gpuhash_oracle.c", "gpuhash_oracle.h", "Makefile")]
+    if (not force and os.path.exists(_SO)
+            and all(os.path.getmtime(_SO) >= os.path.getmtime(s) for s in src)):
+        return _SO
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_SO):
+            build()
+        L = ctypes.CDLL(_SO)
+        P = ctypes.c_void_p
+        L.orc_primary.restype = ctypes.c_uint32
+        L.orc_primary.argtypes = [ctypes.POINTER(Geom), ctypes.c_uint32]
+        L.orc_alternate.restype = ctypes.c_uint32
+        L.orc_alternate.argtypes = [ctypes.POINTER(Geom), ctypes.c_uint32, ctypes.c_uint32]
+        L.orc_search.restype = None
+        L.orc_search.argtypes = [ctypes.POINTER(Geom), P, P, P, ctypes.c_int64]
+        L.orc_search_mt.restype = None
+        L.orc_search_mt.argtypes = [ctypes.POINTER(Geom), P, P, P, ctypes.c_int64, ctypes.c_int]
+        L.orc_insert.restype = None
+        L.orc_insert.argtypes = [ctypes.POINTER(Geom), P, P, P, ctypes.c_int, ctypes.POINTER(Stats)]
+        L.orc_delete.restype = None
+        L.orc_delete.argtypes = [ctypes.POINTER(Geom), P, P, ctypes.c_int64, ctypes.POINTER(Stats)]
+        _lib = L
+    return _lib
+
+
+def geom(mem_p=30, scheme=SCHEME_CUCKOO, iblock_p=3, max_cuckoo=5):
+    return Geom(mem_p, iblock_p, scheme, max_cuckoo)
+
+
+def nbuckets(g):
+    return 1 << (g.mem_p - 6)
+
+
+def new_table(g):
+    """Zeroed table; np.zeros is lazily committed so MEM_P=30 costs nothing
+    until buckets are touched."""
+    return np.zeros((nbuckets(g), 16), dtype=np.uint32)
+
+
+def _ptr(a):
+    return a.ctypes.data_as(ctypes.c_void_p)
+
+
+def _check(a, cols):
+    assert a.dtype == np.uint32 and a.flags["C_CONTIGUOUS"], "uint32 C-contiguous expected"
+    assert a.ndim == 2 and a.shape[1] == cols, f"shape [n,{cols}] expected, got {a.shape}"
+
+
+def primary(g, hash_):
+    return int(lib().orc_primary(ctypes.byref(g), ctypes.c_uint32(int(hash_))))
+
+
+def alternate(g, hash_, sig):
+    return int(lib().orc_alternate(ctypes.byref(g), ctypes.c_uint32(int(hash_)),
+                                   ctypes.c_uint32(int(sig))))
+
+
+def search(g, table, selem, out=None, threads=1):
+    _check(table, 16)
+    _check(selem, 2)
+    n = selem.shape[0]
+    if out is None:
+        out = np.zeros((n, 2), dtype=np.uint32)
+    _check(out, 2)
+    if threads > 1:
+        lib().orc_search_mt(ctypes.byref(g), _ptr(table), _ptr(selem), _ptr(out), n, threads)
+    else:
+        lib().orc_search(ctypes.byref(g), _ptr(table), _ptr(selem), _ptr(out), n)
+    return out
+
+
+def insert(g, table, blocks):
+    """blocks: list of uint32[n_b, 3] arrays, one per insert block, processed in
+    list order then index order (the canonical order)."""
+    _check(table, 16)
+    blocks = [np.ascontiguousarray(b, dtype=np.uint32).reshape(-1, 3) for b in blocks]
+    nb = len(blocks)
+    ptrs = (ctypes.c_void_p * max(nb, 1))(*[b.ctypes.data for b in blocks])
+    cnts = (ctypes.c_int * max(nb, 1))(*[b.shape[0] for b in blocks])
+    st = Stats()
+    lib().orc_insert(ctypes.byref(g), _ptr(table), ptrs, cnts, nb, ctypes.byref(st))
+    return st.as_dict()
+
+
+def delete(g, table, delem):
+    _check(table, 16)
+    _check(delem, 3)
+    st = Stats()
+    lib().orc_delete(ctypes.byref(g), _ptr(table), _ptr(delem), delem.shape[0], ctypes.byref(st))
+    return st.as_dict()

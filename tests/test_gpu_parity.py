@@ -1,0 +1,227 @@
+"""GPU parity: the HIP kernels (through the C ABI) against the CPU oracle on
+identical inputs, bit for bit -- search output words and full table images."""
+import numpy as np
+import pytest
+import torch
+
+from megakv_amd import Geometry, HashIndex, SCHEME_CUCKOO, SCHEME_2CHOICE
+from megakv_amd.lib import load_library
+from oracle import oracle as O
+from tests.gpu_util import (dev, host, ogeom, random_table, random_requests, split_blocks,
+                            run_insert_case, first_diff)
+
+pytestmark = pytest.mark.gpu
+
+SCHEMES = [SCHEME_CUCKOO, SCHEME_2CHOICE]
+
+
+def set_tuning(name, value):
+    assert load_library().mkv_set_tuning(name.encode(), value) == 0
+
+
+@pytest.fixture(autouse=True)
+def _defaults():
+    yield
+    set_tuning("update_rounds", 3)
+    set_tuning("search_u", 4)
+    set_tuning("search_nt", 0)
+
+
+# ---------------------------------------------------------------- search ----
+@pytest.mark.parametrize("n", [0, 1, 15, 16, 17, 63, 64, 65, 255, 1000, 65539])
+@pytest.mark.parametrize("mem_p", [12, 16, 22])
+def test_search_matches_oracle_ragged(n, mem_p):
+    g = Geometry(mem_p=mem_p)
+    rng = np.random.default_rng(1000 + n + mem_p)
+    img = random_table(g, rng, 0.7, sig_space=40)      # few signatures: hits and in-bucket duplicates
+    q = random_requests(g, rng, n, 40)[:, :2].copy()
+    idx = HashIndex(g)
+    idx.load_table(img)
+    for zero_miss in (True, False):
+        exp = np.zeros((n, 2), np.uint32) if zero_miss else np.full((n, 2), 0xABCD1234, np.uint32)
+        O.search(ogeom(g), img, q, out=exp)
+        out = dev(np.full((max(n, 1), 2), 0xABCD1234, np.uint32))[:n]
+        if n:
+            idx.search(dev(q), out=out, zero_miss=zero_miss)
+        torch.cuda.synchronize()
+        assert np.array_equal(host(out), exp), f"zero_miss={zero_miss}"
+
+
+@pytest.mark.parametrize("u", [1, 2, 4, 8])
+@pytest.mark.parametrize("nt", [0, 1])
+def test_search_tuning_variants_agree(u, nt):
+    set_tuning("search_u", u)
+    set_tuning("search_nt", nt)
+    g = Geometry(mem_p=20)
+    rng = np.random.default_rng(77)
+    img = random_table(g, rng, 0.5, sig_space=1000)
+    q = random_requests(g, rng, 30011, 1000)[:, :2].copy()
+    idx = HashIndex(g)
+    idx.load_table(img)
+    out = idx.search(dev(q))
+    assert np.array_equal(host(out), O.search(ogeom(g), img, q))
+
+
+def test_search_kat_image_reference_test():
+    """libgpuhash/test/back/py_search_stream.c:105-129: every query hits in both
+    buckets with loc 1."""
+    g = Geometry(mem_p=24)
+    img = np.empty((g.nbuckets, 16), np.uint32)
+    img[:, :8] = np.arange(1, 9, dtype=np.uint32)
+    img[:, 8:] = 1
+    rng = np.random.default_rng(5)
+    n = 1 << 18
+    q = np.stack([rng.integers(1, 9, size=n), rng.integers(0, g.nbuckets, size=n)], axis=1).astype(np.uint32)
+    idx = HashIndex(g)
+    idx.load_table(img)
+    out = idx.search(dev(q), zero_miss=False)
+    assert (host(out) == 1).all()
+
+
+# ---------------------------------------------------------------- delete ----
+@pytest.mark.parametrize("mem_p,n", [(12, 500), (14, 3000), (18, 20000), (20, 1)])
+def test_delete_matches_oracle(mem_p, n):
+    g = Geometry(mem_p=mem_p)
+    rng = np.random.default_rng(31 + n)
+    img = random_table(g, rng, 0.8, sig_space=30)
+    # small loc space so (sig, loc) pairs really match, with repeats in the batch
+    img[:, 8:] = np.where(img[:, :8] != 0, rng.integers(1, 4, size=(g.nbuckets, 8)), 0)
+    d = random_requests(g, rng, n, 30, hot=0.2)
+    d[:, 2] = rng.integers(1, 4, size=n)
+    exp = img.copy()
+    O.delete(ogeom(g), exp, d)
+    idx = HashIndex(g)
+    idx.load_table(img)
+    idx.delete(dev(d))
+    got = idx.table_numpy()
+    assert np.array_equal(got, exp), first_diff(got, exp)
+
+
+def test_delete_kat_image_reference_test():
+    """libgpuhash/test/back/py_delete_stream.c:100-117"""
+    g = Geometry(mem_p=20)
+    img = np.zeros((g.nbuckets, 16), np.uint32)
+    img[:, :8] = np.arange(1, 9, dtype=np.uint32)
+    rng = np.random.default_rng(6)
+    n = 4096
+    d = np.stack([rng.integers(1, 9, size=n), rng.integers(0, g.nbuckets, size=n),
+                  np.zeros(n)], axis=1).astype(np.uint32)
+    exp = img.copy()
+    O.delete(ogeom(g), exp, d)
+    idx = HashIndex(g)
+    idx.load_table(img)
+    idx.delete(dev(d))
+    assert np.array_equal(idx.table_numpy(), exp)
+
+
+# ---------------------------------------------------------------- insert ----
+CASES = [
+    # mem_p, n, fill, sig_space, hot, zero_low, zeros, blocks
+    (12, 1, 0.0, 1000, 0.0, 0.0, 0.0, "single"),
+    (12, 7, 0.5, 1000, 0.0, 0.0, 0.0, "region"),
+    (12, 300, 0.0, 50, 0.0, 0.0, 0.0, "region"),        # 64 buckets: heavy sharing, dup sigs
+    (12, 2000, 0.6, 100000, 0.1, 0.05, 0.02, "app"),     # overflow + eviction chains everywhere
+    (14, 5000, 0.9, 100000, 0.0, 0.0, 0.0, "uneven"),    # nearly full: chains, dropped victims
+    (16, 20000, 0.3, 1 << 30, 0.3, 0.0, 0.0, "region"),  # hot duplicate keys
+    (16, 20000, 0.5, 1 << 30, 0.0, 0.2, 0.01, "app"),    # alternate == primary cases
+    (20, 60000, 0.2, 1 << 31, 0.0, 0.0, 0.0, "region"),  # the reference test's regime
+    (20, 60000, 0.85, 1 << 31, 0.05, 0.0, 0.0, "single"),
+]
+
+
+@pytest.mark.parametrize("scheme", SCHEMES)
+@pytest.mark.parametrize("case", CASES, ids=lambda c: f"p{c[0]}-n{c[1]}-f{c[2]}-{c[7]}")
+def test_insert_matches_oracle(case, scheme):
+    mem_p, n, fill, sig_space, hot, zero_low, zeros, how = case
+    g = Geometry(mem_p=mem_p, scheme=scheme)
+    rng = np.random.default_rng(hash((mem_p, n, scheme)) & 0xFFFF)
+    img = random_table(g, rng, fill, min(sig_space, 2**31))
+    e = random_requests(g, rng, n, sig_space, hot, zero_low, zeros)
+    blocks = split_blocks(e, g, rng, how)
+    got, exp, info = run_insert_case(g, img, blocks)
+    assert np.array_equal(got, exp), (first_diff(got, exp), info)
+    assert sum(info["committed"]) + info["drained"] <= info["total"]
+
+
+@pytest.mark.parametrize("rounds", [1, 2, 6])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_insert_result_independent_of_round_count(rounds, scheme):
+    set_tuning("update_rounds", rounds)
+    g = Geometry(mem_p=14, scheme=scheme)
+    rng = np.random.default_rng(rounds)
+    img = random_table(g, rng, 0.7, 1 << 20)
+    e = random_requests(g, rng, 6000, 1 << 20, hot=0.2, zero_low=0.05)
+    got, exp, info = run_insert_case(g, img, split_blocks(e, g, rng, "region"))
+    assert np.array_equal(got, exp), (first_diff(got, exp), info)
+
+
+def test_insert_tail_fallback_beyond_lds_sort():
+    """> 8192 leftovers after the parallel rounds: the in-order tail walks the
+    request state array instead of sorting in LDS."""
+    set_tuning("update_rounds", 1)
+    g = Geometry(mem_p=16)
+    rng = np.random.default_rng(8)
+    e = random_requests(g, rng, 20000, 1 << 30, hot=1.0)      # 4 keys, 20000 requests
+    got, exp, info = run_insert_case(g, np.zeros((g.nbuckets, 16), np.uint32), [e])
+    assert np.array_equal(got, exp), (first_diff(got, exp), info)
+    assert info["drained"] > 8192
+
+
+def test_insert_many_batches_grow_load_factor():
+    """Repeated batches into one table up to LF 0.9 (cuckoo): every intermediate
+    table image equals the oracle's."""
+    g = Geometry(mem_p=16)
+    og = ogeom(g)
+    rng = np.random.default_rng(9)
+    idx = HashIndex(g)
+    exp = np.zeros((g.nbuckets, 16), np.uint32)
+    for step in range(9):
+        e = random_requests(g, rng, g.nbuckets * 8 // 10, 1 << 31)
+        blocks = split_blocks(e, g, rng, "region")
+        O.insert(og, exp, blocks)
+        idx.insert([dev(b) for b in blocks])
+        got = idx.table_numpy()
+        assert np.array_equal(got, exp), (step, first_diff(got, exp), idx.last_update_info())
+
+
+def test_insert_test_properties_on_gpu():
+    """libgpuhash/test/insert_test.c P1 (:178-195) and P2 (:237-244) with the
+    reference test's own parameters: 16384 requests per pass, region-confined
+    blocks, zeroed table."""
+    g = Geometry(mem_p=24)
+    idx = HashIndex(g)
+    rng = np.random.default_rng(10)
+    region = g.nbuckets // 8
+    for _ in range(6):
+        blocks = []
+        for b in range(8):
+            e = np.empty((2048, 3), np.uint32)
+            e[:, 0] = rng.integers(1, 2**31, size=2048)
+            e[:, 1] = b * region + rng.integers(0, region, size=2048)
+            e[:, 2] = rng.integers(1, 2**31, size=2048)
+            blocks.append(e)
+        allreq = np.concatenate(blocks)
+        idx.insert([dev(b) for b in blocks])
+        out = host(idx.search(dev(allreq[:, :2].copy())))
+        assert ((out[:, 0] == allreq[:, 2]) | (out[:, 1] == allreq[:, 2])).all()
+        idx.delete(dev(allreq))
+        out = host(idx.search(dev(allreq[:, :2].copy())))
+        assert not ((out[:, 0] == allreq[:, 2]) | (out[:, 1] == allreq[:, 2])).any()
+        idx.insert([dev(b) for b in blocks])
+
+
+def test_survey_recorded_eviction_on_gpu():
+    """SURVEY 8(c)(1) at the real MEM_P=30 geometry: victim 0x1003 moves from
+    bucket 0x206 to 0x1006 = inserter_hash ^ victim_sig."""
+    g = Geometry(mem_p=30)
+    idx = HashIndex(g)
+    t = idx.table.view(-1, 16)
+    for b, s0, l0 in ((5, 0x5000, 100), (0x206, 0x1000, 200)):
+        t[b, :8] = torch.arange(s0, s0 + 8, dtype=torch.int32, device="cuda")
+        t[b, 8:] = torch.arange(l0, l0 + 8, dtype=torch.int32, device="cuda")
+    idx.insert([dev(np.array([[0x203, 5, 777]], np.uint32))])
+    torch.cuda.synchronize()
+    assert t[0x206, 3].item() == 0x203 and t[0x206, 11].item() == 777
+    assert t[0x1006, 3].item() == 0x1003 and t[0x1006, 11].item() == 203
+    assert int(t[0x1205].abs().sum().item()) == 0
+    assert idx.last_update_info()["first_hard"] == 0
