@@ -1,0 +1,334 @@
+#!/usr/bin/env python3
+"""bench.py -- Mops of the batched GPU hash index on MI355X.
+
+One "step" = one pass of the hot path over one batch of 2^20 synthetic requests
+already resident in HBM, driven the way Mega-KV's scheduler drives it
+(reference src/mega_scheduler.c:393-504): clear the result buffer, search the
+GETs, insert the SETs -- through the drop-in entry points' run-time-geometry
+form (mkv_search / mkv_insert; gpu_hash_search / gpu_hash_insert are thin calls
+of them, include/libgpuhash.h).
+
+Default workload = BASELINE.json configs[2] (the one `metric` is quoted on):
+MEM_P=30 (2^30-byte table), HASH_CUCKOO, batch 2^20, 95 % GET / 5 % SET,
+Zipf-0.99 GET keys, table pre-loaded to load factor 0.2 through the insert
+kernel, K-mix keying; `--workload get100` is configs[1].
+
+  python bench.py [--gpus N] [--steps K] [--warmup W]
+  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N ...
+
+N > 1: one process per GPU, aggregate table MEM_P = 30 + log2 N sharded by the
+top bits of the bucket index, each rank feeds its own 2^20-request batches,
+requests travel to their shard and results back with RCCL all-to-all
+(megakv_amd/sharded.py).  Weak scaling.
+
+Prints ONE JSON line (rank 0).  The oracle is used only for `cpu_baseline`.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import megakv_amd as M  # noqa: E402
+from megakv_amd import workload as W  # noqa: E402
+
+HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+GET_BYTES = 144                 # 8 (request) + 2 x 64 (buckets) + 8 (result)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="zipf95", choices=["zipf95", "get100", "zipf50"])
+    ap.add_argument("--keying", default="mix", choices=["mix", "ref"])
+    ap.add_argument("--sets", default="new", choices=["new", "upd"])
+    ap.add_argument("--scheme", default="cuckoo", choices=["cuckoo", "2choice"])
+    ap.add_argument("--lf", type=float, default=0.2)
+    ap.add_argument("--batch-log2", type=int, default=20)
+    ap.add_argument("--mem-p", type=int, default=30, help="per-GPU table size (log2 bytes)")
+    ap.add_argument("--fused-zero", action="store_true",
+                    help="let the search kernel write zeros on a miss instead of a separate memset")
+    ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
+    ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--cpu-batches", type=int, default=8)
+    ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
+    return ap.parse_args()
+
+
+def dev(a, device):
+    return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(device, non_blocking=False)
+
+
+class Stream:
+    """GET/SET key streams of SURVEY 8(d) for one rank."""
+
+    def __init__(self, args, rank, world, mem_p_agg):
+        self.args = args
+        self.keying = W.KEYING_MIX if args.keying == "mix" else W.KEYING_REF
+        self.P = W.preload_count(mem_p_agg, args.lf)            # keys 1 .. P-1 are pre-loaded
+        theta = 0.0 if args.workload == "get100" else 0.99
+        # reference: mehcached_zipf_init(n = P-2, theta, seed 21); ranks differ by seed only
+        self.zipf = W.ZipfKeys(self.P - 2, theta, 21 + rank)
+        self.zipf_set = W.ZipfKeys(self.P - 2, theta, 1021 + rank)
+        n = 1 << args.batch_log2
+        self.n = n
+        frac_set = {"zipf95": 0.05, "get100": 0.0, "zipf50": 0.5}[args.workload]
+        self.n_set = int(n * frac_set)
+        self.n_get = n - self.n_set
+        # S-new: fresh sequential ids from P, a disjoint range per rank (src/mega_recv.c:671)
+        span = ((1 << 31) - 1 - self.P) // max(world, 1)
+        self.next_set = self.P + rank * span
+
+    def batch(self):
+        gets = W.make_selem(self.zipf.keys(self.n_get), self.keying)
+        if self.n_set == 0:
+            return gets, np.zeros((0, 3), np.uint32)
+        if self.args.sets == "new":
+            k = np.arange(self.next_set, self.next_set + self.n_set, dtype=np.uint64).astype(np.uint32)
+            self.next_set += self.n_set
+        else:
+            k = self.zipf_set.keys(self.n_set)
+        return gets, W.make_ielem(k, None, self.keying)
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
+        args.gpus = world
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    dist = None
+    if world > 1:
+        import torch.distributed as dist_mod
+        dist = dist_mod
+        dist.init_process_group("nccl", device_id=device)
+
+    log2w = world.bit_length() - 1
+    assert 1 << log2w == world and world <= 8, "1/2/4/8 GPUs"
+    mem_p_agg = args.mem_p + log2w
+    scheme = M.SCHEME_CUCKOO if args.scheme == "cuckoo" else M.SCHEME_2CHOICE
+
+    if world == 1:
+        from megakv_amd.index import HashIndex
+        geom = M.Geometry(mem_p=args.mem_p, scheme=scheme)
+        engine = SingleGpu(HashIndex(geom, device=device), args)
+    else:
+        from megakv_amd.sharded import ShardedIndex
+        engine = ShardedIndex(args.mem_p, world, rank, scheme, device, 1 << args.batch_log2)
+
+    stream_gen = Stream(args, rank, world, mem_p_agg)
+
+    # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
+    t0 = time.time()
+    engine.preload(stream_gen.P, stream_gen.keying)
+    torch.cuda.synchronize()
+    t_preload = time.time() - t0
+
+    # ---- distinct pre-generated batches, resident in HBM --------------------------
+    nb = args.steps + args.warmup
+    t0 = time.time()
+    batches = [engine.stage(*stream_gen.batch()) for _ in range(nb)]
+    torch.cuda.synchronize()
+    t_gen = time.time() - t0
+
+    run_stream = torch.cuda.Stream(device=device)
+    use_events = not args.no_events
+    ev = []
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    with torch.cuda.stream(run_stream):
+        engine.reserve(run_stream)
+        for b in batches[:args.warmup]:
+            engine.step(b, run_stream, None)
+        run_stream.synchronize()
+        hit_rate = engine.hit_rate(batches[args.warmup - 1]) if args.warmup else None
+        barrier()
+        t_start = time.perf_counter()
+        for b in batches[args.warmup:]:
+            pair = None
+            if use_events:
+                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                ev.append(pair)
+            engine.step(b, run_stream, pair)
+        run_stream.synchronize()
+    barrier()
+    elapsed = time.perf_counter() - t_start
+    if dist is not None:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    n_ops = (1 << args.batch_log2) * args.steps * world
+    value = n_ops / elapsed / 1e6
+
+    roofline = None
+    if use_events and ev:
+        ms = np.array([a.elapsed_time(b) for a, b in ev])
+        avg_s = float(ms.mean()) * 1e-3
+        algo_bytes = GET_BYTES * engine.search_requests_per_launch(stream_gen)
+        achieved = algo_bytes / avg_s / 1e9
+        roofline = {"bound": "hbm", "kernel": "mkv::k_search", "achieved": round(achieved, 1),
+                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
+                    "traffic": load_traffic(args), "algorithmic_bytes_per_launch": algo_bytes,
+                    "avg_launch_us": round(avg_s * 1e6, 2), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
+                    "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2)}
+
+    cpu = None
+    if rank == 0 and world == 1 and not args.no_cpu:
+        cpu = cpu_baseline(engine, stream_gen, args)
+
+    if rank == 0:
+        line = {
+            "metric": "Mops (search+insert) on Zipf-0.99, 2^30-B table, 1/2/4/8 GPUs; HBM GB/s vs roofline",
+            "value": round(value, 1), "unit": "Mops", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": round(elapsed / args.steps * 1e3, 5),
+            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u32",
+            "data": "synthetic",
+            "config": {"workload": {"zipf95": "BASELINE configs[2]: 95/5 GET/SET Zipf-0.99",
+                                    "get100": "BASELINE configs[1]: 100% GET uniform",
+                                    "zipf50": "BASELINE configs[3]: 50/50 GET/SET Zipf-0.99"}[args.workload],
+                       "mem_p_per_gpu": args.mem_p, "mem_p_aggregate": mem_p_agg, "scheme": args.scheme,
+                       "batch": 1 << args.batch_log2, "gets": stream_gen.n_get, "sets": stream_gen.n_set,
+                       "keying": "K-" + args.keying, "set_keys": "S-" + args.sets, "load_factor": args.lf,
+                       "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "fused" if args.fused_zero else "memset",
+                       "sharding": "single table" if world == 1 else f"{world} shards by top bucket bits, RCCL all-to-all",
+                       "launch": "hipGraph" if args.graph else "eager"},
+            "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu,
+            "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
+        }
+        print(json.dumps(line), flush=True)
+    if dist is not None:
+        dist.destroy_process_group()
+
+
+class SingleGpu:
+    def __init__(self, index, args):
+        self.idx = index
+        self.args = args
+        self.device = index.device
+        self.graphs = {}
+
+    def preload(self, P, keying):
+        g = self.idx.geom
+        step = 1 << 20
+        self.idx.reserve(step + 8)
+        for lo in range(1, P, step):
+            k = np.arange(lo, min(lo + step, P), dtype=np.uint32)
+            blocks = W.bin_inserts(W.make_ielem(k, None, keying), g.mem_p, g.iblock_p, W.BIN_REGION)
+            self.idx.insert([dev(b, self.device) for b in blocks])
+        torch.cuda.synchronize()
+
+    def stage(self, gets, sets):
+        g = self.idx.geom
+        b = {"q": dev(gets, self.device),
+             "out": torch.empty((gets.shape[0], 2), dtype=torch.int32, device=self.device)}
+        if sets.shape[0]:
+            blocks = [dev(x, self.device) for x in W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION)]
+            b["ptrs"], b["cnts"], b["keep"] = self.idx.stage_blocks(blocks)
+        return b
+
+    def search_requests_per_launch(self, sg):
+        return sg.n_get
+
+    def reserve(self, stream):
+        self.idx.reserve((1 << self.args.batch_log2) + 8, stream)
+
+    def hit_rate(self, b):
+        o = b["out"]
+        return round(float(((o[:, 0] != 0) | (o[:, 1] != 0)).float().mean().item()), 6)
+
+    def _launch(self, b, stream, pair):
+        if not self.args.fused_zero:
+            b["out"].zero_()                                   # the caller's cudaMemsetAsync
+        if pair:
+            pair[0].record(stream)
+        self.idx.search(b["q"], out=b["out"], zero_miss=self.args.fused_zero, stream=stream)
+        if pair:
+            pair[1].record(stream)
+        if "ptrs" in b:
+            self.idx.insert_staged(b["ptrs"], b["cnts"], len(b["keep"]), stream)
+
+    def step(self, b, stream, pair):
+        if not self.args.graph:
+            self._launch(b, stream, pair)
+            return
+        key = id(b)
+        if key not in self.graphs:
+            gr = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gr, stream=stream):
+                self._launch(b, torch.cuda.current_stream(), None)
+            self.graphs[key] = gr
+        if pair:
+            pair[0].record(stream)
+        self.graphs[key].replay()
+        if pair:
+            pair[1].record(stream)
+
+    def table_host(self):
+        return self.idx.table_numpy()
+
+
+def load_traffic(args):
+    """HBM bytes per search launch from the rocprofv3 PMC passes of this same
+    command (profiles/make_traffic.py writes the file); null when absent."""
+    p = os.path.join(ROOT, "profiles", "search_traffic.json")
+    try:
+        d = json.load(open(p))
+        key = f"{args.workload}-{args.keying}"
+        return d.get(key, {}).get("hbm_bytes_per_launch")
+    except Exception:
+        return None
+
+
+def cpu_baseline(engine, sg, args):
+    """The CPU oracle (a port: the reference has no CPU index path) on the
+    host's cores, same table image, a bounded sample of the same workload."""
+    from oracle import oracle as O
+    scheme = O.SCHEME_CUCKOO if args.scheme == "cuckoo" else O.SCHEME_2CHOICE
+    og = O.geom(mem_p=args.mem_p, scheme=scheme)
+    table = np.ascontiguousarray(engine.table_host())
+    nb = max(1, args.cpu_batches)
+    work = [sg.batch() for _ in range(nb)]
+    g = engine.idx.geom
+    t0 = time.perf_counter()
+    ops = 0
+    for gets, sets in work:
+        out = np.zeros((gets.shape[0], 2), np.uint32)           # the memset
+        O.search(og, table, gets, out=out)
+        if sets.shape[0]:
+            O.insert(og, table, W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION))
+        ops += gets.shape[0] + sets.shape[0]
+    dt = time.perf_counter() - t0
+    one = ops / dt / 1e6
+    ncpu = min(os.cpu_count() or 1, 64)
+    gets = work[0][0]
+    t0 = time.perf_counter()
+    for gets, _ in work:
+        O.search(og, table, gets, threads=ncpu)
+    mt = sum(w[0].shape[0] for w in work) / (time.perf_counter() - t0) / 1e6
+    return {"value": round(one, 2), "unit": "Mops", "cores": 1, "kind": "port",
+            "sample": f"{nb} batches of 2^{args.batch_log2} requests of the same workload, same table image, "
+                      f"single thread in canonical order ({dt:.1f} s)",
+            "search_only_all_threads": {"value": round(mt, 1), "threads": ncpu}}
+
+
+if __name__ == "__main__":
+    main()

@@ -65,11 +65,13 @@ void mkv_release_all(void);
 /* Diagnostics of the most recent insert/delete on `stream` (synchronises the
  * stream).  Not part of the hot path. */
 typedef struct mkv_update_info_s {
-	uint32_t total;			/* requests in the call */
-	uint32_t committed[6];	/* requests finished by parallel round 1..6 */
-	uint32_t drained;		/* requests finished by the in-order tail */
-	uint32_t first_hard;	/* lowest request index that needed an eviction chain, or 0xffffffff */
-	uint32_t rounds;		/* parallel rounds enqueued */
+	uint32_t total;			/* requests in the call (0xffffffff: over the reserved capacity, nothing done) */
+	uint32_t round1;		/* finished by the first grid-wide round */
+	uint32_t round2;		/* finished by the second grid-wide round */
+	uint32_t tail_parallel;	/* finished by the rounds inside the tail work-group */
+	uint32_t tail_serial;	/* replayed one by one in canonical order */
+	uint32_t undone;		/* optimistic commits rolled back behind an eviction barrier */
+	uint32_t first_hard;	/* lowest request index found needing an eviction chain, or 0xffffffff */
 } mkv_update_info_t;
 
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);
@@ -88,8 +90,8 @@ int mkv_unroute_results(const loc_t *routed, const int32_t *perm, int64_t num_el
 		loc_t *out, void *stream);
 
 /* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
- * "search_nt" (non-temporal table loads), "update_rounds" (1..6 parallel
- * rounds before the in-order tail), "req_cap" (default requests per update
+ * "search_nt" (non-temporal table loads), "tail_rounds" (0..12 reservation
+ * rounds inside the tail work-group), "req_cap" (default requests per update
  * call).  Results never depend on them; they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);
 

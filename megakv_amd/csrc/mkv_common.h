@@ -26,7 +26,7 @@ struct DevGeom {
 
 inline bool make_dev_geom(const mkv_geom_t *g, DevGeom *d)
 {
-	if (!g || g->mem_p < 6 + g->iblock_p || g->mem_p > 37 || g->iblock_p > 5)
+	if (!g || g->mem_p < 6 + g->iblock_p || g->mem_p > 33 || g->iblock_p > 5)
 		return false;
 	if (g->scheme != MKV_SCHEME_CUCKOO && g->scheme != MKV_SCHEME_2CHOICE)
 		return false;
@@ -69,12 +69,12 @@ __device__ __forceinline__ uint32_t preferred_slot(uint32_t empties, uint32_t or
 }
 
 // Process-wide tuning knobs (defaults = measured best on MI355X).
-// Initialised from MKV_SEARCH_U / MKV_SEARCH_NT / MKV_UPDATE_ROUNDS /
+// Initialised from MKV_SEARCH_U / MKV_SEARCH_NT / MKV_TAIL_ROUNDS /
 // MKV_REQ_CAP on first use, changeable through mkv_set_tuning().
 struct Tuning {
 	int search_u;        // requests in flight per 4-lane group: 1, 2, 4 or 8
 	int search_nt;       // non-temporal table loads in search
-	int update_rounds;   // parallel reservation rounds before the in-order tail
+	int tail_rounds;     // reservation rounds inside the tail work-group (0..12)
 	long long req_cap;   // default request capacity of an update workspace
 };
 Tuning &tuning();

@@ -143,10 +143,10 @@ Tuning &tuning()
 			v.search_u = 4;
 		s = getenv("MKV_SEARCH_NT");
 		v.search_nt = s ? atoi(s) != 0 : 0;
-		s = getenv("MKV_UPDATE_ROUNDS");
-		v.update_rounds = s ? atoi(s) : 3;
-		if (v.update_rounds < 1) v.update_rounds = 1;
-		if (v.update_rounds > 6) v.update_rounds = 6;
+		s = getenv("MKV_TAIL_ROUNDS");
+		v.tail_rounds = s ? atoi(s) : 12;
+		if (v.tail_rounds < 0) v.tail_rounds = 0;
+		if (v.tail_rounds > 12) v.tail_rounds = 12;
 		s = getenv("MKV_REQ_CAP");
 		v.req_cap = s ? atoll(s) : (1ll << 22);
 		if (v.req_cap < 1024) v.req_cap = 1024;
@@ -191,10 +191,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.search_u = (int)value;
 	} else if (!strcmp(name, "search_nt")) {
 		t.search_nt = value != 0;
-	} else if (!strcmp(name, "update_rounds")) {
-		if (value < 1 || value > 6)
+	} else if (!strcmp(name, "tail_rounds")) {
+		if (value < 0 || value > 12)
 			return MKV_EINVAL;
-		t.update_rounds = (int)value;
+		t.tail_rounds = (int)value;
 	} else if (!strcmp(name, "req_cap")) {
 		if (value < 1024)
 			return MKV_EINVAL;

@@ -12,32 +12,38 @@
 // HOW.  A request's reach is static except for the cuckoo eviction chain: it
 // touches its primary bucket P and at most its alternate bucket A, both known
 // from the request alone; only a request that finds P and A full with no
-// duplicate ("hard") walks on to data-dependent buckets.  Requests therefore
-// commute unless they share P/A, and the work proceeds in reservation rounds:
+// duplicate ("hard") walks on to data-dependent buckets of its region.
+// Requests commute unless they share P/A, so the work is done in reservation
+// rounds over a per-bucket owner table in HBM (64-bit atomicMin of
+// {round stamp, canonical index}; stamps make stale entries lose, the table is
+// never cleared):
 //
-//   mark    every pending request writes its canonical index into owner[P] and
-//           owner[A] with a 64-bit atomicMin (per-bucket side table in HBM, one
-//           random atomic per bucket touched; a round stamp in the high word
-//           makes stale entries lose, so the tables are never cleared);
-//   decide  (cuckoo only) finds, per closed region, the lowest pending index
-//           that is hard, or that might become hard before its turn (it lost a
-//           reservation, holds no duplicate, and the empty slots of P and A do
-//           not outnumber the other requests registered there).  Nothing at or
-//           beyond that index may commit this round: an eviction chain may
-//           reach any bucket of its region;
-//   commit  every request that owns all its buckets (no earlier pending
-//           request touches them) and lies below the region's barrier executes
-//           against the table with plain loads/stores -- it has exclusive
-//           use of those buckets in this round -- and the rest re-register
-//           for the next round in the other owner table;
-//   tail    after a fixed number of rounds one work-group sorts what is left by
-//           canonical index (LDS bitonic sort) and replays it in order,
-//           eviction chains included.
+//   K1 mark     every request registers on P and A (two atomics) and is copied
+//               into a 16-byte request cache so later passes do not chase the
+//               caller's block pointers again.
+//   K2 round 1  a request that owns all its buckets (no earlier pending request
+//               touches them) executes with plain loads/stores -- it has
+//               exclusive use of those buckets -- and logs what it overwrote;
+//               losers re-register for round 2 and bump a registrant count on
+//               the buckets they lost.
+//   K3 round 2  the same over the losers.  It also classifies them: a loser
+//               might turn hard before its turn unless it holds a duplicate or
+//               the empty slots of P and A outnumber the other registrants.
+//   barrier     hard requests, and losers that might turn hard, publish their
+//               index into a per-region minimum B: an eviction chain may reach
+//               any bucket of the region, so nothing at or beyond B may run
+//               before it.  Commits are optimistic: K4 first rolls back (from
+//               the log) every commit at or beyond the final B.
+//   K4 tail     one 1024-lane work-group runs further rounds over what is left
+//               (same rule, decide-then-commit with work-group barriers), then
+//               sorts the remainder by canonical index in LDS and replays it in
+//               order, eviction chains included.
 //
-// Why that equals the canonical order is argued in DESIGN.md ("insert:
-// proof sketch").  No host synchronisation: the request counts are read on
-// the device (the reference passes them as a device array, gpu_hash.cu:236-237)
-// and every kernel grid-strides over them.
+// Why this equals the canonical order: DESIGN.md, "insert: why the result is
+// the canonical one".  No host synchronisation anywhere: request counts are
+// read on the device (the reference passes them as a device array,
+// gpu_hash.cu:236-237), grids are fixed and stride over them, and the round
+// stamps live on the device so a captured hipGraph can be replayed.
 //
 // The per-lane atomicCAS the north star suggests for slot claims is not needed:
 // exclusivity comes from the reservation, so a commit is two plain stores.
@@ -48,98 +54,138 @@
 
 namespace mkv {
 
-constexpr int kMaxBlocks = 1024;   // insert blocks per call
+constexpr int kMaxBlocks = 1024;    // insert blocks per call
 constexpr int kMaxRegions = 32;
-constexpr int kMaxRounds = 6;
-constexpr int kSortCap = 8192;     // tail requests sorted in LDS; beyond: state scan
+constexpr int kMaxTailRounds = 12;  // in-work-group rounds of the tail
+constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;
+constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
 constexpr uint32_t kGridAll = 1024;
-constexpr uint32_t kGridList = 512;
+constexpr uint32_t kGridList = 256;
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 
+// request state
+constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3;
+
+// Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
+// (request index in the owner tables, registrant count in the count table).
+constexpr int kIdxBits = 24;
+constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1;
+constexpr unsigned long long kStampMax = (1ull << 40) - 1;
+constexpr int64_t kMaxReqCap = (1ll << kIdxBits) - 16;
+
+struct Info {
+	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow;
+};
+
 struct Ctl {
+	unsigned long long next_stamp;   // persists across calls
+	unsigned long long stamp_base;   // stamp of round 1 of the current call
 	uint32_t total;
 	uint32_t overflow;
-	uint32_t list_n[2];
-	uint32_t committed[kMaxRounds];
-	uint32_t drained;
+	uint32_t list_n[2];              // [0] losers of round 1, [1] work left for the tail
+	uint32_t committed[2];
 	uint32_t first_hard;
-	uint32_t barrier[kMaxRounds][kMaxRegions];
-	uint32_t blk_prefix[kMaxBlocks + 1];
+	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
+	Info last;                       // snapshot of the previous call, for diagnostics
 };
 
 struct Req {
 	uint32_t sig, hash, loc;
 };
 
-// Where the requests live: insert = device array of per-block device arrays
-// (reference ABI), delete = one array.
 struct ReqSrc {
-	const uint32_t *const *blk_input;
-	const uint32_t *single;
+	const uint32_t *const *blk_input;   // insert: device array of per-block arrays
+	const uint32_t *single;             // delete: one array
+	const int *blk_elem_num;
+	long long single_n;
 	uint32_t nblk;
 };
 
-__device__ __forceinline__ Req load_req(const ReqSrc &src, const Ctl *ctl, uint32_t idx)
+// ---- coherent access helpers ---------------------------------------------------
+// Inside the tail work-group values written with atomics (owner / count tables)
+// or by other waves of the group are read back: those loads bypass the L1.
+__device__ __forceinline__ unsigned long long ld_agent(const unsigned long long *p)
 {
-	const uint32_t *p;
-	if (src.single) {
-		p = src.single + 3ull * idx;
-	} else {
-		uint32_t b = 0;
-		while (b + 1 < src.nblk && ctl->blk_prefix[b + 1] <= idx)
-			b++;
-		p = src.blk_input[b] + 3ull * (idx - ctl->blk_prefix[b]);
-	}
-	Req r;
-	r.sig = p[0];
-	r.hash = p[1];
-	r.loc = p[2];
-	return r;
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// ---- table access helpers ---------------------------------------------------
+__device__ __forceinline__ uint32_t ld_agent32(const uint32_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+template <bool COHERENT>
 __device__ __forceinline__ void load_sig_row(const uint32_t *table, uint32_t b, uint4 &lo, uint4 &hi)
 {
-	const uint4 *p = reinterpret_cast<const uint4 *>(table + (uint64_t)b * kBucketWords);
-	lo = p[0];
-	hi = p[1];
+	const uint32_t *w = table + (uint64_t)b * kBucketWords;
+	if (COHERENT) {
+		const unsigned long long *q = reinterpret_cast<const unsigned long long *>(w);
+		const unsigned long long a0 = ld_agent(q), a1 = ld_agent(q + 1), a2 = ld_agent(q + 2),
+				a3 = ld_agent(q + 3);
+		lo = make_uint4((uint32_t)a0, (uint32_t)(a0 >> 32), (uint32_t)a1, (uint32_t)(a1 >> 32));
+		hi = make_uint4((uint32_t)a2, (uint32_t)(a2 >> 32), (uint32_t)a3, (uint32_t)(a3 >> 32));
+	} else {
+		const uint4 *p = reinterpret_cast<const uint4 *>(w);
+		lo = p[0];
+		hi = p[1];
+	}
 }
 
-__device__ __forceinline__ void load_loc_row(const uint32_t *table, uint32_t b, uint4 &lo, uint4 &hi)
+template <bool COHERENT>
+__device__ __forceinline__ uint32_t load_word(const uint32_t *table, uint64_t word)
 {
-	const uint4 *p = reinterpret_cast<const uint4 *>(table + (uint64_t)b * kBucketWords);
-	lo = p[2];
-	hi = p[3];
+	return COHERENT ? ld_agent32(table + word) : table[word];
 }
 
-__device__ __forceinline__ void store_sig(uint32_t *table, uint32_t b, uint32_t slot, uint32_t v)
+__device__ __forceinline__ uint64_t sig_word(uint32_t b, uint32_t slot)
 {
-	table[(uint64_t)b * kBucketWords + slot] = v;
+	return (uint64_t)b * kBucketWords + slot;
 }
 
-__device__ __forceinline__ void store_loc(uint32_t *table, uint32_t b, uint32_t slot, uint32_t v)
+__device__ __forceinline__ uint64_t loc_word(uint32_t b, uint32_t slot)
 {
-	table[(uint64_t)b * kBucketWords + kSlots + slot] = v;
+	return (uint64_t)b * kBucketWords + kSlots + slot;
 }
+
+// What a commit overwrote, so it can be rolled back: up to two words
+// (word indices fit 32 bits: mem_p <= 33).
+struct Undo {
+	uint32_t word0, old0, word1, old1;
+};
+constexpr uint32_t kNoWord = 0xffffffffu;
 
 // Duplicate -> overwrite loc; else empty -> claim; returns true when finished.
 // `pref_sig` is the ORIGINAL request's signature (slot preference, ref :301).
+template <bool COHERENT, bool LOG>
 __device__ __forceinline__ bool try_place(uint32_t *table, uint32_t b, uint32_t sig, uint32_t loc,
-		uint32_t pref_sig)
+		uint32_t pref_sig, Undo *u)
 {
 	uint4 lo, hi;
-	load_sig_row(table, b, lo, hi);
-	uint32_t m = eq_mask(lo, hi, sig);
+	load_sig_row<COHERENT>(table, b, lo, hi);
+	const uint32_t m = eq_mask(lo, hi, sig);
 	if (m) {
-		store_loc(table, b, (uint32_t)__ffs((int)m) - 1u, loc);
+		const uint64_t w = loc_word(b, (uint32_t)__ffs((int)m) - 1u);
+		if (LOG) {
+			u->word0 = (uint32_t)w;
+			u->old0 = load_word<COHERENT>(table, w);
+			u->word1 = kNoWord;
+		}
+		table[w] = loc;
 		return true;
 	}
-	uint32_t e = eq_mask(lo, hi, 0u);
+	const uint32_t e = eq_mask(lo, hi, 0u);
 	if (e) {
-		uint32_t s = preferred_slot(e, pref_sig);
-		store_sig(table, b, s, sig);
-		store_loc(table, b, s, loc);
+		const uint32_t s = preferred_slot(e, pref_sig);
+		const uint64_t ws = sig_word(b, s), wl = loc_word(b, s);
+		if (LOG) {
+			u->word0 = (uint32_t)ws;
+			u->old0 = 0u;
+			u->word1 = (uint32_t)wl;
+			u->old1 = load_word<COHERENT>(table, wl);   // a deleted entry's loc stays behind (ref :461-463)
+		}
+		table[ws] = sig;
+		table[wl] = loc;
 		return true;
 	}
 	return false;
@@ -147,42 +193,41 @@ __device__ __forceinline__ bool try_place(uint32_t *table, uint32_t b, uint32_t 
 
 // delete in one bucket: zero the signature of every slot holding (sig, loc);
 // returns whether any matched (ref gpu_hash.cu:459-468).
+template <bool COHERENT>
 __device__ __forceinline__ bool delete_in(uint32_t *table, uint32_t b, uint32_t sig, uint32_t loc)
 {
-	uint4 slo, shi, llo, lhi;
-	load_sig_row(table, b, slo, shi);
+	uint4 slo, shi;
+	load_sig_row<COHERENT>(table, b, slo, shi);
 	uint32_t m = eq_mask(slo, shi, sig);
-	if (!m)
-		return false;
-	load_loc_row(table, b, llo, lhi);
-	m &= eq_mask(llo, lhi, loc);
-	uint32_t mm = m;
-	while (mm) {
-		uint32_t s = (uint32_t)__ffs((int)mm) - 1u;
-		store_sig(table, b, s, 0u);
-		mm &= mm - 1u;
+	bool any = false;
+	while (m) {
+		const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+		m &= m - 1u;
+		if (load_word<COHERENT>(table, loc_word(b, s)) == loc) {
+			table[sig_word(b, s)] = 0u;
+			any = true;
+		}
 	}
-	return m != 0u;
+	return any;
 }
 
 // A request whose reach is static.  Returns false (nothing written) only for a
-// cuckoo request that turns out to need an eviction chain.
-template <Op OP>
-__device__ __forceinline__ bool apply_static(uint32_t *table, const DevGeom &g, const Req &r,
-		uint32_t P, uint32_t A)
+// cuckoo request that needs an eviction chain.
+template <Op OP, bool COHERENT, bool LOG>
+__device__ __forceinline__ bool apply_static(uint32_t *table, const Req &r, uint32_t P, uint32_t A, Undo *u)
 {
 	if (OP == OP_DELETE) {
-		if (!delete_in(table, P, r.sig, r.loc))
-			delete_in(table, A, r.sig, r.loc);
+		if (!delete_in<COHERENT>(table, P, r.sig, r.loc))
+			delete_in<COHERENT>(table, A, r.sig, r.loc);
 		return true;
 	}
-	if (try_place(table, P, r.sig, r.loc, r.sig))
+	if (try_place<COHERENT, LOG>(table, P, r.sig, r.loc, r.sig, u))
 		return true;
-	if (try_place(table, A, r.sig, r.loc, r.sig))
+	if (try_place<COHERENT, LOG>(table, A, r.sig, r.loc, r.sig, u))
 		return true;
 	if (OP == OP_2CHOICE) {
-		// no room: signature alone replaces slot sig&7, stale loc stays (ref :197-209)
-		store_sig(table, A, r.sig & 7u, r.sig);
+		// no room: the signature alone replaces slot sig&7, stale loc stays (ref :197-209)
+		table[sig_word(A, r.sig & 7u)] = r.sig;
 		return true;
 	}
 	return false;
@@ -194,62 +239,62 @@ __device__ void apply_serial(uint32_t *table, const DevGeom &g, const Req &r)
 {
 	const uint32_t P = r.hash & g.hash_mask;
 	const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-	if (apply_static<OP>(table, g, r, P, A))
+	if (apply_static<OP, true, false>(table, r, P, A, nullptr))
 		return;
 	// cuckoo, P and A full without duplicate (ref :357-423)
 	uint32_t sig = r.sig, loc = r.loc, b = A;
 	const uint32_t v = r.sig & 7u;          // victim slot: ORIGINAL signature (:360)
 	for (uint32_t k = 0;; k++) {
-		const uint32_t vsig = table[(uint64_t)b * kBucketWords + v];
-		const uint32_t vloc = table[(uint64_t)b * kBucketWords + kSlots + v];
-		store_sig(table, b, v, sig);
-		store_loc(table, b, v, loc);
+		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
+		const uint32_t vloc = ld_agent32(table + loc_word(b, v));
+		table[sig_word(b, v)] = sig;
+		table[loc_word(b, v)] = loc;
 		if (k >= g.max_cuckoo)
 			return;                         // victim dropped (:414-423)
 		sig = vsig;
 		loc = vloc;
 		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
-		if (try_place(table, b, sig, loc, r.sig))
+		if (try_place<true, false>(table, b, sig, loc, r.sig, nullptr))
 			return;
 	}
 }
 
-// ---- reservation tables -----------------------------------------------------
-__device__ __forceinline__ void bump(unsigned long long *cnt, uint32_t b, uint32_t stamp_inc)
+__device__ __forceinline__ Req req_of(const uint4 &rc)
 {
-	atomicMax(&cnt[b], (unsigned long long)stamp_inc << 32);
+	Req r;
+	r.sig = rc.x;
+	r.hash = rc.y;
+	r.loc = rc.z;
+	return r;
+}
+
+// ---- reservation tables -----------------------------------------------------
+__device__ __forceinline__ void bump(unsigned long long *cnt, uint32_t b, unsigned long long stamp)
+{
+	atomicMax(&cnt[b], stamp << kIdxBits);   // a stale entry restarts at (stamp, 0)
 	atomicAdd(&cnt[b], 1ull);
 }
 
-__device__ __forceinline__ uint32_t read_cnt(const unsigned long long *cnt, uint32_t b, uint32_t stamp_inc)
+__device__ __forceinline__ uint32_t cnt_of(unsigned long long v, unsigned long long stamp)
 {
-	unsigned long long v = cnt[b];
-	return (uint32_t)(v >> 32) == stamp_inc ? (uint32_t)v : 0u;
+	return (v >> kIdxBits) == stamp ? (uint32_t)(v & kIdxMask) : 0u;
 }
 
-template <Op OP>
-__device__ __forceinline__ void register_req(unsigned long long *owner, unsigned long long *cnt,
-		uint32_t P, uint32_t A, uint32_t idx, uint32_t stamp_min, uint32_t stamp_inc)
+// owner key of request idx in the round stamped `stamp`: newer rounds compare lower
+__device__ __forceinline__ unsigned long long owner_key(unsigned long long stamp, uint32_t idx)
 {
-	const unsigned long long key = ((unsigned long long)stamp_min << 32) | idx;
+	return ((kStampMax - stamp) << kIdxBits) | idx;
+}
+
+__device__ __forceinline__ void reserve(unsigned long long *owner, uint32_t P, uint32_t A,
+		unsigned long long key)
+{
 	atomicMin(&owner[P], key);
 	if (A != P)
 		atomicMin(&owner[A], key);
-	if (OP == OP_CUCKOO) {
-		bump(cnt, P, stamp_inc);
-		if (A != P)
-			bump(cnt, A, stamp_inc);
-	}
 }
 
-__device__ __forceinline__ bool is_clean(const unsigned long long *owner, uint32_t P, uint32_t A,
-		uint32_t idx, uint32_t stamp_min)
-{
-	const unsigned long long key = ((unsigned long long)stamp_min << 32) | idx;
-	return owner[P] == key && (A == P || owner[A] == key);
-}
-
-// wave-aggregated append; returns nothing, order inside the list is arbitrary
+// wave-aggregated append; order inside the list is arbitrary
 __device__ __forceinline__ void list_append(uint32_t *list, uint32_t *list_n, bool want, uint32_t idx)
 {
 	const unsigned long long mask = __ballot(want);
@@ -272,211 +317,422 @@ __device__ __forceinline__ void count_add(uint32_t *ctr, bool flag)
 		atomicAdd(ctr, (uint32_t)__popcll(mask));
 }
 
-// ---- kernels ----------------------------------------------------------------
-__global__ void k_prep(Ctl *ctl, const int *blk_elem_num, int nblk, long long single_n,
-		uint32_t req_cap)
-{
-	const uint32_t t = threadIdx.x;
-	if (t == 0) {
-		unsigned long long sum = 0;
-		ctl->blk_prefix[0] = 0;
-		if (blk_elem_num) {
-			for (int b = 0; b < nblk; b++) {
-				int c = blk_elem_num[b];
-				sum += c > 0 ? (unsigned long long)c : 0ull;
-				ctl->blk_prefix[b + 1] = (uint32_t)(sum > 0xfffffffeull ? 0xfffffffeull : sum);
-			}
-		} else {
-			sum = single_n > 0 ? (unsigned long long)single_n : 0ull;
-		}
-		const bool over = sum > req_cap;
-		ctl->overflow = over ? 1u : 0u;
-		ctl->total = over ? 0u : (uint32_t)sum;
-		ctl->list_n[0] = 0;
-		ctl->list_n[1] = 0;
-		ctl->drained = 0;
-		ctl->first_hard = kNone;
-	}
-	for (uint32_t i = t; i < kMaxRounds * kMaxRegions; i += blockDim.x)
-		(&ctl->barrier[0][0])[i] = kNone;
-	if (t < kMaxRounds)
-		ctl->committed[t] = 0;
-}
-
-// round 1: every request registers
+// ---- K1: mark -----------------------------------------------------------------
 template <Op OP>
-__global__ __launch_bounds__(256) void k_mark_all(Ctl *ctl, ReqSrc src, DevGeom g,
-		unsigned long long *owner, unsigned long long *cnt, uint8_t *state,
-		uint32_t stamp_min, uint32_t stamp_inc)
+__global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
+		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
 {
-	const uint32_t total = ctl->total;
-	for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-			idx += gridDim.x * blockDim.x) {
-		const Req r = load_req(src, ctl, idx);
-		if (OP != OP_DELETE && r.sig == 0u && r.loc == 0u) {
-			state[idx] = 1;                 // skipped by the reference too (:259-262)
-			continue;
+	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
+	__shared__ uint32_t s_total;
+	const uint32_t t = threadIdx.x;
+	const uint32_t nblk = src.nblk;
+	if (src.single) {
+		if (t == 0) {
+			const unsigned long long n = src.single_n > 0 ? (unsigned long long)src.single_n : 0ull;
+			s_prefix[0] = 0;
+			s_total = n > req_cap ? kNone : (uint32_t)n;
 		}
-		state[idx] = 0;
-		const uint32_t P = r.hash & g.hash_mask;
-		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-		register_req<OP>(owner, cnt, P, A, idx, stamp_min, stamp_inc);
+	} else {
+		for (uint32_t b = t; b < nblk; b += blockDim.x) {
+			const int c = src.blk_elem_num[b];
+			s_prefix[b + 1] = c > 0 ? (uint32_t)c : 0u;
+		}
+		__syncthreads();
+		if (t == 0) {
+			unsigned long long sum = 0;
+			s_prefix[0] = 0;
+			for (uint32_t b = 0; b < nblk; b++) {
+				sum += s_prefix[b + 1];
+				s_prefix[b + 1] = (uint32_t)(sum > 0xfffffff0ull ? 0xfffffff0ull : sum);
+			}
+			s_total = sum > req_cap ? kNone : (uint32_t)sum;
+		}
 	}
-}
-
-// cuckoo: per-region barrier index of this round
-template <bool FROM_LIST>
-__global__ __launch_bounds__(256) void k_decide(Ctl *ctl, ReqSrc src, DevGeom g,
-		const uint32_t *table, const unsigned long long *owner, const unsigned long long *cnt,
-		const uint8_t *state, const uint32_t *list, int list_sel, int round,
-		uint32_t stamp_min, uint32_t stamp_inc)
-{
-	const uint32_t count = FROM_LIST ? ctl->list_n[list_sel] : ctl->total;
-	for (uint32_t i = blockIdx.x * blockDim.x + threadIdx.x; i < count;
-			i += gridDim.x * blockDim.x) {
-		uint32_t idx = i;
-		if (FROM_LIST)
-			idx = list[i];
-		else if (state[idx])
-			continue;
-		const Req r = load_req(src, ctl, idx);
-		const uint32_t P = r.hash & g.hash_mask;
-		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-		uint4 lo, hi;
-		load_sig_row(table, P, lo, hi);
-		if (eq_mask(lo, hi, r.sig))
-			continue;                       // duplicate in P: finishes in P whenever it runs
-		const uint32_t eP = (uint32_t)__popc(eq_mask(lo, hi, 0u));
-		const bool clean = is_clean(owner, P, A, idx, stamp_min);
-		if (clean && eP)
-			continue;
-		uint32_t eA = 0;
-		if (A != P) {
-			load_sig_row(table, A, lo, hi);
-			if (eq_mask(lo, hi, r.sig))
-				continue;                   // duplicate in A: never goes past A
-			eA = (uint32_t)__popc(eq_mask(lo, hi, 0u));
-		}
-		bool bad;
-		if (clean) {
-			bad = (eP + eA) == 0u;          // hard right now
-			if (bad)
-				atomicMin(&ctl->first_hard, idx);
+	__syncthreads();
+	const bool over = s_total == kNone;
+	const uint32_t total = over ? 0u : s_total;
+	if (blockIdx.x == 0 && t == 0) {
+		ctl->total = total;
+		ctl->overflow = over ? 1u : 0u;
+	}
+	const unsigned long long stamp = ctl->stamp_base;
+	for (uint32_t idx = blockIdx.x * blockDim.x + t; idx < total; idx += gridDim.x * blockDim.x) {
+		const uint32_t *p;
+		if (src.single) {
+			p = src.single + 3ull * idx;
 		} else {
-			// other requests registered on P / A can each take one empty slot
-			uint32_t others = read_cnt(cnt, P, stamp_inc) - 1u;
-			if (A != P)
-				others += read_cnt(cnt, A, stamp_inc) - 1u;
-			bad = (eP + eA) < 1u + others;
+			uint32_t lo = 0, hi = nblk;             // block b: prefix[b] <= idx < prefix[b+1]
+			while (hi - lo > 1) {
+				const uint32_t mid = (lo + hi) >> 1;
+				if (s_prefix[mid] <= idx)
+					lo = mid;
+				else
+					hi = mid;
+			}
+			p = src.blk_input[lo] + 3ull * (idx - s_prefix[lo]);
 		}
-		if (bad)
-			atomicMin(&ctl->barrier[round][P >> g.region_shift], idx);
+		Req r;
+		r.sig = p[0];
+		r.hash = p[1];
+		r.loc = p[2];
+		reqc[idx] = make_uint4(r.sig, r.hash, r.loc, 0u);
+		if (OP != OP_DELETE && r.sig == 0u && r.loc == 0u) {
+			state[idx] = ST_DONE;               // skipped by the reference too (:259-262)
+			continue;
+		}
+		state[idx] = ST_PENDING;
+		const uint32_t P = r.hash & g.hash_mask;
+		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+		reserve(owner, P, A, owner_key(stamp, idx));
 	}
 }
 
-template <Op OP, bool FROM_LIST, bool MARK_NEXT>
-__global__ __launch_bounds__(256) void k_commit(Ctl *ctl, ReqSrc src, DevGeom g, uint32_t *table,
+// ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
+// ROUND 1 iterates every request; ROUND 2 the list of round-1 losers, which it also
+// classifies against the round-1 registrant counts.
+template <Op OP, int ROUND>
+__global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, unsigned long long *cnt,
-		uint8_t *state, const uint32_t *list, uint32_t *list_next, int list_sel, int round,
-		uint32_t stamp_min, uint32_t stamp_min_next, uint32_t stamp_inc_next)
+		const uint4 *reqc, uint8_t *state, Undo *undo, uint32_t *list_lose, uint32_t *list_tail)
 {
-	const uint32_t count = FROM_LIST ? ctl->list_n[list_sel] : ctl->total;
+	const uint32_t count = ROUND == 1 ? ctl->total : ctl->list_n[0];
+	const unsigned long long stamp1 = ctl->stamp_base;
+	const unsigned long long stamp = stamp1 + (ROUND - 1);
 	const uint32_t span = gridDim.x * blockDim.x;
-	// all lanes of a wave iterate together so the wave-wide appends stay convergent
-	const uint32_t iters = (count + span - 1) / span;
+	const uint32_t iters = (count + span - 1) / span;   // whole waves iterate together
 	for (uint32_t it = 0; it < iters; it++) {
 		const uint32_t i = it * span + blockIdx.x * blockDim.x + threadIdx.x;
 		bool pending = i < count;
 		uint32_t idx = i;
 		if (pending) {
-			if (FROM_LIST)
-				idx = list[i];
+			if (ROUND == 1)
+				pending = state[idx] == ST_PENDING;
 			else
-				pending = state[idx] == 0;
+				idx = list_lose[i];
 		}
-		bool done = false;
-		uint32_t P = 0, A = 0;
+		bool done = false, lose = false, to_tail = false;
 		if (pending) {
-			const Req r = load_req(src, ctl, idx);
-			P = r.hash & g.hash_mask;
-			A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-			bool ok = is_clean(owner, P, A, idx, stamp_min);
-			if (OP == OP_CUCKOO && ok)
-				ok = idx < ctl->barrier[round][P >> g.region_shift];
-			if (ok)
-				done = apply_static<OP>(table, g, r, P, A);
-			if (done)
-				state[idx] = 1;
+			const Req r = req_of(reqc[idx]);
+			const uint32_t P = r.hash & g.hash_mask;
+			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+			const unsigned long long key = owner_key(stamp, idx);
+			const unsigned long long oP = owner[P];
+			const unsigned long long oA = owner[A];
+			const bool clean = oP == key && (A == P || oA == key);
+			const uint32_t region = P >> g.region_shift;
+
+			if (OP == OP_CUCKOO && ROUND == 2) {
+				// This request lost a round-1 reservation.  Could it turn hard before
+				// its turn?  Not if it holds a duplicate, or if the empty slots of P
+				// and A outnumber the other round-1 registrants (each takes at most one).
+				uint4 lo, hi;
+				load_sig_row<false>(table, P, lo, hi);
+				bool safe = eq_mask(lo, hi, r.sig) != 0u;
+				if (!safe) {
+					uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
+					uint32_t others = cnt_of(cnt[P], stamp1);
+					if (A != P) {
+						load_sig_row<false>(table, A, lo, hi);
+						safe = eq_mask(lo, hi, r.sig) != 0u;
+						room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
+						others += cnt_of(cnt[A], stamp1);
+					}
+					safe = safe || room >= 1u + others;
+				}
+				if (!safe)
+					atomicMin(&ctl->barrier[region], idx);
+			}
+
+			// a barrier already published at or below this request: leave it to the tail
+			const bool blocked = OP == OP_CUCKOO && idx >= ctl->barrier[region];
+			if (clean && !blocked) {
+				Undo u;
+				u.word0 = kNoWord;
+				u.word1 = kNoWord;
+				u.old0 = 0u;
+				u.old1 = 0u;
+				done = apply_static<OP, false, OP == OP_CUCKOO>(table, r, P, A, &u);
+				if (done) {
+					state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
+					if (OP == OP_CUCKOO)
+						undo[idx] = u;
+				} else {
+					// hard right now: it and everything after it in the region wait for the tail
+					atomicMin(&ctl->barrier[region], idx);
+					atomicMin(&ctl->first_hard, idx);
+					to_tail = true;
+				}
+			} else if (ROUND == 1 && !blocked) {
+				lose = true;
+				reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+				if (OP == OP_CUCKOO) {
+					// registrant counts of round 1: every non-owner adds itself
+					if (oP != key)
+						bump(cnt, P, stamp1);
+					if (A != P && oA != key)
+						bump(cnt, A, stamp1);
+				}
+			} else {
+				to_tail = true;
+			}
 		}
-		const bool left = pending && !done;
-		if (MARK_NEXT && left)
-			register_req<OP>(owner_next, cnt, P, A, idx, stamp_min_next, stamp_inc_next);
-		list_append(list_next, &ctl->list_n[list_sel ^ 1], left, idx);
-		count_add(&ctl->committed[round], done);
+		if (ROUND == 1)
+			list_append(list_lose, &ctl->list_n[0], lose, idx);
+		list_append(list_tail, &ctl->list_n[1], to_tail, idx);
+		count_add(&ctl->committed[ROUND - 1], done);
 	}
 }
 
-// resets the size of the list the NEXT commit will append to
-__global__ void k_reset_list(Ctl *ctl, int which)
+// ---- K4: tail -------------------------------------------------------------------
+__device__ __forceinline__ void wg_sync()
 {
-	ctl->list_n[which] = 0;
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__syncthreads();
+}
+
+// bitonic sort of n2 (power of two) keys in LDS, ascending
+__device__ void lds_sort(uint32_t *keys, uint32_t n2)
+{
+	const uint32_t t = threadIdx.x;
+	for (uint32_t k = 2; k <= n2; k <<= 1) {
+		for (uint32_t j = k >> 1; j > 0; j >>= 1) {
+			for (uint32_t i = t; i < n2; i += blockDim.x) {
+				const uint32_t ixj = i ^ j;
+				if (ixj > i) {
+					const uint32_t a = keys[i], b = keys[ixj];
+					if ((a > b) == ((i & k) == 0)) {
+						keys[i] = b;
+						keys[ixj] = a;
+					}
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
+// Reservation rounds inside the tail work-group over keys[0..m) (kNone = done).
+template <Op OP>
+__device__ void tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
+		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
+		const uint32_t *s_bar, uint32_t *s_rbar, uint32_t *s_progress, uint32_t *s_par, int max_rounds)
+{
+	const uint32_t t = threadIdx.x;
+	const unsigned long long stamp0 = ctl->stamp_base + 2;
+	for (int round = 0; round < max_rounds; round++) {
+		const unsigned long long stamp = stamp0 + (unsigned)round;
+		if (t < kMaxRegions)
+			s_rbar[t] = s_bar[t];
+		if (t == 0)
+			*s_progress = 0;
+		// register; the count decides who might turn hard
+		for (uint32_t i = t; i < m; i += blockDim.x) {
+			const uint32_t idx = keys[i];
+			if (idx == kNone)
+				continue;
+			const uint4 rc = reqc[idx];
+			const uint32_t P = rc.y & g.hash_mask;
+			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+			reserve(owner, P, A, owner_key(stamp, idx));
+			if (OP == OP_CUCKOO) {
+				bump(cnt, P, stamp);
+				if (A != P)
+					bump(cnt, A, stamp);
+			}
+		}
+		wg_sync();
+		// decide: the lowest index per region that is hard or might turn hard
+		if (OP == OP_CUCKOO) {
+			for (uint32_t i = t; i < m; i += blockDim.x) {
+				const uint32_t idx = keys[i];
+				if (idx == kNone)
+					continue;
+				const uint4 rc = reqc[idx];
+				const uint32_t P = rc.y & g.hash_mask;
+				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+				const uint32_t region = P >> g.region_shift;
+				if (idx >= s_rbar[region])
+					continue;
+				uint4 lo, hi;
+				load_sig_row<true>(table, P, lo, hi);
+				if (eq_mask(lo, hi, rc.x))
+					continue;
+				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
+				const unsigned long long key = owner_key(stamp, idx);
+				const bool clean = ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key);
+				if (clean && room)
+					continue;
+				uint32_t others = cnt_of(ld_agent(&cnt[P]), stamp) - 1u;
+				if (A != P) {
+					load_sig_row<true>(table, A, lo, hi);
+					if (eq_mask(lo, hi, rc.x))
+						continue;
+					room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
+					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
+				}
+				const bool bad = clean ? room == 0u : room < 1u + others;
+				if (bad)
+					atomicMin(&s_rbar[region], idx);
+			}
+			wg_sync();
+		}
+		// commit
+		for (uint32_t i = t; i < m; i += blockDim.x) {
+			const uint32_t idx = keys[i];
+			if (idx == kNone)
+				continue;
+			const Req r = req_of(reqc[idx]);
+			const uint32_t P = r.hash & g.hash_mask;
+			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+			const unsigned long long key = owner_key(stamp, idx);
+			if (OP == OP_CUCKOO && idx >= s_rbar[P >> g.region_shift])
+				continue;
+			if (ld_agent(&owner[P]) != key || (A != P && ld_agent(&owner[A]) != key))
+				continue;
+			if (apply_static<OP, true, false>(table, r, P, A, nullptr)) {
+				state[idx] = ST_DONE;
+				keys[i] = kNone;
+				atomicAdd(s_progress, 1u);
+			}
+		}
+		wg_sync();
+		const uint32_t progress = *s_progress;
+		if (t == 0)
+			*s_par += progress;
+		__syncthreads();
+		if (progress == 0)
+			break;
+	}
 }
 
 template <Op OP>
-__global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, ReqSrc src, DevGeom g, uint32_t *table,
-		uint8_t *state, const uint32_t *list, int list_sel)
+__global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
+		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
+		const Undo *undo, const uint32_t *list_tail, int max_rounds)
 {
 	__shared__ uint32_t keys[kSortCap];
-	const uint32_t m = ctl->list_n[list_sel];
-	if (m == 0)
-		return;
+	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier
+	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
+	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial;
 	const uint32_t t = threadIdx.x;
-	if (m <= (uint32_t)kSortCap) {
+	const uint32_t total = ctl->total;
+	const uint32_t m_list = ctl->list_n[1];
+	if (t < kMaxRegions)
+		s_bar[t] = t < g.nregions ? ctl->barrier[t] : kNone;
+	if (t == 0) {
+		s_n = m_list;
+		s_undone = 0;
+		s_par = 0;
+		s_serial = 0;
+	}
+	__syncthreads();
+	bool any_bar = false;
+	for (uint32_t k = 0; k < g.nregions; k++)
+		any_bar |= s_bar[k] != kNone;
+
+	// -- roll back optimistic commits at or beyond the barrier, newest round first
+	if (OP == OP_CUCKOO && any_bar) {
+		for (int pass = 0; pass < 2; pass++) {
+			const uint8_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
+			for (uint32_t idx = t; idx < total; idx += blockDim.x) {
+				if (state[idx] != tag)
+					continue;
+				const uint4 rc = reqc[idx];
+				const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
+				if (idx < s_bar[region])
+					continue;
+				const Undo u = undo[idx];
+				if (u.word1 != kNoWord)
+					table[u.word1] = u.old1;
+				if (u.word0 != kNoWord)
+					table[u.word0] = u.old0;
+				state[idx] = ST_PENDING;
+				const uint32_t slot = atomicAdd(&s_n, 1u);   // behind the listed requests
+				if (slot < (uint32_t)kSortCap)
+					keys[slot] = idx;
+				atomicAdd(&s_undone, 1u);
+			}
+			wg_sync();
+		}
+	}
+	const uint32_t m = s_n;
+	if (m != 0 && m <= (uint32_t)kSortCap) {
+		for (uint32_t i = t; i < m_list; i += blockDim.x)
+			keys[i] = list_tail[i];
 		uint32_t n2 = 1;
 		while (n2 < m)
 			n2 <<= 1;
-		for (uint32_t i = t; i < n2; i += blockDim.x)
-			keys[i] = i < m ? list[i] : kNone;
+		for (uint32_t i = m + t; i < n2; i += blockDim.x)
+			keys[i] = kNone;
 		__syncthreads();
-		for (uint32_t k = 2; k <= n2; k <<= 1) {
-			for (uint32_t j = k >> 1; j > 0; j >>= 1) {
-				for (uint32_t i = t; i < n2; i += blockDim.x) {
-					const uint32_t ixj = i ^ j;
-					if (ixj > i) {
-						const uint32_t a = keys[i], b = keys[ixj];
-						const bool up = (i & k) == 0;
-						if ((a > b) == up) {
-							keys[i] = b;
-							keys[ixj] = a;
-						}
-					}
-				}
-				__syncthreads();
-			}
-		}
+		tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_bar, s_rbar, &s_progress,
+				&s_par, max_rounds);
+		// what is left: canonical order, one request at a time
+		lds_sort(keys, n2);
 		if (t == 0) {
+			uint32_t d = 0;
 			for (uint32_t i = 0; i < m; i++) {
 				const uint32_t idx = keys[i];
-				const Req r = load_req(src, ctl, idx);
-				apply_serial<OP>(table, g, r);
-				state[idx] = 1;
+				if (idx == kNone)
+					break;
+				apply_serial<OP>(table, g, req_of(reqc[idx]));
+				state[idx] = ST_DONE;
+				d++;
 			}
-			ctl->drained = m;
+			s_serial = d;
 		}
-	} else if (t == 0) {
-		// too many leftovers for LDS: walk the state array in canonical order
-		const uint32_t total = ctl->total;
+	} else if (m != 0 && t == 0) {
+		// too much left for LDS: walk the request states in canonical order
 		uint32_t d = 0;
 		for (uint32_t idx = 0; idx < total; idx++) {
-			if (state[idx])
+			if (state[idx] != ST_PENDING)
 				continue;
-			const Req r = load_req(src, ctl, idx);
-			apply_serial<OP>(table, g, r);
-			state[idx] = 1;
+			apply_serial<OP>(table, g, req_of(reqc[idx]));
+			state[idx] = ST_DONE;
 			d++;
 		}
-		ctl->drained = d;
+		s_serial = d;
 	}
+	__syncthreads();
+	if (t == 0) {
+		// diagnostics of this call, then the control block of the next one
+		ctl->last.total = total;
+		ctl->last.round1 = ctl->committed[0];
+		ctl->last.round2 = ctl->committed[1];
+		ctl->last.tail_parallel = s_par;
+		ctl->last.tail_serial = s_serial;
+		ctl->last.undone = s_undone;
+		ctl->last.first_hard = ctl->first_hard;
+		ctl->last.overflow = ctl->overflow;
+		ctl->list_n[0] = 0;
+		ctl->list_n[1] = 0;
+		ctl->committed[0] = 0;
+		ctl->committed[1] = 0;
+		ctl->first_hard = kNone;
+		ctl->total = 0;
+		const unsigned long long st = ctl->next_stamp;
+		ctl->stamp_base = st;
+		ctl->next_stamp = st + kStampsPerCall;
+	}
+	if (t < kMaxRegions)
+		ctl->barrier[t] = kNone;
+}
+
+__global__ void k_init_ctl(Ctl *ctl)
+{
+	const uint32_t t = threadIdx.x;
+	if (t == 0) {
+		ctl->stamp_base = 1;
+		ctl->next_stamp = 1 + kStampsPerCall;
+		ctl->total = 0;
+		ctl->overflow = 0;
+		ctl->list_n[0] = ctl->list_n[1] = 0;
+		ctl->committed[0] = ctl->committed[1] = 0;
+		ctl->first_hard = kNone;
+		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0};
+	}
+	if (t < kMaxRegions)
+		ctl->barrier[t] = kNone;
 }
 
 // ---- per-stream workspace -----------------------------------------------------
@@ -488,9 +744,9 @@ struct Workspace {
 	unsigned long long *cnt = nullptr;
 	uint8_t *state = nullptr;
 	uint32_t *list[2] = {nullptr, nullptr};
+	uint4 *reqc = nullptr;
+	Undo *undo = nullptr;
 	Ctl *ctl = nullptr;
-	uint32_t round_counter = 1;
-	int last_rounds = 0;
 };
 
 static std::mutex g_ws_mutex;
@@ -504,6 +760,8 @@ static void free_ws(Workspace *w)
 	}
 	if (w->cnt) (void)hipFree(w->cnt);
 	if (w->state) (void)hipFree(w->state);
+	if (w->reqc) (void)hipFree(w->reqc);
+	if (w->undo) (void)hipFree(w->undo);
 	if (w->ctl) (void)hipFree(w->ctl);
 	*w = Workspace();
 }
@@ -537,97 +795,52 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = ok && hipMalloc(&w->list[i], (size_t)rc * 4) == hipSuccess;
 	}
 	ok = ok && hipMalloc(&w->cnt, nb * 8) == hipSuccess;
-	ok = ok && hipMalloc(&w->state, (size_t)rc) == hipSuccess;
+	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
+	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
+	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
 	if (ok) {
 		// owner entries start at "no owner" (all ones); counters at zero
 		ok = ok && hipMemsetAsync(w->owner[0], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->owner[1], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 8, stream) == hipSuccess;
-		ok = ok && hipMemsetAsync(w->ctl, 0, sizeof(Ctl), stream) == hipSuccess;
+		if (ok)
+			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl);
 	}
 	if (!ok) {
 		free_ws(w);
 		return MKV_ENOMEM;
 	}
-	w->round_counter = 1;
 	*out = w;
 	return MKV_OK;
 }
 
-static int default_rounds()
-{
-	return tuning().update_rounds;
-}
-
-static int64_t default_req_cap()
-{
-	return (int64_t)tuning().req_cap;
-}
-
 template <Op OP>
-static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, const int *blk_elem_num,
-		int64_t single_n, hipStream_t stream)
+static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipStream_t stream)
 {
 	Workspace *w = nullptr;
-	int64_t need = default_req_cap();
-	if (single_n > need)
-		need = single_n;
+	int64_t need = (int64_t)tuning().req_cap;
+	if (src.single_n > kMaxReqCap)
+		return MKV_ETOOBIG;
+	if (src.single_n > need)
+		need = src.single_n;
+	if (need > kMaxReqCap)
+		need = kMaxReqCap;
 	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, need, stream);
 	if (rc != MKV_OK)
 		return rc;
-	const int rounds = default_rounds();
-	w->last_rounds = rounds;
+	int tail_rounds = tuning().tail_rounds;
+	if (tail_rounds > kMaxTailRounds)
+		tail_rounds = kMaxTailRounds;
 
-	hipLaunchKernelGGL(k_prep, dim3(1), dim3(256), 0, stream, w->ctl, blk_elem_num, (int)src.nblk,
-			(long long)single_n, (uint32_t)(w->req_cap > 0xfffffff0ll ? 0xfffffff0ll : w->req_cap));
-
-	uint32_t stamp_inc = w->round_counter;
-	uint32_t stamp_min = kNone - stamp_inc;
-	hipLaunchKernelGGL((k_mark_all<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->cnt, w->state, stamp_min, stamp_inc);
-
-	for (int r = 0; r < rounds; r++) {
-		const bool first = r == 0;
-		const bool last = r == rounds - 1;
-		const int set = r & 1;          // owner table of this round
-		const int lsel = r & 1;         // list read by this round (r > 0); appends go to lsel^1
-		const uint32_t next_inc = stamp_inc + 1;
-		const uint32_t next_min = kNone - next_inc;
-		const dim3 grid(first ? kGridAll : kGridList), block(256);
-		if (OP == OP_CUCKOO) {
-			if (first)
-				hipLaunchKernelGGL((k_decide<false>), grid, block, 0, stream, w->ctl, src, g, table,
-						w->owner[set], w->cnt, w->state, w->list[lsel], lsel, r, stamp_min, stamp_inc);
-			else
-				hipLaunchKernelGGL((k_decide<true>), grid, block, 0, stream, w->ctl, src, g, table,
-						w->owner[set], w->cnt, w->state, w->list[lsel], lsel, r, stamp_min, stamp_inc);
-		}
-		if (!first)
-			hipLaunchKernelGGL(k_reset_list, dim3(1), dim3(1), 0, stream, w->ctl, lsel ^ 1);
-#define MKV_COMMIT(FL, MN)                                                                          \
-	hipLaunchKernelGGL((k_commit<OP, FL, MN>), grid, block, 0, stream, w->ctl, src, g, table,        \
-			w->owner[set], w->owner[set ^ 1], w->cnt, w->state, w->list[lsel], w->list[lsel ^ 1],   \
-			lsel, r, stamp_min, next_min, next_inc)
-		if (first && !last) MKV_COMMIT(false, true);
-		else if (first && last) MKV_COMMIT(false, false);
-		else if (!first && !last) MKV_COMMIT(true, true);
-		else MKV_COMMIT(true, false);
-#undef MKV_COMMIT
-		stamp_inc = next_inc;
-		stamp_min = next_min;
-	}
-	w->round_counter = stamp_inc + 1;
-	if (w->round_counter > 0xfff00000u) {
-		// stamps about to wrap: start a fresh epoch
-		(void)hipMemsetAsync(w->owner[0], 0xff, w->nbuckets * 8, stream);
-		(void)hipMemsetAsync(w->owner[1], 0xff, w->nbuckets * 8, stream);
-		(void)hipMemsetAsync(w->cnt, 0, w->nbuckets * 8, stream);
-		w->round_counter = 1;
-	}
-	const int tail_sel = rounds & 1;    // list the last commit appended to
-	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, src, g, table, w->state,
-			w->list[tail_sel], tail_sel);
+	hipLaunchKernelGGL((k_mark<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
+			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
+			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, w->list[0], w->list[1]);
+	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
+			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->list[0], w->list[1]);
+	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
+			w->cnt, w->reqc, w->state, w->undo, w->list[1], tail_rounds);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -646,11 +859,13 @@ extern "C" int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk
 	mkv::ReqSrc src;
 	src.blk_input = reinterpret_cast<const uint32_t *const *>(blk_input);
 	src.single = nullptr;
+	src.blk_elem_num = blk_elem_num;
+	src.single_n = 0;
 	src.nblk = (uint32_t)num_blks;
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
-		return mkv::run_update<mkv::OP_2CHOICE>(d, t, src, blk_elem_num, 0, (hipStream_t)stream);
-	return mkv::run_update<mkv::OP_CUCKOO>(d, t, src, blk_elem_num, 0, (hipStream_t)stream);
+		return mkv::run_update<mkv::OP_2CHOICE>(d, t, src, (hipStream_t)stream);
+	return mkv::run_update<mkv::OP_CUCKOO>(d, t, src, (hipStream_t)stream);
 }
 
 extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
@@ -663,14 +878,14 @@ extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 		return MKV_OK;
 	if (!table || !in)
 		return MKV_EINVAL;
-	if (num_elem > 0xfffffff0ll)
-		return MKV_ETOOBIG;
 	mkv::ReqSrc src;
 	src.blk_input = nullptr;
 	src.single = reinterpret_cast<const uint32_t *>(in);
+	src.blk_elem_num = nullptr;
+	src.single_n = num_elem;
 	src.nblk = 1;
-	return mkv::run_update<mkv::OP_DELETE>(d, reinterpret_cast<uint32_t *>(table), src, nullptr,
-			num_elem, (hipStream_t)stream);
+	return mkv::run_update<mkv::OP_DELETE>(d, reinterpret_cast<uint32_t *>(table), src,
+			(hipStream_t)stream);
 }
 
 extern "C" int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *stream)
@@ -679,9 +894,11 @@ extern "C" int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *s
 	if (!mkv::make_dev_geom(geom, &d) || max_requests < 0)
 		return MKV_EINVAL;
 	mkv::Workspace *w = nullptr;
-	int64_t need = mkv::default_req_cap();
+	int64_t need = (int64_t)mkv::tuning().req_cap;
 	if (max_requests > need)
 		need = max_requests;
+	if (need > mkv::kMaxReqCap)
+		return MKV_ETOOBIG;
 	return mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, need, (hipStream_t)stream);
 }
 
@@ -715,11 +932,12 @@ extern "C" int mkv_last_update_info(void *stream, mkv_update_info_t *info)
 		return MKV_EHIP;
 	if (hipMemcpy(&h, w->ctl, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
 		return MKV_EHIP;
-	info->total = h.overflow ? 0xffffffffu : h.total;
-	for (int i = 0; i < 6; i++)
-		info->committed[i] = i < mkv::kMaxRounds ? h.committed[i] : 0;
-	info->drained = h.drained;
-	info->first_hard = h.first_hard;
-	info->rounds = (uint32_t)w->last_rounds;
+	info->total = h.last.overflow ? 0xffffffffu : h.last.total;
+	info->round1 = h.last.round1;
+	info->round2 = h.last.round2;
+	info->tail_parallel = h.last.tail_parallel;
+	info->tail_serial = h.last.tail_serial;
+	info->undone = h.last.undone;
+	info->first_hard = h.last.first_hard;
 	return MKV_OK;
 }

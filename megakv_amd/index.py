@@ -167,8 +167,7 @@ class HashIndex:
         info = MkvUpdateInfo()
         _check(self.lib.mkv_last_update_info(_stream_ptr(stream), ctypes.byref(info)),
                "mkv_last_update_info")
-        return {"total": info.total, "committed": list(info.committed), "drained": info.drained,
-                "first_hard": info.first_hard, "rounds": info.rounds}
+        return {k: int(getattr(info, k)) for k, _ in info._fields_}
 
     def table_numpy(self):
         """Table image as uint32 [nbuckets,16] on the host (sig[8] | loc[8])."""
