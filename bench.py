@@ -55,12 +55,18 @@ def parse():
     ap.add_argument("--lf", type=float, default=0.2)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--mem-p", type=int, default=30, help="per-GPU table size (log2 bytes)")
-    ap.add_argument("--fused-zero", action="store_true",
-                    help="let the search kernel write zeros on a miss instead of a separate memset")
+    ap.add_argument("--memset", action="store_true",
+                    help="clear the result buffer with a separate memset (reference call sequence) instead of "
+                         "letting the search kernel write zeros on a miss")
+    ap.add_argument("--overlap", default="fused", choices=["fused", "side", "none"],
+                    help="where the insert's table-independent mark pass runs: inside the search launch, on a "
+                         "side stream, or as its own kernel after the search")
+    ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--cpu-batches", type=int, default=8)
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
+    ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: mkv_set_tuning('debug_skip')")
     return ap.parse_args()
 
 
@@ -131,6 +137,7 @@ def main():
         engine = ShardedIndex(args.mem_p, world, rank, scheme, device, 1 << args.batch_log2)
 
     stream_gen = Stream(args, rank, world, mem_p_agg)
+    dbg_skip = args.debug_skip
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
     t0 = time.time()
@@ -154,6 +161,9 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    if dbg_skip:
+        from megakv_amd.lib import load_library
+        load_library().mkv_set_tuning(b"debug_skip", dbg_skip)
     with torch.cuda.stream(run_stream):
         engine.reserve(run_stream)
         for b in batches[:args.warmup]:
@@ -162,12 +172,11 @@ def main():
         hit_rate = engine.hit_rate(batches[args.warmup - 1]) if args.warmup else None
         barrier()
         t_start = time.perf_counter()
-        for b in batches[args.warmup:]:
-            pair = None
-            if use_events:
-                pair = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                ev.append(pair)
-            engine.step(b, run_stream, pair)
+        every = max(1, args.events_every)
+        timer = engine.make_timer((args.steps + every - 1) // every) if (use_events and not args.graph) else None
+        for i, b in enumerate(batches[args.warmup:]):
+            engine.step(b, run_stream, [timer.h, i // every] if (timer and i % every == 0) else None)
+        t_submit = time.perf_counter() - t_start
         run_stream.synchronize()
     barrier()
     elapsed = time.perf_counter() - t_start
@@ -180,15 +189,15 @@ def main():
     value = n_ops / elapsed / 1e6
 
     roofline = None
-    if use_events and ev:
-        ms = np.array([a.elapsed_time(b) for a, b in ev])
+    if use_events and timer:
+        ms = np.array(timer.elapsed_ms())
         avg_s = float(ms.mean()) * 1e-3
         algo_bytes = GET_BYTES * engine.search_requests_per_launch(stream_gen)
         achieved = algo_bytes / avg_s / 1e9
         roofline = {"bound": "hbm", "kernel": "mkv::k_search", "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": load_traffic(args), "algorithmic_bytes_per_launch": algo_bytes,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
+                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(len(ms)), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
                     "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2)}
 
     cpu = None
@@ -208,10 +217,11 @@ def main():
                        "mem_p_per_gpu": args.mem_p, "mem_p_aggregate": mem_p_agg, "scheme": args.scheme,
                        "batch": 1 << args.batch_log2, "gets": stream_gen.n_get, "sets": stream_gen.n_set,
                        "keying": "K-" + args.keying, "set_keys": "S-" + args.sets, "load_factor": args.lf,
-                       "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "fused" if args.fused_zero else "memset",
+                       "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "memset" if args.memset else "by the search kernel", "mark_pass": args.overlap,
                        "sharding": "single table" if world == 1 else f"{world} shards by top bucket bits, RCCL all-to-all",
                        "launch": "hipGraph" if args.graph else "eager"},
             "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu,
+            "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
         print(json.dumps(line), flush=True)
@@ -251,20 +261,23 @@ class SingleGpu:
     def reserve(self, stream):
         self.idx.reserve((1 << self.args.batch_log2) + 8, stream)
 
+    def make_timer(self, slots):
+        from megakv_amd.index import SearchTimer
+        return SearchTimer(slots)
+
     def hit_rate(self, b):
         o = b["out"]
         return round(float(((o[:, 0] != 0) | (o[:, 1] != 0)).float().mean().item()), 6)
 
     def _launch(self, b, stream, pair):
-        if not self.args.fused_zero:
-            b["out"].zero_()                                   # the caller's cudaMemsetAsync
-        if pair:
-            pair[0].record(stream)
-        self.idx.search(b["q"], out=b["out"], zero_miss=self.args.fused_zero, stream=stream)
-        if pair:
-            pair[1].record(stream)
-        if "ptrs" in b:
-            self.idx.insert_staged(b["ptrs"], b["cnts"], len(b["keep"]), stream)
+        if not isinstance(pair, tuple) or pair is None:
+            # one library call per cycle: memset(out) -> search -> insert; `pair` is
+            # (timer handle, slot) packed as a list when the search launch is timed
+            timer, slot = (pair[0], pair[1]) if pair else (None, 0)
+            self.idx.cycle(b["q"], b["out"], b.get("ptrs"), b.get("cnts"), len(b["keep"]) if "keep" in b else 0,
+                           memset=self.args.memset, overlap=self.args.overlap, stream=stream,
+                           timer=timer, slot=slot)
+            return
 
     def step(self, b, stream, pair):
         if not self.args.graph:
@@ -276,11 +289,7 @@ class SingleGpu:
             with torch.cuda.graph(gr, stream=stream):
                 self._launch(b, torch.cuda.current_stream(), None)
             self.graphs[key] = gr
-        if pair:
-            pair[0].record(stream)
         self.graphs[key].replay()
-        if pair:
-            pair[1].record(stream)
 
     def table_host(self):
         return self.idx.table_numpy()

@@ -52,6 +52,30 @@ int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 		int64_t num_elem, void *stream);
 
+/* One scheduler cycle of one worker in a single call, in the reference's order
+ * (src/mega_scheduler.c:393-502): clear out -> search -> delete -> insert, all
+ * asynchronous and ordered on `stream`; a part is skipped when its count is 0.
+ * Results are those of the three separate calls.  Two things differ in how:
+ * the result buffer is cleared by the search kernel itself (a miss writes 0;
+ * MKV_CYCLE_MEMSET asks for the separate memset instead), and the insert's first
+ * pass, which reads only the requests and never the table, is launched as extra
+ * work-groups of the search kernel.  MKV_CYCLE_SIDE_STREAM runs that pass on an
+ * internal side stream instead (it starts after everything enqueued on `stream`
+ * before the call); MKV_CYCLE_NO_OVERLAP issues the plain three-call sequence. */
+#define MKV_CYCLE_MEMSET      0x100u
+#define MKV_CYCLE_NO_OVERLAP  0x200u
+#define MKV_CYCLE_SIDE_STREAM 0x400u
+int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t *search_in,
+		loc_t *search_out, int64_t num_search, delem_t *delete_in, int64_t num_delete,
+		ielem_t **blk_input, int *blk_elem_num, int num_blks, uint32_t search_flags, void *stream,
+		void *timer, int slot);
+
+/* Measurement aid: `slots` HIP event pairs; mkv_cycle(timer, slot) records pair
+ * `slot` on the caller's stream around its search launch.  timer may be NULL. */
+void *mkv_timer_create(int slots);
+int mkv_timer_elapsed_ms(void *timer, int slot, float *ms);
+void mkv_timer_destroy(void *timer);
+
 /* Insert/delete keep a private device workspace per stream (conflict tables and
  * request state).  It is created on the first call that needs it; call this
  * beforehand to size it explicitly (and keep allocation out of a region being
@@ -75,6 +99,8 @@ typedef struct mkv_update_info_s {
 } mkv_update_info_t;
 
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);
+/* cycle_insert != 0: the insert half of the last mkv_cycle on `stream` */
+int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
 
 /* ---- request routing for the sharded (multi-GPU) index, SURVEY 8(e) -------
  * shard(e) = ((e.hash & hash_mask_agg) >> shard_shift); requests are grouped by

@@ -5,6 +5,8 @@
 #include <stdio.h>
 #include <stdlib.h>
 
+#include <hip/hip_runtime.h>
+
 #include "libgpuhash.h"
 #include "megakv_hip.h"
 
@@ -68,6 +70,123 @@ extern "C" void gpu_delete_insert(bucket_t *hash_table, delem_t *delete_in, uint
 			"gpu_delete_insert/delete");
 	die_on(mkv_insert(&kGeom, hash_table, insert_blk_input, insert_blk_elem_num, num_insert_blks,
 				(void *)stream), "gpu_delete_insert/insert");
+}
+
+// HIP event pairs recorded on the caller's stream around the search launch of
+// mkv_cycle: how bench.py times the dominant kernel inside the timed region.
+struct MkvTimer {
+	int slots;
+	hipEvent_t *ev;
+};
+
+extern "C" void *mkv_timer_create(int slots)
+{
+	if (slots <= 0)
+		return nullptr;
+	MkvTimer *t = new MkvTimer;
+	t->slots = slots;
+	t->ev = new hipEvent_t[2 * slots];
+	for (int i = 0; i < 2 * slots; i++) {
+		if (hipEventCreate(&t->ev[i]) != hipSuccess) {
+			for (int j = 0; j < i; j++)
+				(void)hipEventDestroy(t->ev[j]);
+			delete[] t->ev;
+			delete t;
+			return nullptr;
+		}
+	}
+	return t;
+}
+
+extern "C" int mkv_timer_elapsed_ms(void *timer, int slot, float *ms)
+{
+	MkvTimer *t = reinterpret_cast<MkvTimer *>(timer);
+	if (!t || !ms || slot < 0 || slot >= t->slots)
+		return MKV_EINVAL;
+	return hipEventElapsedTime(ms, t->ev[2 * slot], t->ev[2 * slot + 1]) == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+extern "C" void mkv_timer_destroy(void *timer)
+{
+	MkvTimer *t = reinterpret_cast<MkvTimer *>(timer);
+	if (!t)
+		return;
+	for (int i = 0; i < 2 * t->slots; i++)
+		(void)hipEventDestroy(t->ev[i]);
+	delete[] t->ev;
+	delete t;
+}
+
+extern "C" int mkv_tuning_is_default_search(void);
+extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_input, int *blk_elem_num,
+		int num_blks, void *stream);
+extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, void *stream, int joined);
+extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
+		const bucket_t *table, int64_t num_search, ielem_t **blk_input, int *blk_elem_num, int num_blks,
+		void *stream);
+
+// One scheduler cycle for one worker in a single call: clear the result buffer,
+// search, delete, insert, all on `stream` (reference src/mega_scheduler.c:393-502
+// does exactly this sequence per worker).  Saves host round trips for callers
+// that are not bound to the three-call ABI.
+extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t *search_in,
+		loc_t *search_out, int64_t num_search, delem_t *delete_in, int64_t num_delete,
+		ielem_t **blk_input, int *blk_elem_num, int num_blks, uint32_t search_flags, void *stream,
+		void *timer, int slot)
+{
+	int rc = MKV_OK;
+	MkvTimer *tm = reinterpret_cast<MkvTimer *>(timer);
+	if (tm && (slot < 0 || slot >= tm->slots))
+		return MKV_EINVAL;
+	// The insert's mark pass does not touch the table.  Default: it rides in the
+	// search launch (extra work-groups of one kernel).  MKV_CYCLE_SIDE_STREAM: it
+	// runs on a side stream beside the search kernel.  MKV_CYCLE_NO_OVERLAP: plain
+	// sequence of the three entry points.
+	const bool can = num_blks > 0 && !(search_flags & MKV_CYCLE_NO_OVERLAP);
+	const bool side = can && (search_flags & MKV_CYCLE_SIDE_STREAM);
+	const bool fused = can && !side && num_search > 0 && !(search_flags & MKV_CYCLE_MEMSET) &&
+			mkv_tuning_is_default_search();
+	const bool overlap = side;
+	if (side) {
+		rc = mkv_cycle_insert_begin(geom, blk_input, blk_elem_num, num_blks, stream);
+		if (rc != MKV_OK)
+			return rc;
+	}
+	if (fused) {
+		if (tm)
+			(void)hipEventRecord(tm->ev[2 * slot], (hipStream_t)stream);
+		rc = mkv_cycle_search_mark(geom, search_in, search_out, table, num_search, blk_input, blk_elem_num,
+				num_blks, stream);
+		if (tm)
+			(void)hipEventRecord(tm->ev[2 * slot + 1], (hipStream_t)stream);
+		if (rc != MKV_OK)
+			return rc;
+	} else if (num_search > 0) {
+		if (search_flags & MKV_CYCLE_MEMSET) {
+			if (hipMemsetAsync(search_out, 0, (size_t)num_search * 2 * sizeof(loc_t),
+						(hipStream_t)stream) != hipSuccess)
+				return MKV_EHIP;
+		}
+		if (tm)
+			(void)hipEventRecord(tm->ev[2 * slot], (hipStream_t)stream);
+		// memset + write-on-hit and write-always give the same buffer: fused unless asked
+		rc = mkv_search(geom, search_in, search_out, table, num_search,
+				(search_flags & MKV_CYCLE_MEMSET) ? MKV_SEARCH_KEEP_MISS : MKV_SEARCH_ZERO_MISS, stream);
+		if (tm)
+			(void)hipEventRecord(tm->ev[2 * slot + 1], (hipStream_t)stream);
+		if (rc != MKV_OK)
+			return rc;
+	}
+	if (num_delete > 0) {
+		rc = mkv_delete(geom, delete_in, table, num_delete, stream);
+		if (rc != MKV_OK)
+			return rc;
+	}
+	if (overlap || fused)
+		rc = mkv_cycle_insert_end(geom, table, stream, overlap ? 1 : 0);
+	else if (num_blks > 0)
+		rc = mkv_insert(geom, table, blk_input, blk_elem_num, num_blks, stream);
+	return rc;
 }
 
 extern "C" const char *mkv_version(void)

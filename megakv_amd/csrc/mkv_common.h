@@ -76,6 +76,8 @@ struct Tuning {
 	int search_nt;       // non-temporal table loads in search
 	int tail_rounds;     // reservation rounds inside the tail work-group (0..12)
 	long long req_cap;   // default request capacity of an update workspace
+	int debug_skip;      // diagnostics only (breaks results): bit0 no table stores, bit1 no undo log,
+	                     // bit2 no owner loads, bit3 no bucket load, bit4 no state store
 };
 Tuning &tuning();
 

@@ -1,0 +1,92 @@
+// mkv_search_body.h -- the search work-group body, shared by the stand-alone
+// search kernel (mkv_search.hip) and the fused search+mark kernel of mkv_cycle
+// (mkv_update.hip).  See mkv_search.hip for the design notes.
+#pragma once
+
+#include "mkv_common.h"
+
+namespace mkv {
+
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+
+// quad_perm [1,0,3,2]: swap lanes inside each pair.
+__device__ __forceinline__ uint32_t dpp_swap1(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);
+}
+// quad_perm [2,3,0,1]: swap the pairs of a quad.
+__device__ __forceinline__ uint32_t dpp_swap2(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);
+}
+
+template <int U, bool ZERO_MISS, bool NT>
+__device__ __forceinline__ void search_body(uint32_t block, const uint2 *__restrict__ in,
+		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n,
+		uint32_t hash_mask, uint32_t blk_mask)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t q = lane & 3u;       // 0,1 primary halves; 2,3 alternate halves
+	const uint32_t grp = lane >> 2;     // request slot inside the wave, 0..15
+	const int64_t wave = (int64_t)block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int64_t base = wave * (16 * U);
+
+	u32x4 sv[U], lv[U];
+	uint32_t sig[U];
+	bool live[U];
+
+#pragma unroll
+	for (int u = 0; u < U; u++) {
+		const int64_t e = base + u * 16 + grp;
+		live[u] = e < n;
+		uint2 req = live[u] ? in[e] : make_uint2(0u, 0u);    // {sig, hash}
+		sig[u] = req.x;
+		const uint32_t pri = req.y & hash_mask;
+		const uint32_t alt = alt_bucket(req.y, req.x, hash_mask, blk_mask);
+		const uint32_t b = (q & 2u) ? alt : pri;
+		const u32x4 *p = reinterpret_cast<const u32x4 *>(table) + ((uint64_t)b << 2) + (q & 1u);
+		if (live[u]) {
+			if (NT) {
+				sv[u] = __builtin_nontemporal_load(p);
+				lv[u] = __builtin_nontemporal_load(p + 2);
+			} else {
+				sv[u] = p[0];
+				lv[u] = p[2];
+			}
+		} else {
+			sv[u] = (u32x4)(0u);
+			lv[u] = sv[u];
+		}
+	}
+
+#pragma unroll
+	for (int u = 0; u < U; u++) {
+		const int64_t e = base + u * 16 + grp;
+		// highest matching slot of this lane's four
+		uint32_t hit = 0u, val = 0u;
+		if (sv[u].x == sig[u]) { hit = 1u; val = lv[u].x; }
+		if (sv[u].y == sig[u]) { hit = 1u; val = lv[u].y; }
+		if (sv[u].z == sig[u]) { hit = 1u; val = lv[u].z; }
+		if (sv[u].w == sig[u]) { hit = 1u; val = lv[u].w; }
+		// merge the pair: the odd lane holds slots 4..7 and takes precedence
+		const uint32_t phit = dpp_swap1(hit), pval = dpp_swap1(val);
+		if (q & 1u) {
+			// odd lanes do not store; keep their registers consistent anyway
+		} else {
+			if (phit) { hit = 1u; val = pval; }
+		}
+		if (ZERO_MISS) {
+			// lane q==0 gathers the alternate result and stores both words
+			const uint32_t ahit = dpp_swap2(hit), aval = dpp_swap2(val);
+			if (q == 0u && live[u]) {
+				uint2 r = make_uint2(hit ? val : 0u, ahit ? aval : 0u);
+				*reinterpret_cast<uint2 *>(out + 2 * e) = r;
+			}
+		} else {
+			if ((q & 1u) == 0u && hit && live[u])
+				out[2 * e + (q >> 1)] = val;
+		}
+	}
+}
+
+}  // namespace mkv

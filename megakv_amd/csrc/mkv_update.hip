@@ -51,6 +51,7 @@
 #include <unordered_map>
 
 #include "mkv_common.h"
+#include "mkv_search_body.h"
 
 namespace mkv {
 
@@ -65,7 +66,12 @@ constexpr uint32_t kGridList = 256;
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 
 // request state
-constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3;
+// PENDING: registered, not yet tried; ROUND1/ROUND2: committed optimistically by
+// that round; LOSER: lost a round-1 reservation (round 2 retries it); TAIL: left
+// for the tail work-group.  Rounds find their work by these tags -- no atomic
+// work lists, no same-address atomics on the hot path.
+constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_LOSER = 4, ST_TAIL = 5;
+constexpr int kShards = 64;         // statistics counters are spread over this many words
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
 // (request index in the owner tables, registrant count in the count table).
@@ -83,9 +89,10 @@ struct Ctl {
 	unsigned long long stamp_base;   // stamp of round 1 of the current call
 	uint32_t total;
 	uint32_t overflow;
-	uint32_t list_n[2];              // [0] losers of round 1, [1] work left for the tail
-	uint32_t committed[2];
+	uint32_t any_loser;              // plain flags, set by whoever produces such work
+	uint32_t any_tail;
 	uint32_t first_hard;
+	uint32_t committed[2][kShards];
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
 };
@@ -146,6 +153,30 @@ __device__ __forceinline__ uint64_t sig_word(uint32_t b, uint32_t slot)
 __device__ __forceinline__ uint64_t loc_word(uint32_t b, uint32_t slot)
 {
 	return (uint64_t)b * kBucketWords + kSlots + slot;
+}
+
+// A whole 64-byte bucket in registers: one round trip instead of a dependent
+// chain of row loads.
+struct Bkt {
+	uint4 s0, s1, l0, l1;   // sig[0..3], sig[4..7], loc[0..3], loc[4..7]
+};
+
+__device__ __forceinline__ Bkt load_bucket(const uint32_t *table, uint32_t b)
+{
+	const uint4 *p = reinterpret_cast<const uint4 *>(table + (uint64_t)b * kBucketWords);
+	Bkt k;
+	k.s0 = p[0];
+	k.s1 = p[1];
+	k.l0 = p[2];
+	k.l1 = p[3];
+	return k;
+}
+
+__device__ __forceinline__ uint32_t loc_at(const Bkt &k, uint32_t slot)
+{
+	const uint4 v = (slot & 4u) ? k.l1 : k.l0;
+	const uint32_t a = (slot & 1u) ? v.y : v.x, b = (slot & 1u) ? v.w : v.z;
+	return (slot & 2u) ? b : a;
 }
 
 // What a commit overwrote, so it can be rolled back: up to two words
@@ -209,6 +240,83 @@ __device__ __forceinline__ bool delete_in(uint32_t *table, uint32_t b, uint32_t 
 		}
 	}
 	return any;
+}
+
+// try_place on a bucket already in registers (grid-wide rounds).
+template <bool LOG>
+__device__ __forceinline__ bool place_loaded(uint32_t *table, uint32_t b, const Bkt &k, uint32_t sig,
+		uint32_t loc, uint32_t pref_sig, Undo *u)
+{
+	const uint32_t m = eq_mask(k.s0, k.s1, sig);
+	if (m) {
+		const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+		const uint64_t w = loc_word(b, s);
+		if (LOG) {
+			u->word0 = (uint32_t)w;
+			u->old0 = loc_at(k, s);
+			u->word1 = kNoWord;
+		}
+		table[w] = loc;
+		return true;
+	}
+	const uint32_t e = eq_mask(k.s0, k.s1, 0u);
+	if (e) {
+		const uint32_t s = preferred_slot(e, pref_sig);
+		const uint64_t ws = sig_word(b, s), wl = loc_word(b, s);
+		if (LOG) {
+			u->word0 = (uint32_t)ws;
+			u->old0 = 0u;
+			u->word1 = (uint32_t)wl;
+			u->old1 = loc_at(k, s);
+		}
+		table[ws] = sig;
+		table[wl] = loc;
+		return true;
+	}
+	return false;
+}
+
+// delete on a bucket in registers
+__device__ __forceinline__ bool delete_loaded(uint32_t *table, uint32_t b, const Bkt &k, uint32_t sig,
+		uint32_t loc)
+{
+	const uint32_t m = eq_mask(k.s0, k.s1, sig) & eq_mask(k.l0, k.l1, loc);
+	uint32_t mm = m;
+	while (mm) {
+		const uint32_t s = (uint32_t)__ffs((int)mm) - 1u;
+		mm &= mm - 1u;
+		table[sig_word(b, s)] = 0u;
+	}
+	return m != 0u;
+}
+
+// A static-reach request, first half: the primary bucket (already in registers).
+// Returns true when the request is finished there.
+template <Op OP, bool LOG>
+__device__ __forceinline__ bool apply_primary(uint32_t *table, const Req &r, uint32_t P, const Bkt &kP,
+		Undo *u)
+{
+	if (OP == OP_DELETE)
+		return delete_loaded(table, P, kP, r.sig, r.loc);
+	return place_loaded<LOG>(table, P, kP, r.sig, r.loc, r.sig, u);
+}
+
+// Second half: the alternate bucket.  Returns false (nothing written) only for a
+// cuckoo request that needs an eviction chain.
+template <Op OP, bool LOG>
+__device__ __forceinline__ bool apply_alternate(uint32_t *table, const Req &r, uint32_t A, Undo *u)
+{
+	if (OP == OP_DELETE) {
+		delete_in<false>(table, A, r.sig, r.loc);
+		return true;
+	}
+	if (try_place<false, LOG>(table, A, r.sig, r.loc, r.sig, u))
+		return true;
+	if (OP == OP_2CHOICE) {
+		table[sig_word(A, r.sig & 7u)] = r.sig;     // ref :197-209
+		return true;
+	}
+	return false;
 }
 
 // A request whose reach is static.  Returns false (nothing written) only for a
@@ -294,38 +402,26 @@ __device__ __forceinline__ void reserve(unsigned long long *owner, uint32_t P, u
 		atomicMin(&owner[A], key);
 }
 
-// wave-aggregated append; order inside the list is arbitrary
-__device__ __forceinline__ void list_append(uint32_t *list, uint32_t *list_n, bool want, uint32_t idx)
+// statistics: one atomic per wave, spread over kShards words
+__device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 {
-	const unsigned long long mask = __ballot(want);
-	if (!mask)
-		return;
-	const uint32_t lane = threadIdx.x & 63u;
-	const uint32_t leader = (uint32_t)__ffsll((long long)mask) - 1u;
-	uint32_t base = 0;
-	if (lane == leader)
-		base = atomicAdd(list_n, (uint32_t)__popcll(mask));
-	base = __shfl(base, (int)leader);
-	if (want)
-		list[base + (uint32_t)__popcll(mask & ((1ull << lane) - 1ull))] = idx;
-}
-
-__device__ __forceinline__ void count_add(uint32_t *ctr, bool flag)
-{
-	const unsigned long long mask = __ballot(flag);
-	if (mask && (threadIdx.x & 63u) == (uint32_t)__ffsll((long long)mask) - 1u)
-		atomicAdd(ctr, (uint32_t)__popcll(mask));
+	for (int off = 32; off > 0; off >>= 1)
+		n += __shfl_down(n, off);
+	if ((threadIdx.x & 63u) == 0u && n)
+		atomicAdd(&shards[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kShards - 1)], n);
 }
 
 // ---- K1: mark -----------------------------------------------------------------
 template <Op OP>
-__global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
-		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
+__device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
+		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
+	__shared__ const uint32_t *s_ptr[kMaxBlocks];
 	__shared__ uint32_t s_total;
 	const uint32_t t = threadIdx.x;
 	const uint32_t nblk = src.nblk;
+	const unsigned long long stamp = ctl->stamp_base;
 	if (src.single) {
 		if (t == 0) {
 			const unsigned long long n = src.single_n > 0 ? (unsigned long long)src.single_n : 0ull;
@@ -335,6 +431,7 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 	} else {
 		for (uint32_t b = t; b < nblk; b += blockDim.x) {
 			const int c = src.blk_elem_num[b];
+			s_ptr[b] = src.blk_input[b];        // fetched beside the counts: one round trip
 			s_prefix[b + 1] = c > 0 ? (uint32_t)c : 0u;
 		}
 		__syncthreads();
@@ -351,12 +448,11 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 	__syncthreads();
 	const bool over = s_total == kNone;
 	const uint32_t total = over ? 0u : s_total;
-	if (blockIdx.x == 0 && t == 0) {
+	if (block == 0 && t == 0) {
 		ctl->total = total;
 		ctl->overflow = over ? 1u : 0u;
 	}
-	const unsigned long long stamp = ctl->stamp_base;
-	for (uint32_t idx = blockIdx.x * blockDim.x + t; idx < total; idx += gridDim.x * blockDim.x) {
+	for (uint32_t idx = block * blockDim.x + t; idx < total; idx += nblocks * blockDim.x) {
 		const uint32_t *p;
 		if (src.single) {
 			p = src.single + 3ull * idx;
@@ -369,7 +465,7 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 				else
 					hi = mid;
 			}
-			p = src.blk_input[lo] + 3ull * (idx - s_prefix[lo]);
+			p = s_ptr[lo] + 3ull * (idx - s_prefix[lo]);
 		}
 		Req r;
 		r.sig = p[0];
@@ -387,100 +483,167 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 	}
 }
 
+template <Op OP>
+__global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
+		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
+{
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap);
+}
+
+// mkv_cycle: the mark pass never touches the table, so it rides in the search
+// launch as extra work-groups (horizontal fusion): its latency-bound atomics hide
+// under the bandwidth-bound probes and one kernel boundary disappears.
+template <Op OP>
+__global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ in,
+		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n, uint32_t search_blocks,
+		Ctl *ctl, ReqSrc src, DevGeom g, unsigned long long *owner, uint4 *reqc, uint8_t *state,
+		uint32_t req_cap)
+{
+	// mark blocks first: they are few and latency-bound, let them start early
+	const uint32_t mark_blocks = gridDim.x - search_blocks;
+	if (blockIdx.x < mark_blocks)
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap);
+	else
+		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
+}
+
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
 // ROUND 1 iterates every request; ROUND 2 the list of round-1 losers, which it also
 // classifies against the round-1 registrant counts.
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, unsigned long long *cnt,
-		const uint4 *reqc, uint8_t *state, Undo *undo, uint32_t *list_lose, uint32_t *list_tail)
+		const uint4 *reqc, uint8_t *state, Undo *undo, int dbg)
 {
-	const uint32_t count = ROUND == 1 ? ctl->total : ctl->list_n[0];
+	if (ROUND == 2 && ctl->any_loser == 0u)
+		return;
+	const uint32_t count = ctl->total;
 	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
 	const uint32_t span = gridDim.x * blockDim.x;
-	const uint32_t iters = (count + span - 1) / span;   // whole waves iterate together
-	for (uint32_t it = 0; it < iters; it++) {
-		const uint32_t i = it * span + blockIdx.x * blockDim.x + threadIdx.x;
-		bool pending = i < count;
-		uint32_t idx = i;
+	uint32_t ndone = 0;
+	for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += span) {
+		// first round trip: request and its state -- independent loads
+		const uint8_t st = state[idx];
+		const bool pending = st == (ROUND == 1 ? ST_PENDING : ST_LOSER);
+		const uint4 rc = (ROUND == 1 || pending) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
+		const Req r = req_of(rc);
+		const uint32_t P = r.hash & g.hash_mask;
+		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+		const uint32_t region = P >> g.region_shift;
+		const unsigned long long key = owner_key(stamp, idx);
+		// second round trip: reservation of P, barrier, primary bucket -- all independent.
+		// The reservation of A is only read if P cannot take the request: a request
+		// needs exclusive use of exactly the buckets it touches.
+		unsigned long long oP = 0, cP = 0, cA = 0;
+		uint32_t bar = kNone;
+		Bkt kP;
+		kP.s0 = kP.s1 = kP.l0 = kP.l1 = make_uint4(0u, 0u, 0u, 0u);
 		if (pending) {
-			if (ROUND == 1)
-				pending = state[idx] == ST_PENDING;
+			if (dbg & 4)
+				oP = key;
+			else if (dbg & 32)
+				oP = ld_agent(&owner[P]);
+			else if (dbg & 64)
+				oP = atomicMin(const_cast<unsigned long long *>(&owner[P]), key);
 			else
-				idx = list_lose[i];
+				oP = owner[P];
+			if (OP == OP_CUCKOO) {
+				bar = ctl->barrier[region];
+				if (ROUND == 2) {
+					cP = cnt[P];
+					cA = cnt[A];
+				}
+			}
+			if (!(dbg & 8))
+				kP = load_bucket(table, P);
 		}
 		bool done = false, lose = false, to_tail = false;
 		if (pending) {
-			const Req r = req_of(reqc[idx]);
-			const uint32_t P = r.hash & g.hash_mask;
-			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-			const unsigned long long key = owner_key(stamp, idx);
-			const unsigned long long oP = owner[P];
-			const unsigned long long oA = owner[A];
-			const bool clean = oP == key && (A == P || oA == key);
-			const uint32_t region = P >> g.region_shift;
-
 			if (OP == OP_CUCKOO && ROUND == 2) {
 				// This request lost a round-1 reservation.  Could it turn hard before
 				// its turn?  Not if it holds a duplicate, or if the empty slots of P
 				// and A outnumber the other round-1 registrants (each takes at most one).
-				uint4 lo, hi;
-				load_sig_row<false>(table, P, lo, hi);
-				bool safe = eq_mask(lo, hi, r.sig) != 0u;
+				bool safe = eq_mask(kP.s0, kP.s1, r.sig) != 0u;
 				if (!safe) {
-					uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
-					uint32_t others = cnt_of(cnt[P], stamp1);
+					uint32_t room = (uint32_t)__popc(eq_mask(kP.s0, kP.s1, 0u));
+					uint32_t others = cnt_of(cP, stamp1);
 					if (A != P) {
+						uint4 lo, hi;
 						load_sig_row<false>(table, A, lo, hi);
 						safe = eq_mask(lo, hi, r.sig) != 0u;
 						room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
-						others += cnt_of(cnt[A], stamp1);
+						others += cnt_of(cA, stamp1);
 					}
 					safe = safe || room >= 1u + others;
 				}
-				if (!safe)
+				if (!safe) {
 					atomicMin(&ctl->barrier[region], idx);
+					if (idx < bar)
+						bar = idx;
+				}
 			}
-
 			// a barrier already published at or below this request: leave it to the tail
-			const bool blocked = OP == OP_CUCKOO && idx >= ctl->barrier[region];
-			if (clean && !blocked) {
+			const bool blocked = OP == OP_CUCKOO && idx >= bar;
+			bool ownP = oP == key, ownA = true, hard = false;
+			if (ownP && !blocked) {
 				Undo u;
 				u.word0 = kNoWord;
 				u.word1 = kNoWord;
 				u.old0 = 0u;
 				u.old1 = 0u;
-				done = apply_static<OP, false, OP == OP_CUCKOO>(table, r, P, A, &u);
+				if (dbg & 1)
+					done = true;
+				else
+					done = apply_primary<OP, OP == OP_CUCKOO>(table, r, P, kP, &u);
+				if (!done) {
+					// P cannot take it: the alternate bucket is needed, and its reservation
+					ownA = A == P || owner[A] == key;
+					if (ownA) {
+						done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
+						hard = !done;
+					}
+				}
 				if (done) {
-					state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
-					if (OP == OP_CUCKOO)
+					if (!(dbg & 16))
+						state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
+					if (OP == OP_CUCKOO && !(dbg & 2))
 						undo[idx] = u;
+					ndone++;
+				}
+			}
+			if (hard) {
+				// hard right now: it and everything after it in the region wait for the tail
+				atomicMin(&ctl->barrier[region], idx);
+				atomicMin(&ctl->first_hard, idx);
+				to_tail = true;
+			} else if (!done) {
+				if (ROUND == 1 && !blocked) {
+					lose = true;
+					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+					if (OP == OP_CUCKOO) {
+						// registrant counts of round 1: every registrant that is not the
+						// owner adds itself (owners are counted as the +1 in the test above)
+						if (!ownP)
+							bump(cnt, P, stamp1);
+						if (A != P && (ownP ? !ownA : owner[A] != key))
+							bump(cnt, A, stamp1);
+					}
 				} else {
-					// hard right now: it and everything after it in the region wait for the tail
-					atomicMin(&ctl->barrier[region], idx);
-					atomicMin(&ctl->first_hard, idx);
 					to_tail = true;
 				}
-			} else if (ROUND == 1 && !blocked) {
-				lose = true;
-				reserve(owner_next, P, A, owner_key(stamp + 1, idx));
-				if (OP == OP_CUCKOO) {
-					// registrant counts of round 1: every non-owner adds itself
-					if (oP != key)
-						bump(cnt, P, stamp1);
-					if (A != P && oA != key)
-						bump(cnt, A, stamp1);
-				}
-			} else {
-				to_tail = true;
 			}
 		}
-		if (ROUND == 1)
-			list_append(list_lose, &ctl->list_n[0], lose, idx);
-		list_append(list_tail, &ctl->list_n[1], to_tail, idx);
-		count_add(&ctl->committed[ROUND - 1], done);
+		if (lose) {
+			state[idx] = ST_LOSER;
+			ctl->any_loser = 1u;
+		}
+		if (to_tail) {
+			state[idx] = ST_TAIL;
+			ctl->any_tail = 1u;
+		}
 	}
+	count_add(ctl->committed[ROUND - 1], ndone);
 }
 
 // ---- K4: tail -------------------------------------------------------------------
@@ -608,7 +771,7 @@ __device__ void tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigne
 template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
-		const Undo *undo, const uint32_t *list_tail, int max_rounds)
+		const Undo *undo, int max_rounds)
 {
 	__shared__ uint32_t keys[kSortCap];
 	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier
@@ -616,11 +779,11 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial;
 	const uint32_t t = threadIdx.x;
 	const uint32_t total = ctl->total;
-	const uint32_t m_list = ctl->list_n[1];
+	const bool any_tail = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
 	if (t < kMaxRegions)
 		s_bar[t] = t < g.nregions ? ctl->barrier[t] : kNone;
 	if (t == 0) {
-		s_n = m_list;
+		s_n = 0;
 		s_undone = 0;
 		s_par = 0;
 		s_serial = 0;
@@ -646,19 +809,34 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 					table[u.word1] = u.old1;
 				if (u.word0 != kNoWord)
 					table[u.word0] = u.old0;
-				state[idx] = ST_PENDING;
-				const uint32_t slot = atomicAdd(&s_n, 1u);   // behind the listed requests
-				if (slot < (uint32_t)kSortCap)
-					keys[slot] = idx;
+				state[idx] = ST_TAIL;
 				atomicAdd(&s_undone, 1u);
 			}
 			wg_sync();
 		}
 	}
+	// -- gather what is left (tags TAIL, and LOSER if round 2 did not run)
+	if (any_tail || (OP == OP_CUCKOO && any_bar)) {
+		// 16 tags per load (the state array is padded to a multiple of 16)
+		const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+		for (uint32_t base = t * 16u; base < total; base += blockDim.x * 16u) {
+			const uint4 v = st4[base >> 4];
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+				const uint32_t idx = base + (uint32_t)k;
+				if (idx < total && (st == ST_TAIL || st == ST_LOSER || st == ST_PENDING)) {
+					const uint32_t slot = atomicAdd(&s_n, 1u);
+					if (slot < (uint32_t)kSortCap)
+						keys[slot] = idx;
+				}
+			}
+		}
+		__syncthreads();
+	}
 	const uint32_t m = s_n;
 	if (m != 0 && m <= (uint32_t)kSortCap) {
-		for (uint32_t i = t; i < m_list; i += blockDim.x)
-			keys[i] = list_tail[i];
 		uint32_t n2 = 1;
 		while (n2 < m)
 			n2 <<= 1;
@@ -685,7 +863,8 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		// too much left for LDS: walk the request states in canonical order
 		uint32_t d = 0;
 		for (uint32_t idx = 0; idx < total; idx++) {
-			if (state[idx] != ST_PENDING)
+			const uint8_t st = state[idx];
+			if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING)
 				continue;
 			apply_serial<OP>(table, g, req_of(reqc[idx]));
 			state[idx] = ST_DONE;
@@ -694,20 +873,30 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		s_serial = d;
 	}
 	__syncthreads();
+	if (t < 64) {
+		// statistics shards: one wave sums and clears them
+		uint32_t c1 = ctl->committed[0][t], c2 = ctl->committed[1][t];
+		ctl->committed[0][t] = 0;
+		ctl->committed[1][t] = 0;
+		for (int off = 32; off > 0; off >>= 1) {
+			c1 += __shfl_down(c1, off);
+			c2 += __shfl_down(c2, off);
+		}
+		if (t == 0) {
+			ctl->last.round1 = c1;
+			ctl->last.round2 = c2;
+		}
+	}
 	if (t == 0) {
 		// diagnostics of this call, then the control block of the next one
 		ctl->last.total = total;
-		ctl->last.round1 = ctl->committed[0];
-		ctl->last.round2 = ctl->committed[1];
 		ctl->last.tail_parallel = s_par;
 		ctl->last.tail_serial = s_serial;
 		ctl->last.undone = s_undone;
 		ctl->last.first_hard = ctl->first_hard;
 		ctl->last.overflow = ctl->overflow;
-		ctl->list_n[0] = 0;
-		ctl->list_n[1] = 0;
-		ctl->committed[0] = 0;
-		ctl->committed[1] = 0;
+		ctl->any_loser = 0;
+		ctl->any_tail = 0;
 		ctl->first_hard = kNone;
 		ctl->total = 0;
 		const unsigned long long st = ctl->next_stamp;
@@ -726,8 +915,9 @@ __global__ void k_init_ctl(Ctl *ctl)
 		ctl->next_stamp = 1 + kStampsPerCall;
 		ctl->total = 0;
 		ctl->overflow = 0;
-		ctl->list_n[0] = ctl->list_n[1] = 0;
-		ctl->committed[0] = ctl->committed[1] = 0;
+		ctl->any_loser = ctl->any_tail = 0;
+		for (int k = 0; k < kShards; k++)
+			ctl->committed[0][k] = ctl->committed[1][k] = 0;
 		ctl->first_hard = kNone;
 		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0};
 	}
@@ -743,10 +933,13 @@ struct Workspace {
 	unsigned long long *owner[2] = {nullptr, nullptr};
 	unsigned long long *cnt = nullptr;
 	uint8_t *state = nullptr;
-	uint32_t *list[2] = {nullptr, nullptr};
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
 	Ctl *ctl = nullptr;
+	// mkv_cycle only: side stream on which the table-independent mark pass of the
+	// insert overlaps the search kernel, and the fork/join events
+	hipStream_t aux = nullptr;
+	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 static std::mutex g_ws_mutex;
@@ -754,24 +947,28 @@ static std::unordered_map<uint64_t, Workspace *> g_ws;   // key: device<<56 ^ st
 
 static void free_ws(Workspace *w)
 {
-	for (int i = 0; i < 2; i++) {
+	for (int i = 0; i < 2; i++)
 		if (w->owner[i]) (void)hipFree(w->owner[i]);
-		if (w->list[i]) (void)hipFree(w->list[i]);
-	}
 	if (w->cnt) (void)hipFree(w->cnt);
 	if (w->state) (void)hipFree(w->state);
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
 	if (w->ctl) (void)hipFree(w->ctl);
+	if (w->aux) (void)hipStreamDestroy(w->aux);
+	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
+	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
 	*w = Workspace();
 }
 
-static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStream_t stream)
+constexpr uint64_t kCycleSalt = 0x00a5a5a5a5a5a5a5ull;   // second workspace of a stream (mkv_cycle inserts)
+
+static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStream_t stream,
+		uint64_t salt = 0)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess)
 		return MKV_EHIP;
-	const uint64_t key = ((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream;
+	const uint64_t key = ((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^ salt;
 	std::lock_guard<std::mutex> lock(g_ws_mutex);
 	Workspace *&w = g_ws[key];
 	if (!w)
@@ -790,10 +987,8 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	w->nbuckets = nb;
 	w->req_cap = rc;
 	bool ok = true;
-	for (int i = 0; i < 2 && ok; i++) {
+	for (int i = 0; i < 2 && ok; i++)
 		ok = ok && hipMalloc(&w->owner[i], nb * 8) == hipSuccess;
-		ok = ok && hipMalloc(&w->list[i], (size_t)rc * 4) == hipSuccess;
-	}
 	ok = ok && hipMalloc(&w->cnt, nb * 8) == hipSuccess;
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
@@ -807,6 +1002,11 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl);
 	}
+	if (ok && salt == kCycleSalt) {
+		ok = ok && hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&w->ev_fork, hipEventDisableTiming) == hipSuccess;
+		ok = ok && hipEventCreateWithFlags(&w->ev_join, hipEventDisableTiming) == hipSuccess;
+	}
 	if (!ok) {
 		free_ws(w);
 		return MKV_ENOMEM;
@@ -815,32 +1015,53 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	return MKV_OK;
 }
 
-template <Op OP>
-static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipStream_t stream)
+static int64_t ws_need(const ReqSrc &src)
 {
-	Workspace *w = nullptr;
 	int64_t need = (int64_t)tuning().req_cap;
-	if (src.single_n > kMaxReqCap)
-		return MKV_ETOOBIG;
 	if (src.single_n > need)
 		need = src.single_n;
 	if (need > kMaxReqCap)
 		need = kMaxReqCap;
-	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, need, stream);
+	return need;
+}
+
+// K1 alone: touches the requests and the workspace, never the table.
+template <Op OP>
+static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream)
+{
+	hipLaunchKernelGGL((k_mark<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
+			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+}
+
+template <Op OP>
+static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream);
+
+template <Op OP>
+static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipStream_t stream)
+{
+	Workspace *w = nullptr;
+	if (src.single_n > kMaxReqCap)
+		return MKV_ETOOBIG;
+	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src), stream);
 	if (rc != MKV_OK)
 		return rc;
+	launch_mark<OP>(w, g, src, stream);
+	return launch_rounds<OP>(w, g, table, stream);
+}
+
+// K2..K4
+template <Op OP>
+static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream)
+{
 	int tail_rounds = tuning().tail_rounds;
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
-
-	hipLaunchKernelGGL((k_mark<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, w->list[0], w->list[1]);
+			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, tuning().debug_skip);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->list[0], w->list[1]);
+			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, 0);
 	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->reqc, w->state, w->undo, w->list[1], tail_rounds);
+			w->cnt, w->reqc, w->state, w->undo, tail_rounds);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -866,6 +1087,94 @@ extern "C" int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		return mkv::run_update<mkv::OP_2CHOICE>(d, t, src, (hipStream_t)stream);
 	return mkv::run_update<mkv::OP_CUCKOO>(d, t, src, (hipStream_t)stream);
+}
+
+// Insert of mkv_cycle, in two halves around the search launch: the mark pass is
+// enqueued on the workspace's side stream right after `fork` (everything already
+// on `stream` is complete before it starts, this cycle's search is not waited
+// for), the rounds follow on `stream` once mark has joined.
+extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_input, int *blk_elem_num,
+		int num_blks, void *stream)
+{
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || num_blks <= 0 || num_blks > mkv::kMaxBlocks || !blk_input ||
+			!blk_elem_num)
+		return MKV_EINVAL;
+	mkv::ReqSrc src;
+	src.blk_input = reinterpret_cast<const uint32_t *const *>(blk_input);
+	src.single = nullptr;
+	src.blk_elem_num = blk_elem_num;
+	src.single_n = 0;
+	src.nblk = (uint32_t)num_blks;
+	mkv::Workspace *w = nullptr;
+	hipStream_t s = (hipStream_t)stream;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
+	if (rc != MKV_OK)
+		return rc;
+	if (hipEventRecord(w->ev_fork, s) != hipSuccess || hipStreamWaitEvent(w->aux, w->ev_fork, 0) != hipSuccess)
+		return MKV_EHIP;
+	if (d.scheme == MKV_SCHEME_2CHOICE)
+		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux);
+	else
+		mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, w->aux);
+	if (hipEventRecord(w->ev_join, w->aux) != hipSuccess)
+		return MKV_EHIP;
+	return MKV_OK;
+}
+
+// Search of a cycle and mark pass of its insert in ONE launch; the rounds follow
+// with mkv_cycle_insert_end(..., joined = 0).
+extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
+		const bucket_t *table, int64_t num_search, ielem_t **blk_input, int *blk_elem_num, int num_blks,
+		void *stream)
+{
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || num_blks <= 0 || num_blks > mkv::kMaxBlocks || !blk_input ||
+			!blk_elem_num || num_search <= 0 || !in || !out || !table)
+		return MKV_EINVAL;
+	mkv::ReqSrc src;
+	src.blk_input = reinterpret_cast<const uint32_t *const *>(blk_input);
+	src.single = nullptr;
+	src.blk_elem_num = blk_elem_num;
+	src.single_n = 0;
+	src.nblk = (uint32_t)num_blks;
+	mkv::Workspace *w = nullptr;
+	hipStream_t s = (hipStream_t)stream;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
+	if (rc != MKV_OK)
+		return rc;
+	const int64_t search_blocks = (num_search + 255) / 256;      // U = 4: 256 requests per block
+	const uint32_t mark_blocks = 256;
+	if (search_blocks + mark_blocks > 0x7fffffffLL)
+		return MKV_ETOOBIG;
+	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
+	const uint2 *in2 = reinterpret_cast<const uint2 *>(in);
+	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
+	if (d.scheme == MKV_SCHEME_2CHOICE)
+		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, 0, s, in2, out, t4, num_search,
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+	else
+		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, 0, s, in2, out, t4, num_search,
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, void *stream, int joined)
+{
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || !table)
+		return MKV_EINVAL;
+	mkv::Workspace *w = nullptr;
+	hipStream_t s = (hipStream_t)stream;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, 0, s, mkv::kCycleSalt);
+	if (rc != MKV_OK)
+		return rc;
+	if (joined && hipStreamWaitEvent(s, w->ev_join, 0) != hipSuccess)
+		return MKV_EHIP;
+	uint32_t *t = reinterpret_cast<uint32_t *>(table);
+	if (d.scheme == MKV_SCHEME_2CHOICE)
+		return mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s);
+	return mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s);
 }
 
 extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
@@ -899,7 +1208,10 @@ extern "C" int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *s
 		need = max_requests;
 	if (need > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	return mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, need, (hipStream_t)stream);
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, need, (hipStream_t)stream);
+	if (rc == MKV_OK)
+		rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, need, (hipStream_t)stream, mkv::kCycleSalt);
+	return rc;
 }
 
 extern "C" void mkv_release_all(void)
@@ -912,7 +1224,14 @@ extern "C" void mkv_release_all(void)
 	mkv::g_ws.clear();
 }
 
+extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
+
 extern "C" int mkv_last_update_info(void *stream, mkv_update_info_t *info)
+{
+	return mkv_last_update_info_ex(stream, 0, info);
+}
+
+extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info)
 {
 	if (!info)
 		return MKV_EINVAL;
@@ -922,7 +1241,8 @@ extern "C" int mkv_last_update_info(void *stream, mkv_update_info_t *info)
 	mkv::Workspace *w = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
-		auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream);
+		auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^
+				(cycle_insert ? mkv::kCycleSalt : 0ull));
 		if (it == mkv::g_ws.end() || !it->second->ctl)
 			return MKV_EINVAL;
 		w = it->second;

@@ -21,6 +21,9 @@ SCHEME_2CHOICE = 1
 
 MKV_SEARCH_KEEP_MISS = 0
 MKV_SEARCH_ZERO_MISS = 1
+MKV_CYCLE_MEMSET = 0x100
+MKV_CYCLE_NO_OVERLAP = 0x200
+MKV_CYCLE_SIDE_STREAM = 0x400
 
 
 @dataclass(frozen=True)
@@ -94,6 +97,30 @@ class MkvError(RuntimeError):
     pass
 
 
+class SearchTimer:
+    """HIP event pairs recorded by the library around the search launch of a cycle."""
+
+    def __init__(self, slots):
+        self.lib = load_library()
+        self.slots = slots
+        self.h = self.lib.mkv_timer_create(slots)
+        if not self.h:
+            raise MkvError("mkv_timer_create failed")
+
+    def elapsed_ms(self):
+        out = []
+        v = ctypes.c_float()
+        for i in range(self.slots):
+            _check(self.lib.mkv_timer_elapsed_ms(ctypes.c_void_p(self.h), i, ctypes.byref(v)), "mkv_timer_elapsed_ms")
+            out.append(v.value)
+        return out
+
+    def close(self):
+        if self.h:
+            self.lib.mkv_timer_destroy(ctypes.c_void_p(self.h))
+            self.h = None
+
+
 def _check(rc, what):
     if rc != 0:
         raise MkvError(f"{what} failed with code {rc}")
@@ -151,6 +178,25 @@ class HashIndex:
         _check(self.lib.mkv_insert(ctypes.byref(self._g), _dev_ptr(self.table), _dev_ptr(ptrs),
                                    _dev_ptr(cnts), num_blks, _stream_ptr(stream)), "mkv_insert")
 
+    def cycle(self, selem, out, ptrs=None, cnts=None, num_blks=0, delem=None, memset=False, overlap="fused",
+              stream=None, timer=None, slot=0):
+        """search -> delete -> insert of one scheduler cycle in one library call.
+        overlap: "fused" (mark pass inside the search launch), "side" (side stream), "none"."""
+        if overlap is True:
+            overlap = "fused"
+        if overlap is False:
+            overlap = "none"
+        flags = (MKV_CYCLE_MEMSET if memset else 0) | {"fused": 0, "side": MKV_CYCLE_SIDE_STREAM,
+                                                        "none": MKV_CYCLE_NO_OVERLAP}[overlap]
+        null = ctypes.c_void_p(0)
+        _check(self.lib.mkv_cycle(
+            ctypes.byref(self._g), _dev_ptr(self.table),
+            _dev_ptr(selem) if selem is not None else null, _dev_ptr(out) if out is not None else null,
+            selem.shape[0] if selem is not None else 0,
+            _dev_ptr(delem) if delem is not None else null, delem.shape[0] if delem is not None else 0,
+            _dev_ptr(ptrs) if num_blks else null, _dev_ptr(cnts) if num_blks else null, num_blks,
+            flags, _stream_ptr(stream), ctypes.c_void_p(timer) if timer else null, slot), "mkv_cycle")
+
     # -- delete ----------------------------------------------------------------
     def delete(self, delem, stream=None):
         assert delem.shape[1] == 3 and delem.element_size() == 4
@@ -163,10 +209,10 @@ class HashIndex:
         _check(self.lib.mkv_reserve(ctypes.byref(self._g), int(max_requests), _stream_ptr(stream)),
                "mkv_reserve")
 
-    def last_update_info(self, stream=None):
+    def last_update_info(self, stream=None, cycle_insert=False):
         info = MkvUpdateInfo()
-        _check(self.lib.mkv_last_update_info(_stream_ptr(stream), ctypes.byref(info)),
-               "mkv_last_update_info")
+        _check(self.lib.mkv_last_update_info_ex(_stream_ptr(stream), 1 if cycle_insert else 0,
+                                                ctypes.byref(info)), "mkv_last_update_info")
         return {k: int(getattr(info, k)) for k, _ in info._fields_}
 
     def table_numpy(self):

@@ -29,7 +29,7 @@ ABI_SYMBOLS = [
     "gpu_hash_search", "gpu_hash_insert", "gpu_hash_delete", "gpu_delete_insert",
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
-    "mkv_set_tuning",
+    "mkv_set_tuning", "mkv_cycle", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -65,11 +65,21 @@ def load_library():
     L.mkv_insert.argtypes = [G, P, P, P, INT, P]
     L.mkv_delete.restype = INT
     L.mkv_delete.argtypes = [G, P, P, I64, P]
+    L.mkv_cycle.restype = INT
+    L.mkv_cycle.argtypes = [G, P, P, P, I64, P, I64, P, P, INT, U32, P, P, INT]
+    L.mkv_timer_create.restype = P
+    L.mkv_timer_create.argtypes = [INT]
+    L.mkv_timer_elapsed_ms.restype = INT
+    L.mkv_timer_elapsed_ms.argtypes = [P, INT, ctypes.POINTER(ctypes.c_float)]
+    L.mkv_timer_destroy.restype = None
+    L.mkv_timer_destroy.argtypes = [P]
     L.mkv_reserve.restype = INT
     L.mkv_reserve.argtypes = [G, I64, P]
     L.mkv_release_all.restype = None
     L.mkv_last_update_info.restype = INT
     L.mkv_last_update_info.argtypes = [P, ctypes.POINTER(MkvUpdateInfo)]
+    L.mkv_last_update_info_ex.restype = INT
+    L.mkv_last_update_info_ex.argtypes = [P, INT, ctypes.POINTER(MkvUpdateInfo)]
     L.mkv_route_requests.restype = INT
     L.mkv_route_requests.argtypes = [P, INT, I64, U32, U32, INT, P, P, P, P, I64, P]
     L.mkv_unroute_results.restype = INT

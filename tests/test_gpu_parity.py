@@ -226,3 +226,45 @@ def test_survey_recorded_eviction_on_gpu():
     assert t[0x1006, 3].item() == 0x1003 and t[0x1006, 11].item() == 203
     assert int(t[0x1205].abs().sum().item()) == 0
     assert idx.last_update_info()["first_hard"] == 0
+
+
+# ----------------------------------------------------------------- cycle ----
+@pytest.mark.parametrize("memset,overlap", [(False, "fused"), (True, "fused"), (False, "side"), (True, "side"),
+                                            (False, "none"), (True, "none")])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_cycle_equals_search_delete_insert(memset, overlap, scheme):
+    """mkv_cycle (one call: clear -> search -> delete -> insert, mark pass beside the
+    search kernel) against the oracle running the three steps in order, over
+    several consecutive cycles on one stream."""
+    g = Geometry(mem_p=16, scheme=scheme)
+    og = ogeom(g)
+    rng = np.random.default_rng(int(memset) * 2 + len(overlap) + 10 * scheme)
+    img = random_table(g, rng, 0.5, 1 << 20)
+    idx = HashIndex(g)
+    idx.load_table(img)
+    exp = img.copy()
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for step in range(4):
+            q = random_requests(g, rng, 5000, 1 << 20)[:, :2].copy()
+            d = random_requests(g, rng, 700, 1 << 20)
+            e = random_requests(g, rng, 4000, 1 << 20, hot=0.1)
+            # make some searches/deletes hit: reuse stored signatures
+            occ = np.argwhere(exp[:, :8] != 0)[:: max(1, len(np.argwhere(exp[:, :8] != 0)) // 2000)]
+            for k, (b, s) in enumerate(occ[:2000]):
+                q[k] = (exp[b, s], b)
+                if k < 300:
+                    d[k] = (exp[b, s], b, exp[b, 8 + s])
+            blocks = split_blocks(e, g, rng, "region")
+            dq, dd = dev(q), dev(d)
+            dblocks = [dev(b) for b in blocks]
+            ptrs, cnts, keep = idx.stage_blocks(dblocks)
+            out = dev(np.full((q.shape[0], 2), 0x5555AAAA, np.uint32))
+            idx.cycle(dq, out, ptrs, cnts, len(keep), delem=dd, memset=memset, overlap=overlap, stream=stream)
+            exp_out = O.search(og, exp, q)
+            O.delete(og, exp, d)
+            O.insert(og, exp, blocks)
+            stream.synchronize()
+            assert np.array_equal(host(out), exp_out), f"search of cycle {step}"
+            got = idx.table_numpy()
+            assert np.array_equal(got, exp), (step, first_diff(got, exp))
