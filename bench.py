@@ -128,15 +128,15 @@ def main():
     mem_p_agg = args.mem_p + log2w
     scheme = M.SCHEME_CUCKOO if args.scheme == "cuckoo" else M.SCHEME_2CHOICE
 
+    stream_gen = Stream(args, rank, world, mem_p_agg)
     if world == 1:
         from megakv_amd.index import HashIndex
         geom = M.Geometry(mem_p=args.mem_p, scheme=scheme)
         engine = SingleGpu(HashIndex(geom, device=device), args)
     else:
-        from megakv_amd.sharded import ShardedIndex
-        engine = ShardedIndex(args.mem_p, world, rank, scheme, device, 1 << args.batch_log2)
-
-    stream_gen = Stream(args, rank, world, mem_p_agg)
+        from megakv_amd.sharded import ShardedIndex, NcclComm
+        engine = ShardedIndex(args.mem_p, world, rank, scheme, device, stream_gen.n_get, stream_gen.n_set,
+                              NcclComm(dist))
     dbg_skip = args.debug_skip
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
@@ -204,6 +204,8 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu:
         cpu = cpu_baseline(engine, stream_gen, args)
 
+    if world > 1 and engine.overflowed():
+        raise SystemExit("a shard slot overflowed: raise cap_factor (results of this run are invalid)")
     if rank == 0:
         line = {
             "metric": "Mops (search+insert) on Zipf-0.99, 2^30-B table, 1/2/4/8 GPUs; HBM GB/s vs roofline",

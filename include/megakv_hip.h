@@ -115,6 +115,27 @@ int mkv_route_requests(const void *in, int elem_words /* 2 = selem, 3 = ielem */
 int mkv_unroute_results(const loc_t *routed, const int32_t *perm, int64_t num_elem,
 		loc_t *out, void *stream);
 
+/* ---- padded exchange format of the sharded index (no host sync in a step) ----
+ * A rank packs its batch into nshards equal slots, one per peer:
+ *   slot = [n_get, n_set, 0, 0 | cap_get x selem_t | cap_set x ielem_t]  (uint32 words)
+ * stably, so the canonical insert order of a shard is (source rank, index).
+ * perm_get[s*cap_get + r] = batch index of the r-th GET sent to shard s.
+ * *overflow is set to 1 when a slot cannot hold its requests (they are dropped). */
+int64_t mkv_pack_slot_words(int64_t cap_get, int64_t cap_set);
+int64_t mkv_pack_scratch_bytes(int64_t n_get, int64_t n_set, int nshards);
+int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		void *stream);
+/* Search every received slot (counts read from the slot headers on the device);
+ * out is [nslots][cap_get][2]; misses are written as 0.  Also copies the slots'
+ * n_set into set_counts[nslots] for the insert that follows. */
+int mkv_search_slots(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
+		int64_t cap_set, loc_t *out, const bucket_t *table, int *set_counts, void *stream);
+/* out[perm_get[pos]] = back[pos] for every position that carried a request. */
+int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf, int nshards,
+		int64_t cap_get, int64_t cap_set, loc_t *out, void *stream);
+
 /* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
  * "search_nt" (non-temporal table loads), "tail_rounds" (0..12 reservation
  * rounds inside the tail work-group), "req_cap" (default requests per update

@@ -12,6 +12,7 @@
 // Three short kernels: per-wave histogram -> one-block exclusive scan over
 // (shard-major, wave-minor) -> stable scatter, ranks from wave ballots.
 #include "mkv_common.h"
+#include "mkv_search_body.h"
 
 namespace mkv {
 
@@ -189,5 +190,286 @@ extern "C" int mkv_unroute_results(const loc_t *routed, const int32_t *perm, int
 		blocks = 2048;
 	hipLaunchKernelGGL(mkv::k_unroute, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
 			reinterpret_cast<const uint2 *>(routed), perm, num_elem, reinterpret_cast<uint2 *>(out));
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+// ===========================================================================
+// Padded exchange format (no host synchronisation anywhere in a step)
+//
+// Each rank packs its local batch into `nshards` equal slots, one per peer:
+//     slot s = [ n_get, n_set, 0, 0 | cap_get x selem_t | cap_set x ielem_t ]
+// Requests keep their batch order inside a slot (stable), so after the
+// all-to-all the canonical insert order of a shard is (source rank, original
+// index).  Equal slots mean the collective needs no size exchange and no
+// device->host copy; the counts travel in the slot header and are consumed on
+// the device (segmented search, insert block counts).  A slot that would
+// overflow raises a flag the caller checks at the end of a run.
+// ===========================================================================
+namespace mkv {
+
+constexpr int kHdrWords = 4;
+
+// wave w < nw_get counts gets, else sets; counts[(kind*nshards + shard) * nw_kind + wave]
+__global__ __launch_bounds__(256) void k_pack_count(const uint32_t *__restrict__ gets, int64_t n_get,
+		const uint32_t *__restrict__ sets, int64_t n_set, uint32_t hash_mask, uint32_t shift, int nshards,
+		uint32_t *__restrict__ wc_get, int64_t nw_get, uint32_t *__restrict__ wc_set, int64_t nw_set)
+{
+	int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const bool is_set = wave >= nw_get;
+	if (is_set)
+		wave -= nw_get;
+	if (is_set && wave >= nw_set)
+		return;
+	const uint32_t *in = is_set ? sets : gets;
+	const int words = is_set ? 3 : 2;
+	const int64_t n = is_set ? n_set : n_get;
+	const int64_t nw = is_set ? nw_set : nw_get;
+	uint32_t *wc = is_set ? wc_set : wc_get;
+	const uint32_t lane = threadIdx.x & 63u;
+	const int64_t lo = wave * kRouteChunk;
+	uint32_t mine = 0;
+	for (int it = 0; it < kRouteChunk / 64; it++) {
+		const int64_t e = lo + it * 64 + lane;
+		const uint32_t s = e < n ? (in[e * words + 1] & hash_mask) >> shift : 0xffffffffu;
+		for (int k = 0; k < nshards; k++) {
+			const uint32_t c = (uint32_t)__popcll(__ballot(s == (uint32_t)k));
+			if (lane == (uint32_t)k)
+				mine += c;
+		}
+	}
+	if (lane < (uint32_t)nshards)
+		wc[(int64_t)lane * nw + wave] = mine;
+}
+
+// one block: per (kind, shard) exclusive scan over the waves, headers, overflow
+__global__ __launch_bounds__(1024) void k_pack_scan(uint32_t *wc_get, int64_t nw_get, uint32_t *wc_set,
+		int64_t nw_set, int nshards, uint32_t *sendbuf, int64_t slot_words, uint32_t cap_get,
+		uint32_t cap_set, int *overflow)
+{
+	__shared__ uint32_t part[1024];
+	__shared__ uint32_t carry;
+	const uint32_t t = threadIdx.x;
+	for (int kind = 0; kind < 2; kind++) {
+		uint32_t *wc = kind ? wc_set : wc_get;
+		const int64_t nw = kind ? nw_set : nw_get;
+		for (int s = 0; s < nshards; s++) {
+			uint32_t *seg = wc + (int64_t)s * nw;
+			if (t == 0)
+				carry = 0;
+			__syncthreads();
+			for (int64_t base = 0; base < nw; base += 1024) {
+				const int64_t i = base + t;
+				const uint32_t v = i < nw ? seg[i] : 0u;
+				part[t] = v;
+				__syncthreads();
+				for (uint32_t off = 1; off < 1024; off <<= 1) {
+					const uint32_t add = t >= off ? part[t - off] : 0u;
+					__syncthreads();
+					part[t] += add;
+					__syncthreads();
+				}
+				const uint32_t incl = part[t];
+				if (i < nw)
+					seg[i] = carry + incl - v;
+				__syncthreads();
+				if (t == 1023)
+					carry += incl;
+				__syncthreads();
+			}
+			if (t == 0) {
+				const uint32_t total = carry;
+				const uint32_t cap = kind ? cap_set : cap_get;
+				uint32_t *hdr = sendbuf + (int64_t)s * slot_words;
+				if (total > cap) {
+					*overflow = 1;
+					hdr[kind] = 0;             // nothing of this kind is sent for this slot
+				} else {
+					hdr[kind] = total;
+				}
+				if (kind == 0) {
+					hdr[2] = 0;
+					hdr[3] = 0;
+				}
+			}
+			__syncthreads();
+		}
+	}
+}
+
+__global__ __launch_bounds__(256) void k_pack_scatter(const uint32_t *__restrict__ gets, int64_t n_get,
+		const uint32_t *__restrict__ sets, int64_t n_set, uint32_t hash_mask, uint32_t shift, int nshards,
+		const uint32_t *__restrict__ wc_get, int64_t nw_get, const uint32_t *__restrict__ wc_set,
+		int64_t nw_set, uint32_t *__restrict__ sendbuf, int64_t slot_words, uint32_t cap_get,
+		uint32_t cap_set, int32_t *__restrict__ perm_get)
+{
+	int64_t wave = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+	const bool is_set = wave >= nw_get;
+	if (is_set)
+		wave -= nw_get;
+	if (is_set && wave >= nw_set)
+		return;
+	const uint32_t *in = is_set ? sets : gets;
+	const int words = is_set ? 3 : 2;
+	const int64_t n = is_set ? n_set : n_get;
+	const int64_t nw = is_set ? nw_set : nw_get;
+	const uint32_t *wc = is_set ? wc_set : wc_get;
+	const uint32_t cap = is_set ? cap_set : cap_get;
+	const int64_t region = is_set ? kHdrWords + (int64_t)cap_get * 2 : kHdrWords;
+	const uint32_t lane = threadIdx.x & 63u;
+	const int64_t lo = wave * kRouteChunk;
+	// lane s keeps the running within-slot cursor of shard s; a slot that overflowed
+	// (header count 0 while requests exist) drops its requests, the flag is already set
+	uint32_t cursor = 0;
+	bool slot_ok = true;
+	if (lane < (uint32_t)nshards) {
+		cursor = wc[(int64_t)lane * nw + wave];
+	}
+	for (int it = 0; it < kRouteChunk / 64; it++) {
+		const int64_t e = lo + it * 64 + lane;
+		const bool live = e < n;
+		uint32_t w0 = 0, w1 = 0, w2 = 0;
+		if (live) {
+			w0 = in[e * words];
+			w1 = in[e * words + 1];
+			if (is_set)
+				w2 = in[e * words + 2];
+		}
+		const uint32_t s = live ? (w1 & hash_mask) >> shift : 0xffffffffu;
+		uint32_t dst = 0;
+		for (int k = 0; k < nshards; k++) {
+			const unsigned long long m = __ballot(s == (uint32_t)k);
+			const uint32_t base = __shfl(cursor, k);
+			if (s == (uint32_t)k)
+				dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+			if (lane == (uint32_t)k)
+				cursor += (uint32_t)__popcll(m);
+		}
+		(void)slot_ok;
+		if (live && dst < cap) {
+			uint32_t *p = sendbuf + (int64_t)s * slot_words + region + (int64_t)dst * words;
+			p[0] = w0;
+			p[1] = w1;
+			if (is_set)
+				p[2] = w2;
+			else
+				perm_get[(int64_t)s * cap_get + dst] = (int32_t)e;
+		}
+	}
+}
+
+// segmented search over received slots; block (seg, chunk).  Block 0 also
+// publishes the per-source insert counts for the insert that follows.
+__global__ __launch_bounds__(256) void k_search_slots(const uint32_t *__restrict__ recvbuf,
+		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
+		uint32_t hash_mask, uint32_t blk_mask, uint32_t chunks_per_slot, int nslots, int *set_counts)
+{
+	const uint32_t seg = blockIdx.x / chunks_per_slot;
+	const uint32_t chunk = blockIdx.x - seg * chunks_per_slot;
+	const uint32_t *slot = recvbuf + (int64_t)seg * slot_words;
+	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)nslots)
+		set_counts[threadIdx.x] = (int)recvbuf[(int64_t)threadIdx.x * slot_words + 1];
+	const uint32_t n = slot[0];
+	if ((uint64_t)chunk * 256u >= n)
+		return;
+	search_body<4, true, false>(chunk, reinterpret_cast<const uint2 *>(slot + kHdrWords),
+			out + (int64_t)seg * cap_get * 2, table, (int64_t)n, hash_mask, blk_mask);
+}
+
+// results come back in the layout they were sent in: result of slot s, position r
+// belongs to original request perm[s*cap_get + r]
+__global__ __launch_bounds__(256) void k_unpack_results(const uint2 *__restrict__ back,
+		const int32_t *__restrict__ perm_get, const uint32_t *__restrict__ sendbuf, int64_t slot_words,
+		uint32_t cap_get, int nshards, uint2 *__restrict__ out)
+{
+	const int64_t total = (int64_t)nshards * cap_get;
+	for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < total;
+			pos += (int64_t)gridDim.x * blockDim.x) {
+		const uint32_t s = (uint32_t)(pos / cap_get);
+		const uint32_t r = (uint32_t)(pos - (int64_t)s * cap_get);
+		if (r < sendbuf[(int64_t)s * slot_words])
+			out[perm_get[pos]] = back[pos];
+	}
+}
+
+}  // namespace mkv
+
+extern "C" int64_t mkv_pack_slot_words(int64_t cap_get, int64_t cap_set)
+{
+	return mkv::kHdrWords + cap_get * 2 + cap_set * 3;
+}
+
+extern "C" int64_t mkv_pack_scratch_bytes(int64_t n_get, int64_t n_set, int nshards)
+{
+	const int64_t nw_get = (n_get + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
+	const int64_t nw_set = (n_set + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
+	return (nw_get + nw_set) * nshards * 4 + 64;
+}
+
+extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		void *stream)
+{
+	if (n_get < 0 || n_set < 0 || nshards < 1 || nshards > mkv::kMaxShards || shard_shift > 31 ||
+			cap_get < 0 || cap_set < 0 || cap_get > 0x7fffffffLL || cap_set > 0x7fffffffLL || !sendbuf ||
+			!scratch || !overflow || (n_get && (!gets || !perm_get)) || (n_set && !sets))
+		return MKV_EINVAL;
+	const int64_t nw_get = (n_get + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
+	const int64_t nw_set = (n_set + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
+	if (scratch_bytes < (nw_get + nw_set) * nshards * 4)
+		return MKV_ETOOBIG;
+	hipStream_t s = (hipStream_t)stream;
+	uint32_t *wc_get = reinterpret_cast<uint32_t *>(scratch);
+	uint32_t *wc_set = wc_get + nw_get * nshards;
+	const int64_t slot_words = mkv_pack_slot_words(cap_get, cap_set);
+	const int64_t waves = nw_get + nw_set;
+	const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gets);
+	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sets);
+	if (waves > 0) {
+		dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+		hipLaunchKernelGGL(mkv::k_pack_count, grid, block, 0, s, g32, n_get, s32, n_set, hash_mask_agg,
+				shard_shift, nshards, wc_get, nw_get, wc_set, nw_set);
+	}
+	hipLaunchKernelGGL(mkv::k_pack_scan, dim3(1), dim3(1024), 0, s, wc_get, nw_get, wc_set, nw_set, nshards,
+			sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set, overflow);
+	if (waves > 0) {
+		dim3 grid((unsigned)((waves + 3) / 4)), block(256);
+		hipLaunchKernelGGL(mkv::k_pack_scatter, grid, block, 0, s, g32, n_get, s32, n_set, hash_mask_agg,
+				shard_shift, nshards, wc_get, nw_get, wc_set, nw_set, sendbuf, slot_words, (uint32_t)cap_get,
+				(uint32_t)cap_set, perm_get);
+	}
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+extern "C" int mkv_search_slots(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots,
+		int64_t cap_get, int64_t cap_set, loc_t *out, const bucket_t *table, int *set_counts, void *stream)
+{
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || nslots < 1 || nslots > mkv::kMaxShards || cap_get < 0 ||
+			cap_get > 0x7fffffffLL || !recvbuf || !out || !table || !set_counts)
+		return MKV_EINVAL;
+	const uint32_t chunks = (uint32_t)((cap_get + 255) / 256);
+	const uint32_t blocks = (chunks ? chunks : 1u) * (uint32_t)nslots;
+	hipLaunchKernelGGL(mkv::k_search_slots, dim3(blocks), dim3(256), 0, (hipStream_t)stream, recvbuf,
+			mkv_pack_slot_words(cap_get, cap_set), (uint32_t)cap_get, out,
+			reinterpret_cast<const uint4 *>(table), d.hash_mask, d.blk_mask, chunks ? chunks : 1u, nslots,
+			set_counts);
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+extern "C" int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf,
+		int nshards, int64_t cap_get, int64_t cap_set, loc_t *out, void *stream)
+{
+	if (nshards < 1 || cap_get < 0 || !back || !perm_get || !sendbuf || !out)
+		return MKV_EINVAL;
+	const int64_t total = (int64_t)nshards * cap_get;
+	if (total == 0)
+		return MKV_OK;
+	int64_t blocks = (total + 255) / 256;
+	if (blocks > 2048)
+		blocks = 2048;
+	hipLaunchKernelGGL(mkv::k_unpack_results, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+			reinterpret_cast<const uint2 *>(back), perm_get, sendbuf, mkv_pack_slot_words(cap_get, cap_set),
+			(uint32_t)cap_get, nshards, reinterpret_cast<uint2 *>(out));
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }

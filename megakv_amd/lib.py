@@ -29,7 +29,8 @@ ABI_SYMBOLS = [
     "gpu_hash_search", "gpu_hash_insert", "gpu_hash_delete", "gpu_delete_insert",
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
-    "mkv_set_tuning", "mkv_cycle", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_set_tuning", "mkv_cycle", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
+    "mkv_search_slots", "mkv_unpack_results", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -82,6 +83,16 @@ def load_library():
     L.mkv_last_update_info_ex.argtypes = [P, INT, ctypes.POINTER(MkvUpdateInfo)]
     L.mkv_route_requests.restype = INT
     L.mkv_route_requests.argtypes = [P, INT, I64, U32, U32, INT, P, P, P, P, I64, P]
+    L.mkv_pack_slot_words.restype = I64
+    L.mkv_pack_slot_words.argtypes = [I64, I64]
+    L.mkv_pack_scratch_bytes.restype = I64
+    L.mkv_pack_scratch_bytes.argtypes = [I64, I64, INT]
+    L.mkv_pack_requests.restype = INT
+    L.mkv_pack_requests.argtypes = [P, I64, P, I64, U32, U32, INT, P, I64, I64, P, P, I64, P, P]
+    L.mkv_search_slots.restype = INT
+    L.mkv_search_slots.argtypes = [G, P, INT, I64, I64, P, P, P, P]
+    L.mkv_unpack_results.restype = INT
+    L.mkv_unpack_results.argtypes = [P, P, P, INT, I64, I64, P, P]
     L.mkv_unroute_results.restype = INT
     L.mkv_unroute_results.argtypes = [P, P, I64, P, P]
     L.mkv_set_tuning.restype = INT

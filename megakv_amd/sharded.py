@@ -1,0 +1,218 @@
+"""Sharded (multi-GPU) hash index: one process per GPU, RCCL all-to-all over xGMI.
+
+New design -- the reference is single-GPU.  The table shards
+naturally: an entry's alternate bucket keeps the top bits of its primary bucket
+index (reference libgpuhash/gpu_hash.cu:66-67), so with G = 2^k ranks and an
+aggregate table of MEM_P_agg = MEM_P_local + k, rank g owns the buckets whose
+top k index bits are g, as a local MEM_P_local table whose region split is
+IBLOCK_P - k (the alternate rule restricted to the shard).  A request is served
+entirely by shard(hash) = (hash & HASH_MASK_agg) >> (MEM_P_local - 6).
+
+One step on every rank (all stream-ordered, no host synchronisation):
+  1. pack     local batch -> G equal slots [n_get, n_set | gets | sets], stable
+              (mkv_pack_requests, three short kernels)
+  2. forward  all_to_all_single of the slots (equal splits: no size exchange)
+  3. local    search of every received slot (counts read from the headers on the
+              device), then insert with one block per source rank -- canonical
+              order inside a shard = (source rank, index in its batch)
+  4. back     all_to_all_single of the result slots
+  5. unpack   results to the original request order
+
+The collective is injected (`comm`): RCCL through torch.distributed for real
+runs, a CPU-staged gloo exchange so two processes can share one GPU in tests.
+The device operations are injected too (`ops`), so the orchestration can run on
+CPU tensors in the gloo tests.
+"""
+import ctypes
+import math
+
+import numpy as np
+import torch
+
+from .index import Geometry, HashIndex, _dev_ptr, _stream_ptr, _check
+from . import workload as W
+
+
+def shard_geometry(mem_p_local, world, scheme, iblock_p=3, max_cuckoo=5):
+    k = world.bit_length() - 1
+    assert 1 << k == world, "world size must be a power of two"
+    assert k <= iblock_p, "at most 2^IBLOCK_P shards: regions are the closed units"
+    return Geometry(mem_p=mem_p_local, scheme=scheme, iblock_p=iblock_p - k, max_cuckoo=max_cuckoo)
+
+
+class NcclComm:
+    """RCCL all-to-all on device tensors (stream-ordered by torch.distributed)."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_to_all(self, out, inp):
+        self.dist.all_to_all_single(out, inp)
+
+
+class StagedComm:
+    """all-to-all through host memory with any backend (gloo): lets several
+    ranks share one GPU in tests.  Synchronises the stream; not for benchmarks."""
+
+    def __init__(self, dist):
+        self.dist = dist
+
+    def all_to_all(self, out, inp):
+        torch.cuda.current_stream().synchronize() if inp.is_cuda else None
+        h_in = inp.cpu()
+        h_out = torch.empty_like(h_in)
+        self.dist.all_to_all_single(h_out, h_in)
+        out.copy_(h_out)
+
+
+class HipOps:
+    """The device side of a step, through the C ABI of the HIP library."""
+
+    def __init__(self, index: HashIndex):
+        self.idx = index
+        self.lib = index.lib
+
+    def slot_words(self, cap_get, cap_set):
+        return int(self.lib.mkv_pack_slot_words(cap_get, cap_set))
+
+    def scratch_bytes(self, n_get, n_set, g):
+        return int(self.lib.mkv_pack_scratch_bytes(n_get, n_set, g))
+
+    def pack(self, gets, sets, agg_mask, shift, g, sendbuf, cap_get, cap_set, perm, scratch, overflow):
+        null = ctypes.c_void_p(0)
+        _check(self.lib.mkv_pack_requests(
+            _dev_ptr(gets) if gets.shape[0] else null, gets.shape[0],
+            _dev_ptr(sets) if sets.shape[0] else null, sets.shape[0],
+            agg_mask, shift, g, _dev_ptr(sendbuf), cap_get, cap_set, _dev_ptr(perm), _dev_ptr(scratch),
+            scratch.numel() * scratch.element_size(), _dev_ptr(overflow), _stream_ptr(None)), "mkv_pack_requests")
+
+    def search_slots(self, recvbuf, g, cap_get, cap_set, out_slots, set_counts):
+        _check(self.lib.mkv_search_slots(ctypes.byref(self.idx._g), _dev_ptr(recvbuf), g, cap_get, cap_set,
+                                         _dev_ptr(out_slots), _dev_ptr(self.idx.table), _dev_ptr(set_counts),
+                                         _stream_ptr(None)), "mkv_search_slots")
+
+    def insert_slots(self, ptrs, set_counts, g):
+        self.idx.insert_staged(ptrs, set_counts, g, None)
+
+    def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out):
+        _check(self.lib.mkv_unpack_results(_dev_ptr(back), _dev_ptr(perm), _dev_ptr(sendbuf), g, cap_get,
+                                           cap_set, _dev_ptr(out), _stream_ptr(None)), "mkv_unpack_results")
+
+    def slot_set_pointers(self, recvbuf, g, slot_words, cap_get):
+        base = recvbuf.data_ptr()
+        return torch.tensor([base + 4 * (s * slot_words + 4 + 2 * cap_get) for s in range(g)],
+                            dtype=torch.int64).to(recvbuf.device)
+
+
+class _TorchTimer:
+    """event pairs around the local search launch (bench.py roofline at N > 1)"""
+
+    def __init__(self, slots):
+        self.h = self
+        self.ev = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                   for _ in range(slots)]
+
+    def start(self, slot):
+        self.ev[slot][0].record()
+
+    def stop(self, slot):
+        self.ev[slot][1].record()
+
+    def elapsed_ms(self):
+        return [a.elapsed_time(b) for a, b in self.ev]
+
+
+class ShardedIndex:
+    def __init__(self, mem_p_local, world, rank, scheme, device, n_get, n_set, comm, ops=None,
+                 cap_factor=2.0, index=None):
+        self.world, self.rank = world, rank
+        self.device = torch.device(device)
+        self.geom = shard_geometry(mem_p_local, world, scheme)
+        self.k = world.bit_length() - 1
+        self.mem_p_agg = mem_p_local + self.k
+        self.agg_mask = (1 << (self.mem_p_agg - 6)) - 1
+        self.shift = mem_p_local - 6
+        self.comm = comm
+        if ops is None:
+            index = index or HashIndex(self.geom, device=device)
+            ops = HipOps(index)
+        self.idx = index
+        self.ops = ops
+        # slot capacities: twice the average share, so Zipf-hot shards still fit
+        self.n_get, self.n_set = n_get, n_set
+        self.cap_get = int(math.ceil(n_get / world * cap_factor / 256.0)) * 256 if n_get else 0
+        self.cap_set = int(math.ceil(n_set / world * cap_factor / 16.0)) * 16 + 16 if n_set else 0
+        self.slot_words = ops.slot_words(self.cap_get, self.cap_set)
+        i32 = dict(dtype=torch.int32, device=self.device)
+        self.sendbuf = torch.zeros((world, self.slot_words), **i32)
+        self.recvbuf = torch.zeros((world, self.slot_words), **i32)
+        self.out_slots = torch.zeros((world, max(self.cap_get, 1), 2), **i32)
+        self.back_slots = torch.zeros((world, max(self.cap_get, 1), 2), **i32)
+        self.perm = torch.zeros((world * max(self.cap_get, 1),), **i32)
+        self.scratch = torch.zeros((ops.scratch_bytes(max(n_get, 1), max(n_set, 1), world) // 4 + 16,), **i32)
+        self.overflow = torch.zeros((1,), **i32)
+        self.set_counts = torch.zeros((world,), **i32)
+        self.set_ptrs = ops.slot_set_pointers(self.recvbuf, world, self.slot_words, self.cap_get)
+
+    # -- shard of a request ---------------------------------------------------------
+    def shard_of(self, hash_np):
+        return (hash_np.astype(np.uint64) & np.uint64(self.agg_mask)) >> np.uint64(self.shift)
+
+    # -- one step -----------------------------------------------------------------------
+    def step_tensors(self, gets, sets, out):
+        """gets [n,2], sets [m,3] int32 tensors of this rank; out [n,2] receives the
+        search results in request order.  Everything is enqueued on the current stream."""
+        o, w = self.ops, self.world
+        o.pack(gets, sets, self.agg_mask, self.shift, w, self.sendbuf, self.cap_get, self.cap_set,
+               self.perm, self.scratch, self.overflow)
+        self.comm.all_to_all(self.recvbuf, self.sendbuf)
+        timing = getattr(self, "_timing", None)
+        if timing:
+            timing[0].start(timing[1])
+        o.search_slots(self.recvbuf, w, self.cap_get, self.cap_set, self.out_slots, self.set_counts)
+        if timing:
+            timing[0].stop(timing[1])
+        if self.cap_set:
+            o.insert_slots(self.set_ptrs, self.set_counts, w)
+        self.comm.all_to_all(self.back_slots, self.out_slots)
+        o.unpack(self.back_slots, self.perm, self.sendbuf, w, self.cap_get, self.cap_set, out)
+
+    # -- the engine interface bench.py drives --------------------------------------------------
+    def preload(self, P, keying):
+        g = self.geom
+        step = 1 << 22
+        self.idx.reserve(2 * step // self.world + 4096)
+        for lo in range(1, P, step):
+            k = np.arange(lo, min(lo + step, P), dtype=np.uint64).astype(np.uint32)
+            e = W.make_ielem(k, None, keying)
+            mine = e[self.shard_of(e[:, 1]) == self.rank]
+            blocks = W.bin_inserts(mine, g.mem_p, g.iblock_p, W.BIN_REGION)
+            self.idx.insert([torch.from_numpy(np.ascontiguousarray(b).view(np.int32)).to(self.device)
+                             for b in blocks])
+        torch.cuda.synchronize()
+
+    def stage(self, gets, sets):
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(self.device)
+        return {"q": dev(gets), "s": dev(sets.reshape(-1, 3)),
+                "out": torch.zeros((gets.shape[0], 2), dtype=torch.int32, device=self.device)}
+
+    def reserve(self, stream):
+        self.idx.reserve(self.world * self.cap_set + 1024, stream)
+
+    def make_timer(self, slots):
+        return _TorchTimer(slots)
+
+    def step(self, b, stream, pair):
+        self._timing = pair            # [timer, slot] or None
+        self.step_tensors(b["q"], b["s"], b["out"])
+        self._timing = None
+
+    def hit_rate(self, b):
+        o = b["out"]
+        return round(float(((o[:, 0] != 0) | (o[:, 1] != 0)).float().mean().item()), 6)
+
+    def search_requests_per_launch(self, sg):
+        return sg.n_get
+
+    def overflowed(self):
+        return bool(self.overflow.item())
