@@ -137,7 +137,7 @@ int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_
 		int64_t cap_get, int64_t cap_set, loc_t *out, void *stream);
 
 /* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
- * "search_nt" (non-temporal table loads), "tail_rounds" (0..12 reservation
+ * "search_nt" (non-temporal table loads), "tail_rounds" (0..48 reservation
  * rounds inside the tail work-group), "req_cap" (default requests per update
  * call).  Results never depend on them; they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);

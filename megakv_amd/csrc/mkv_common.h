@@ -74,7 +74,7 @@ __device__ __forceinline__ uint32_t preferred_slot(uint32_t empties, uint32_t or
 struct Tuning {
 	int search_u;        // requests in flight per 4-lane group: 1, 2, 4 or 8
 	int search_nt;       // non-temporal table loads in search
-	int tail_rounds;     // reservation rounds inside the tail work-group (0..12)
+	int tail_rounds;     // reservation rounds inside the tail work-group (0..48)
 	long long req_cap;   // default request capacity of an update workspace
 	int debug_skip;      // diagnostics only (breaks results): bit0 no table stores, bit1 no undo log,
 	                     // bit2 no owner loads, bit3 no bucket load, bit4 no state store

@@ -71,9 +71,9 @@ Tuning &tuning()
 		s = getenv("MKV_SEARCH_NT");
 		v.search_nt = s ? atoi(s) != 0 : 0;
 		s = getenv("MKV_TAIL_ROUNDS");
-		v.tail_rounds = s ? atoi(s) : 12;
+		v.tail_rounds = s ? atoi(s) : 48;
 		if (v.tail_rounds < 0) v.tail_rounds = 0;
-		if (v.tail_rounds > 12) v.tail_rounds = 12;
+		if (v.tail_rounds > 48) v.tail_rounds = 48;
 		s = getenv("MKV_REQ_CAP");
 		v.req_cap = s ? atoll(s) : (1ll << 22);
 		if (v.req_cap < 1024) v.req_cap = 1024;
@@ -120,7 +120,7 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 	} else if (!strcmp(name, "search_nt")) {
 		t.search_nt = value != 0;
 	} else if (!strcmp(name, "tail_rounds")) {
-		if (value < 0 || value > 12)
+		if (value < 0 || value > 48)
 			return MKV_EINVAL;
 		t.tail_rounds = (int)value;
 	} else if (!strcmp(name, "debug_skip")) {

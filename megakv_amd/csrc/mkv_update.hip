@@ -57,7 +57,7 @@ namespace mkv {
 
 constexpr int kMaxBlocks = 1024;    // insert blocks per call
 constexpr int kMaxRegions = 32;
-constexpr int kMaxTailRounds = 12;  // in-work-group rounds of the tail
+constexpr int kMaxTailRounds = 48;  // in-work-group rounds of the tail
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;
 constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
 constexpr uint32_t kGridAll = 1024;
@@ -675,19 +675,32 @@ __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 }
 
 // Reservation rounds inside the tail work-group over keys[0..m) (kNone = done).
+// Same rule as the grid-wide rounds, with decide-then-commit separated by
+// work-group barriers.  A region whose lowest pending request is itself the
+// round's barrier (hard, or possibly hard) gets that one request replayed
+// exactly -- it is first in canonical order and nothing else of its region runs
+// in that round -- after which the requests behind it are parallel work again.
+// Returns the number of requests still pending.
 template <Op OP>
-__device__ void tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
+__device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
-		const uint32_t *s_bar, uint32_t *s_rbar, uint32_t *s_progress, uint32_t *s_par, int max_rounds)
+		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
+		int max_rounds)
 {
 	const uint32_t t = threadIdx.x;
 	const unsigned long long stamp0 = ctl->stamp_base + 2;
-	for (int round = 0; round < max_rounds; round++) {
+	uint32_t left = m;
+	for (int round = 0; round < max_rounds && left != 0; round++) {
 		const unsigned long long stamp = stamp0 + (unsigned)round;
-		if (t < kMaxRegions)
-			s_rbar[t] = s_bar[t];
-		if (t == 0)
+		if (t < kMaxRegions) {
+			s_rbar[t] = kNone;
+			s_rmin[t] = kNone;
+		}
+		if (t == 0) {
 			*s_progress = 0;
+			*s_left = 0;
+		}
+		__syncthreads();
 		// register; the count decides who might turn hard
 		for (uint32_t i = t; i < m; i += blockDim.x) {
 			const uint32_t idx = keys[i];
@@ -701,6 +714,7 @@ __device__ void tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigne
 				bump(cnt, P, stamp);
 				if (A != P)
 					bump(cnt, A, stamp);
+				atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
 		}
 		wg_sync();
@@ -748,35 +762,50 @@ __device__ void tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigne
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
-			if (OP == OP_CUCKOO && idx >= s_rbar[P >> g.region_shift])
-				continue;
-			if (ld_agent(&owner[P]) != key || (A != P && ld_agent(&owner[A]) != key))
-				continue;
-			if (apply_static<OP, true, false>(table, r, P, A, nullptr)) {
+			bool done = false;
+			if (OP == OP_CUCKOO) {
+				const uint32_t region = P >> g.region_shift;
+				const uint32_t bar = s_rbar[region];
+				if (idx == bar && idx == s_rmin[region]) {
+					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
+					done = true;
+				} else if (idx >= bar) {
+					atomicAdd(s_left, 1u);
+					continue;
+				}
+			}
+			if (!done && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
+				done = apply_static<OP, true, false>(table, r, P, A, nullptr);
+			if (done) {
 				state[idx] = ST_DONE;
 				keys[i] = kNone;
 				atomicAdd(s_progress, 1u);
+			} else {
+				atomicAdd(s_left, 1u);
 			}
 		}
 		wg_sync();
 		const uint32_t progress = *s_progress;
+		left = *s_left;
 		if (t == 0)
 			*s_par += progress;
 		__syncthreads();
 		if (progress == 0)
 			break;
 	}
+	return left;
 }
 
 template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
-		const Undo *undo, int max_rounds)
+		const Undo *undo, uint32_t *glist, int max_rounds)
 {
-	__shared__ uint32_t keys[kSortCap];
-	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier
+	__shared__ uint32_t lkeys[kSortCap];
+	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
-	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial;
+	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
+	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left;
 	const uint32_t t = threadIdx.x;
 	const uint32_t total = ctl->total;
 	const bool any_tail = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
@@ -826,51 +855,57 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			for (int k = 0; k < 16; k++) {
 				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 				const uint32_t idx = base + (uint32_t)k;
-				if (idx < total && (st == ST_TAIL || st == ST_LOSER || st == ST_PENDING)) {
-					const uint32_t slot = atomicAdd(&s_n, 1u);
-					if (slot < (uint32_t)kSortCap)
-						keys[slot] = idx;
-				}
+				if (idx < total && (st == ST_TAIL || st == ST_LOSER || st == ST_PENDING))
+					glist[atomicAdd(&s_n, 1u)] = idx;
 			}
 		}
 		__syncthreads();
 	}
 	const uint32_t m = s_n;
-	if (m != 0 && m <= (uint32_t)kSortCap) {
+	if (m != 0) {
+		// work list: LDS when it fits, else the global list it was gathered into
+		const bool in_lds = m <= (uint32_t)kSortCap;
+		uint32_t *keys = in_lds ? lkeys : glist;
 		uint32_t n2 = 1;
 		while (n2 < m)
 			n2 <<= 1;
-		for (uint32_t i = m + t; i < n2; i += blockDim.x)
-			keys[i] = kNone;
-		__syncthreads();
-		tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_bar, s_rbar, &s_progress,
-				&s_par, max_rounds);
-		// what is left: canonical order, one request at a time
-		lds_sort(keys, n2);
-		if (t == 0) {
+		if (in_lds) {
+			for (uint32_t i = t; i < m; i += blockDim.x)
+				lkeys[i] = glist[i];
+			for (uint32_t i = m + t; i < n2; i += blockDim.x)
+				lkeys[i] = kNone;
+		}
+		wg_sync();
+		const uint32_t left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin,
+				&s_progress, &s_par, &s_left, max_rounds);
+		if (left != 0 && in_lds) {
+			// what is left: canonical order, one request at a time
+			lds_sort(lkeys, n2);
+			if (t == 0) {
+				uint32_t d = 0;
+				for (uint32_t i = 0; i < m; i++) {
+					const uint32_t idx = lkeys[i];
+					if (idx == kNone)
+						break;
+					apply_serial<OP>(table, g, req_of(reqc[idx]));
+					state[idx] = ST_DONE;
+					d++;
+				}
+				s_serial = d;
+			}
+		} else if (left != 0 && t == 0) {
+			// too much left for LDS: walk the request states in canonical order
 			uint32_t d = 0;
-			for (uint32_t i = 0; i < m; i++) {
-				const uint32_t idx = keys[i];
-				if (idx == kNone)
-					break;
+			for (uint32_t idx = 0; idx < total; idx++) {
+				const uint8_t st = state[idx];
+				if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING)
+					continue;
 				apply_serial<OP>(table, g, req_of(reqc[idx]));
 				state[idx] = ST_DONE;
 				d++;
 			}
 			s_serial = d;
 		}
-	} else if (m != 0 && t == 0) {
-		// too much left for LDS: walk the request states in canonical order
-		uint32_t d = 0;
-		for (uint32_t idx = 0; idx < total; idx++) {
-			const uint8_t st = state[idx];
-			if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING)
-				continue;
-			apply_serial<OP>(table, g, req_of(reqc[idx]));
-			state[idx] = ST_DONE;
-			d++;
-		}
-		s_serial = d;
 	}
 	__syncthreads();
 	if (t < 64) {
@@ -935,6 +970,7 @@ struct Workspace {
 	uint8_t *state = nullptr;
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
+	uint32_t *glist = nullptr;
 	Ctl *ctl = nullptr;
 	// mkv_cycle only: side stream on which the table-independent mark pass of the
 	// insert overlaps the search kernel, and the fork/join events
@@ -953,6 +989,7 @@ static void free_ws(Workspace *w)
 	if (w->state) (void)hipFree(w->state);
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
+	if (w->glist) (void)hipFree(w->glist);
 	if (w->ctl) (void)hipFree(w->ctl);
 	if (w->aux) (void)hipStreamDestroy(w->aux);
 	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
@@ -993,6 +1030,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
+	ok = ok && hipMalloc(&w->glist, (size_t)rc * 4) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
 	if (ok) {
 		// owner entries start at "no owner" (all ones); counters at zero
@@ -1061,7 +1099,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, 0);
 	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->reqc, w->state, w->undo, tail_rounds);
+			w->cnt, w->reqc, w->state, w->undo, w->glist, tail_rounds);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

@@ -22,7 +22,7 @@ def set_tuning(name, value):
 @pytest.fixture(autouse=True)
 def _defaults():
     yield
-    set_tuning("tail_rounds", 12)
+    set_tuning("tail_rounds", 48)
     set_tuning("search_u", 4)
     set_tuning("search_nt", 0)
 
