@@ -96,6 +96,7 @@ typedef struct mkv_update_info_s {
 	uint32_t tail_serial;	/* replayed one by one in canonical order */
 	uint32_t undone;		/* optimistic commits rolled back behind an eviction barrier */
 	uint32_t first_hard;	/* lowest request index found needing an eviction chain, or 0xffffffff */
+	uint32_t chains;		/* eviction chains committed in the grid-wide rounds (conflict-free) */
 } mkv_update_info_t;
 
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);

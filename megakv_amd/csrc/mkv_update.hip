@@ -70,7 +70,8 @@ enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 // that round; LOSER: lost a round-1 reservation (round 2 retries it); TAIL: left
 // for the tail work-group.  Rounds find their work by these tags -- no atomic
 // work lists, no same-address atomics on the hot path.
-constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_LOSER = 4, ST_TAIL = 5;
+constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_LOSER = 4, ST_TAIL = 5,
+		ST_CHAIN1 = 6, ST_CHAIN2 = 7;   // committed with an eviction chain (log in the chain log)
 constexpr int kShards = 64;         // statistics counters are spread over this many words
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
@@ -81,7 +82,17 @@ constexpr unsigned long long kStampMax = (1ull << 40) - 1;
 constexpr int64_t kMaxReqCap = (1ll << kIdxBits) - 16;
 
 struct Info {
-	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow;
+	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow, chains;
+};
+
+// Log of an optimistic eviction chain: every word it overwrote, in order.
+constexpr int kChainLogWords = 14;      // 6 evictions x 2 words, or 5 x 2 + final placement
+constexpr uint32_t kChainLogCap = 1u << 16;
+struct ChainLog {
+	uint32_t n;
+	uint32_t word[kChainLogWords];
+	uint32_t old[kChainLogWords];
+	uint32_t pad[3];
 };
 
 struct Ctl {
@@ -92,6 +103,8 @@ struct Ctl {
 	uint32_t any_loser;              // plain flags, set by whoever produces such work
 	uint32_t any_tail;
 	uint32_t first_hard;
+	uint32_t chain_n;                // chain-log entries handed out this call
+	uint32_t chain_ok;               // chains committed optimistically
 	uint32_t committed[2][kShards];
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
@@ -483,6 +496,83 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	}
 }
 
+// Optimistic eviction chain of a hard request that owns P and A (grid-wide rounds).
+// Every data-dependent bucket is claimed in the round-1 owner table first: all
+// requests of the call registered their P and A there in K1, so an entry stamped
+// with this call's round-1 stamp means "somebody of this batch may touch this
+// bucket" (or another chain claimed it) -> conflict: the chain restores what it
+// wrote and reports failure, and the caller falls back to the region barrier.
+// Without conflict the chain's touch set is disjoint from every other request's,
+// so its position in the order is immaterial.  Everything is logged for the
+// roll-back behind a barrier.  Follows ref gpu_hash.cu:357-423.
+__device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint32_t A, uint32_t idx,
+		unsigned long long *owner1, unsigned long long stamp1, Ctl *ctl, ChainLog *logs, uint32_t *log_slot)
+{
+	if (g.max_cuckoo + 1u > (uint32_t)kChainLogWords / 2u)
+		return false;
+	const uint32_t slot = atomicAdd(&ctl->chain_n, 1u);
+	if (slot >= kChainLogCap)
+		return false;
+	ChainLog *L = &logs[slot];
+	const unsigned long long mykey = owner_key(stamp1, idx);
+	const unsigned long long stamp_field = kStampMax - stamp1;
+	uint32_t n = 0;
+	uint32_t sig = r.sig, loc = r.loc, b = A;
+	const uint32_t v = r.sig & 7u;              // victim slot: ORIGINAL signature (:360)
+	bool ok = true;
+	for (uint32_t k = 0;; k++) {
+		const uint64_t ws = sig_word(b, v), wl = loc_word(b, v);
+		const uint32_t vsig = table[ws], vloc = table[wl];
+		L->word[n] = (uint32_t)ws;
+		L->old[n++] = vsig;
+		L->word[n] = (uint32_t)wl;
+		L->old[n++] = vloc;
+		table[ws] = sig;
+		table[wl] = loc;
+		if (k >= g.max_cuckoo)
+			break;                                  // victim dropped (:414-423)
+		sig = vsig;
+		loc = vloc;
+		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
+		const unsigned long long old = atomicMin(&owner1[b], mykey);
+		if ((old >> kIdxBits) == stamp_field && old != mykey) {
+			ok = false;                             // someone of this batch may touch b
+			break;
+		}
+		uint4 lo, hi;
+		load_sig_row<false>(table, b, lo, hi);
+		const uint32_t m = eq_mask(lo, hi, sig);
+		if (m) {
+			const uint64_t w = loc_word(b, (uint32_t)__ffs((int)m) - 1u);
+			L->word[n] = (uint32_t)w;
+			L->old[n++] = table[w];
+			table[w] = loc;
+			break;
+		}
+		const uint32_t e = eq_mask(lo, hi, 0u);
+		if (e) {
+			const uint32_t s = preferred_slot(e, r.sig);
+			const uint64_t ws2 = sig_word(b, s), wl2 = loc_word(b, s);
+			L->word[n] = (uint32_t)ws2;
+			L->old[n++] = 0u;
+			L->word[n] = (uint32_t)wl2;
+			L->old[n++] = table[wl2];
+			table[ws2] = sig;
+			table[wl2] = loc;
+			break;
+		}
+	}
+	if (!ok) {
+		for (uint32_t i = n; i-- > 0;)
+			table[L->word[i]] = L->old[i];
+		L->n = 0;
+		return false;
+	}
+	L->n = n;
+	*log_slot = slot;
+	return true;
+}
+
 template <Op OP>
 __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
@@ -513,7 +603,7 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, unsigned long long *cnt,
-		const uint4 *reqc, uint8_t *state, Undo *undo, int dbg)
+		const uint4 *reqc, uint8_t *state, Undo *undo, ChainLog *chain_logs, int dbg)
 {
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
@@ -522,6 +612,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
 	const uint32_t span = gridDim.x * blockDim.x;
 	uint32_t ndone = 0;
+	// owner table holding the round-1 registrations of every request of this call
+	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
 	for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += span) {
 		// first round trip: request and its state -- independent loads
 		const uint8_t st = state[idx];
@@ -599,9 +691,27 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				if (!done) {
 					// P cannot take it: the alternate bucket is needed, and its reservation
 					ownA = A == P || owner[A] == key;
+					bool chained = false;
 					if (ownA) {
 						done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
-						hard = !done;
+						if (OP == OP_CUCKOO && !done) {
+							// hard: P and A full without duplicate -> eviction chain
+							atomicMin(&ctl->first_hard, idx);
+							uint32_t log_slot = 0;
+							chained = try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot);
+							done = chained;
+							hard = !chained;
+							u.word0 = log_slot;
+						}
+					}
+					if (chained) {
+						state[idx] = ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2;
+						undo[idx] = u;
+						atomicAdd(&ctl->chain_ok, 1u);
+						ndone++;
+						done = true;
+						lose = false;
+						goto next_request;
 					}
 				}
 				if (done) {
@@ -613,9 +723,9 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				}
 			}
 			if (hard) {
-				// hard right now: it and everything after it in the region wait for the tail
+				// a chain that could not be run optimistically: it and everything after it
+				// in the region wait for the tail
 				atomicMin(&ctl->barrier[region], idx);
-				atomicMin(&ctl->first_hard, idx);
 				to_tail = true;
 			} else if (!done) {
 				if (ROUND == 1 && !blocked) {
@@ -634,6 +744,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				}
 			}
 		}
+next_request:
 		if (lose) {
 			state[idx] = ST_LOSER;
 			ctl->any_loser = 1u;
@@ -799,7 +910,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
-		const Undo *undo, uint32_t *glist, int max_rounds)
+		const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds)
 {
 	__shared__ uint32_t lkeys[kSortCap];
 	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
@@ -826,18 +937,26 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	if (OP == OP_CUCKOO && any_bar) {
 		for (int pass = 0; pass < 2; pass++) {
 			const uint8_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
+			const uint8_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
 			for (uint32_t idx = t; idx < total; idx += blockDim.x) {
-				if (state[idx] != tag)
+				const uint8_t st = state[idx];
+				if (st != tag && st != ctag)
 					continue;
 				const uint4 rc = reqc[idx];
 				const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
 				if (idx < s_bar[region])
 					continue;
 				const Undo u = undo[idx];
-				if (u.word1 != kNoWord)
-					table[u.word1] = u.old1;
-				if (u.word0 != kNoWord)
-					table[u.word0] = u.old0;
+				if (st == ctag) {
+					const ChainLog *L = &chain_logs[u.word0];
+					for (uint32_t i = L->n; i-- > 0;)
+						table[L->word[i]] = L->old[i];
+				} else {
+					if (u.word1 != kNoWord)
+						table[u.word1] = u.old1;
+					if (u.word0 != kNoWord)
+						table[u.word0] = u.old0;
+				}
 				state[idx] = ST_TAIL;
 				atomicAdd(&s_undone, 1u);
 			}
@@ -930,6 +1049,9 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->last.undone = s_undone;
 		ctl->last.first_hard = ctl->first_hard;
 		ctl->last.overflow = ctl->overflow;
+		ctl->last.chains = ctl->chain_ok;
+		ctl->chain_n = 0;
+		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
 		ctl->any_tail = 0;
 		ctl->first_hard = kNone;
@@ -954,7 +1076,9 @@ __global__ void k_init_ctl(Ctl *ctl)
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k] = ctl->committed[1][k] = 0;
 		ctl->first_hard = kNone;
-		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0};
+		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0};
+		ctl->chain_n = 0;
+		ctl->chain_ok = 0;
 	}
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
@@ -971,6 +1095,7 @@ struct Workspace {
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
 	uint32_t *glist = nullptr;
+	ChainLog *chain_logs = nullptr;
 	Ctl *ctl = nullptr;
 	// mkv_cycle only: side stream on which the table-independent mark pass of the
 	// insert overlaps the search kernel, and the fork/join events
@@ -990,6 +1115,7 @@ static void free_ws(Workspace *w)
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
 	if (w->glist) (void)hipFree(w->glist);
+	if (w->chain_logs) (void)hipFree(w->chain_logs);
 	if (w->ctl) (void)hipFree(w->ctl);
 	if (w->aux) (void)hipStreamDestroy(w->aux);
 	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
@@ -1031,6 +1157,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
 	ok = ok && hipMalloc(&w->glist, (size_t)rc * 4) == hipSuccess;
+	ok = ok && hipMalloc(&w->chain_logs, (size_t)kChainLogCap * sizeof(ChainLog)) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
 	if (ok) {
 		// owner entries start at "no owner" (all ones); counters at zero
@@ -1095,11 +1222,11 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, tuning().debug_skip);
+			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, tuning().debug_skip);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, 0);
+			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0);
 	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->reqc, w->state, w->undo, w->glist, tail_rounds);
+			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -1297,5 +1424,6 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->tail_serial = h.last.tail_serial;
 	info->undone = h.last.undone;
 	info->first_hard = h.last.first_hard;
+	info->chains = h.last.chains;
 	return MKV_OK;
 }

@@ -126,6 +126,8 @@ CASES = [
     (16, 20000, 0.5, 1 << 30, 0.0, 0.2, 0.01, "app"),    # alternate == primary cases
     (20, 60000, 0.2, 1 << 31, 0.0, 0.0, 0.0, "region"),  # the reference test's regime
     (20, 60000, 0.85, 1 << 31, 0.05, 0.0, 0.0, "single"),
+    (22, 200000, 0.8, 1 << 31, 0.0, 0.0, 0.0, "region"),  # many eviction chains, few conflicts between them
+    (22, 200000, 0.6, 1 << 31, 0.02, 0.01, 0.0, "app"),
 ]
 
 
@@ -154,6 +156,20 @@ def test_insert_result_independent_of_round_count(rounds, scheme):
     e = random_requests(g, rng, 6000, 1 << 20, hot=0.2, zero_low=0.05)
     got, exp, info = run_insert_case(g, img, split_blocks(e, g, rng, "region"))
     assert np.array_equal(got, exp), (first_diff(got, exp), info)
+
+
+def test_eviction_chains_commit_in_parallel():
+    """At LF ~0.8 thousands of requests are hard; chains whose buckets nobody else
+    touches commit inside the grid-wide rounds (info['chains']), the rest behind
+    the region barrier -- the table still equals the oracle's."""
+    g = Geometry(mem_p=24)
+    rng = np.random.default_rng(21)
+    img = random_table(g, rng, 0.8, 1 << 31)
+    e = random_requests(g, rng, 100000, 1 << 31)
+    got, exp, info = run_insert_case(g, img, split_blocks(e, g, rng, "region"))
+    assert np.array_equal(got, exp), (first_diff(got, exp), info)
+    assert info["chains"] > 100, info
+    assert info["first_hard"] != 0xFFFFFFFF
 
 
 def test_insert_tail_fallback_beyond_lds_sort():
