@@ -71,7 +71,8 @@ enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 // for the tail work-group.  Rounds find their work by these tags -- no atomic
 // work lists, no same-address atomics on the hot path.
 constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_LOSER = 4, ST_TAIL = 5,
-		ST_CHAIN1 = 6, ST_CHAIN2 = 7;   // committed with an eviction chain (log in the chain log)
+		ST_CHAIN1 = 6, ST_CHAIN2 = 7,   // committed with an eviction chain (log in the chain log)
+		ST_CHAIN_OK = 8;                // tail rounds: chain walked and all its buckets claimed
 constexpr int kShards = 64;         // statistics counters are spread over this many words
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
@@ -652,29 +653,6 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 		}
 		bool done = false, lose = false, to_tail = false;
 		if (pending) {
-			if (OP == OP_CUCKOO && ROUND == 2) {
-				// This request lost a round-1 reservation.  Could it turn hard before
-				// its turn?  Not if it holds a duplicate, or if the empty slots of P
-				// and A outnumber the other round-1 registrants (each takes at most one).
-				bool safe = eq_mask(kP.s0, kP.s1, r.sig) != 0u;
-				if (!safe) {
-					uint32_t room = (uint32_t)__popc(eq_mask(kP.s0, kP.s1, 0u));
-					uint32_t others = cnt_of(cP, stamp1);
-					if (A != P) {
-						uint4 lo, hi;
-						load_sig_row<false>(table, A, lo, hi);
-						safe = eq_mask(lo, hi, r.sig) != 0u;
-						room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
-						others += cnt_of(cA, stamp1);
-					}
-					safe = safe || room >= 1u + others;
-				}
-				if (!safe) {
-					atomicMin(&ctl->barrier[region], idx);
-					if (idx < bar)
-						bar = idx;
-				}
-			}
 			// a barrier already published at or below this request: leave it to the tail
 			const bool blocked = OP == OP_CUCKOO && idx >= bar;
 			bool ownP = oP == key, ownA = true, hard = false;
@@ -728,6 +706,29 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				atomicMin(&ctl->barrier[region], idx);
 				to_tail = true;
 			} else if (!done) {
+				if (OP == OP_CUCKOO && ROUND == 2) {
+					// Lost round 1 AND still pending after round 2.  Round-1 commits behind
+					// it relied on its reach being static; could it turn hard before its
+					// turn?  Not if it holds a duplicate, or if P (or A, or both together)
+					// has more empty slots than other round-1 registrants (each takes at
+					// most one).  Otherwise it becomes the region's barrier.
+					bool safe = eq_mask(kP.s0, kP.s1, r.sig) != 0u;
+					if (!safe) {
+						const uint32_t roomP = (uint32_t)__popc(eq_mask(kP.s0, kP.s1, 0u));
+						const uint32_t othP = cnt_of(cP, stamp1);
+						safe = roomP >= 1u + othP;
+						if (!safe && A != P) {
+							uint4 lo, hi;
+							load_sig_row<false>(table, A, lo, hi);
+							const uint32_t roomA = (uint32_t)__popc(eq_mask(lo, hi, 0u));
+							const uint32_t othA = cnt_of(cA, stamp1);
+							safe = eq_mask(lo, hi, r.sig) != 0u || roomA >= 1u + othA ||
+									roomP + roomA >= 1u + othP + othA;
+						}
+					}
+					if (!safe)
+						atomicMin(&ctl->barrier[region], idx);
+				}
 				if (ROUND == 1 && !blocked) {
 					lose = true;
 					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
@@ -782,6 +783,44 @@ __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 			}
 			__syncthreads();
 		}
+	}
+}
+
+// Tail rounds, decide phase: read-only walk of the eviction chain of a hard request
+// that owns P and A, claiming every further bucket in the round's owner table.
+// True = nobody registered or claimed any of them this round, the chain never
+// returns to a bucket it already used (so the walk saw what the real run will
+// see) -- the request may run its chain in this round's commit phase.
+__device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
+		uint32_t idx, unsigned long long *owner, unsigned long long stamp)
+{
+	if (g.max_cuckoo > 6u)
+		return false;
+	const unsigned long long mykey = owner_key(stamp, idx);
+	const unsigned long long stamp_field = kStampMax - stamp;
+	const uint32_t v = r.sig & 7u;
+	uint32_t seen[8];
+	uint32_t nseen = 0;
+	uint32_t b = A;
+	for (uint32_t k = 0;; k++) {
+		if (k >= g.max_cuckoo)
+			return true;                            // last eviction drops its victim: no further bucket
+		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
+		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);
+		if (nb == P || nb == A)
+			return false;
+		for (uint32_t i = 0; i < nseen; i++)
+			if (seen[i] == nb)
+				return false;
+		const unsigned long long old = atomicMin(&owner[nb], mykey);
+		if ((old >> kIdxBits) == stamp_field && old != mykey)
+			return false;
+		seen[nseen++] = nb;
+		uint4 lo, hi;
+		load_sig_row<true>(table, nb, lo, hi);
+		if (eq_mask(lo, hi, vsig) || eq_mask(lo, hi, 0u))
+			return true;                            // the victim finds a duplicate or room here
+		b = nb;
 	}
 }
 
@@ -858,7 +897,14 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
 					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
 				}
-				const bool bad = clean ? room == 0u : room < 1u + others;
+				bool bad = clean ? room == 0u : room < 1u + others;
+				if (bad && clean) {
+					// hard right now: it may still run this round if its chain is all its own
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp)) {
+						state[idx] = ST_CHAIN_OK;
+						bad = false;
+					}
+				}
 				if (bad)
 					atomicMin(&s_rbar[region], idx);
 			}
@@ -881,8 +927,13 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
 					done = true;
 				} else if (idx >= bar) {
+					if (state[idx] == ST_CHAIN_OK)
+						state[idx] = ST_TAIL;
 					atomicAdd(s_left, 1u);
 					continue;
+				} else if (state[idx] == ST_CHAIN_OK) {
+					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
+					done = true;
 				}
 			}
 			if (!done && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
@@ -974,7 +1025,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			for (int k = 0; k < 16; k++) {
 				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 				const uint32_t idx = base + (uint32_t)k;
-				if (idx < total && (st == ST_TAIL || st == ST_LOSER || st == ST_PENDING))
+				if (idx < total && (st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
 					glist[atomicAdd(&s_n, 1u)] = idx;
 			}
 		}
@@ -1017,7 +1068,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			uint32_t d = 0;
 			for (uint32_t idx = 0; idx < total; idx++) {
 				const uint8_t st = state[idx];
-				if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING)
+				if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING && st != ST_CHAIN_OK)
 					continue;
 				apply_serial<OP>(table, g, req_of(reqc[idx]));
 				state[idx] = ST_DONE;
