@@ -255,6 +255,7 @@ class SingleGpu:
         if sets.shape[0]:
             blocks = [dev(x, self.device) for x in W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION)]
             b["ptrs"], b["cnts"], b["keep"] = self.idx.stage_blocks(blocks)
+            b["n_set"] = int(sets.shape[0])
         return b
 
     def search_requests_per_launch(self, sg):
@@ -278,7 +279,7 @@ class SingleGpu:
             timer, slot = (pair[0], pair[1]) if pair else (None, 0)
             self.idx.cycle(b["q"], b["out"], b.get("ptrs"), b.get("cnts"), len(b["keep"]) if "keep" in b else 0,
                            memset=self.args.memset, overlap=self.args.overlap, stream=stream,
-                           timer=timer, slot=slot)
+                           timer=timer, slot=slot, insert_hint=b.get("n_set", 0))
             return
 
     def step(self, b, stream, pair):

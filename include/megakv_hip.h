@@ -49,6 +49,14 @@ int mkv_search(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, void *stream);
 
+/* Same, with an upper bound on the total number of requests (the counts are device
+ * memory, so the library cannot know it).  With a hint above the "insert_chunk"
+ * tuning value (64 K) the batch is processed in canonical-index chunks, which keeps
+ * the redo work behind an eviction barrier small; results do not depend on it.
+ * size_hint <= 0: unknown, one pass (what mkv_insert / gpu_hash_insert do). */
+int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
+
 int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 		int64_t num_elem, void *stream);
 
@@ -61,14 +69,15 @@ int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
  * pass, which reads only the requests and never the table, is launched as extra
  * work-groups of the search kernel.  MKV_CYCLE_SIDE_STREAM runs that pass on an
  * internal side stream instead (it starts after everything enqueued on `stream`
- * before the call); MKV_CYCLE_NO_OVERLAP issues the plain three-call sequence. */
+ * before the call); MKV_CYCLE_NO_OVERLAP issues the plain three-call sequence.
+ * insert_hint: upper bound on the insert requests (see mkv_insert_hinted), 0 = unknown. */
 #define MKV_CYCLE_MEMSET      0x100u
 #define MKV_CYCLE_NO_OVERLAP  0x200u
 #define MKV_CYCLE_SIDE_STREAM 0x400u
 int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t *search_in,
 		loc_t *search_out, int64_t num_search, delem_t *delete_in, int64_t num_delete,
-		ielem_t **blk_input, int *blk_elem_num, int num_blks, uint32_t search_flags, void *stream,
-		void *timer, int slot);
+		ielem_t **blk_input, int *blk_elem_num, int num_blks, int64_t insert_hint, uint32_t search_flags,
+		void *stream, void *timer, int slot);
 
 /* Measurement aid: `slots` HIP event pairs; mkv_cycle(timer, slot) records pair
  * `slot` on the caller's stream around its search launch.  timer may be NULL. */
@@ -97,6 +106,8 @@ typedef struct mkv_update_info_s {
 	uint32_t undone;		/* optimistic commits rolled back behind an eviction barrier */
 	uint32_t first_hard;	/* lowest request index found needing an eviction chain, or 0xffffffff */
 	uint32_t chains;		/* eviction chains committed in the grid-wide rounds (conflict-free) */
+	uint32_t bar_chain;		/* region barriers raised by chains that met another request's bucket */
+	uint32_t bar_class;		/* region barriers raised for requests that might turn hard */
 } mkv_update_info_t;
 
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);
@@ -139,7 +150,7 @@ int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_
 
 /* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
  * "search_nt" (non-temporal table loads), "tail_rounds" (0..48 reservation
- * rounds inside the tail work-group), "req_cap" (default requests per update
+ * rounds inside the tail work-group), "insert_chunk" (requests per chunk of a hinted insert), "req_cap" (default requests per update
  * call).  Results never depend on them; they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);
 

@@ -119,11 +119,14 @@ extern "C" void mkv_timer_destroy(void *timer)
 
 extern "C" int mkv_tuning_is_default_search(void);
 extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_input, int *blk_elem_num,
-		int num_blks, void *stream);
-extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, void *stream, int joined);
+		int num_blks, long long size_hint, void *stream);
+extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream, int joined);
 extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 		const bucket_t *table, int64_t num_search, ielem_t **blk_input, int *blk_elem_num, int num_blks,
-		void *stream);
+		long long size_hint, void *stream);
+extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
 
 // One scheduler cycle for one worker in a single call: clear the result buffer,
 // search, delete, insert, all on `stream` (reference src/mega_scheduler.c:393-502
@@ -131,8 +134,8 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 // that are not bound to the three-call ABI.
 extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t *search_in,
 		loc_t *search_out, int64_t num_search, delem_t *delete_in, int64_t num_delete,
-		ielem_t **blk_input, int *blk_elem_num, int num_blks, uint32_t search_flags, void *stream,
-		void *timer, int slot)
+		ielem_t **blk_input, int *blk_elem_num, int num_blks, int64_t insert_hint, uint32_t search_flags,
+		void *stream, void *timer, int slot)
 {
 	int rc = MKV_OK;
 	MkvTimer *tm = reinterpret_cast<MkvTimer *>(timer);
@@ -148,7 +151,7 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 			mkv_tuning_is_default_search();
 	const bool overlap = side;
 	if (side) {
-		rc = mkv_cycle_insert_begin(geom, blk_input, blk_elem_num, num_blks, stream);
+		rc = mkv_cycle_insert_begin(geom, blk_input, blk_elem_num, num_blks, insert_hint, stream);
 		if (rc != MKV_OK)
 			return rc;
 	}
@@ -156,7 +159,7 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 		if (tm)
 			(void)hipEventRecord(tm->ev[2 * slot], (hipStream_t)stream);
 		rc = mkv_cycle_search_mark(geom, search_in, search_out, table, num_search, blk_input, blk_elem_num,
-				num_blks, stream);
+				num_blks, insert_hint, stream);
 		if (tm)
 			(void)hipEventRecord(tm->ev[2 * slot + 1], (hipStream_t)stream);
 		if (rc != MKV_OK)
@@ -183,9 +186,10 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 			return rc;
 	}
 	if (overlap || fused)
-		rc = mkv_cycle_insert_end(geom, table, stream, overlap ? 1 : 0);
+		rc = mkv_cycle_insert_end(geom, table, blk_input, blk_elem_num, num_blks, insert_hint, stream,
+				overlap ? 1 : 0);
 	else if (num_blks > 0)
-		rc = mkv_insert(geom, table, blk_input, blk_elem_num, num_blks, stream);
+		rc = mkv_insert_hinted(geom, table, blk_input, blk_elem_num, num_blks, insert_hint, stream);
 	return rc;
 }
 

@@ -78,6 +78,10 @@ Tuning &tuning()
 		v.req_cap = s ? atoll(s) : (1ll << 22);
 		if (v.req_cap < 1024) v.req_cap = 1024;
 		v.debug_skip = 0;
+		s = getenv("MKV_INSERT_CHUNK");
+		v.insert_chunk = s ? atoll(s) : 65536;
+		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
+		v.insert_chunk &= ~15ll;
 		return v;
 	}();
 	return t;
@@ -123,6 +127,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 0 || value > 48)
 			return MKV_EINVAL;
 		t.tail_rounds = (int)value;
+	} else if (!strcmp(name, "insert_chunk")) {
+		if (value < 1024)
+			return MKV_EINVAL;
+		t.insert_chunk = value & ~15ll;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

@@ -83,7 +83,8 @@ constexpr unsigned long long kStampMax = (1ull << 40) - 1;
 constexpr int64_t kMaxReqCap = (1ll << kIdxBits) - 16;
 
 struct Info {
-	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow, chains;
+	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow, chains,
+			bar_chain, bar_class;   // barriers published by failed chains / by classification
 };
 
 // Log of an optimistic eviction chain: every word it overwrote, in order.
@@ -106,6 +107,8 @@ struct Ctl {
 	uint32_t first_hard;
 	uint32_t chain_n;                // chain-log entries handed out this call
 	uint32_t chain_ok;               // chains committed optimistically
+	uint32_t bar_chain, bar_class;
+	uint32_t carry_lo;               // lowest request index carried over from earlier chunk passes (kNone: none)
 	uint32_t committed[2][kShards];
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
@@ -428,7 +431,8 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 // ---- K1: mark -----------------------------------------------------------------
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
-		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
+		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap,
+		uint32_t lo_idx, uint32_t hi_idx)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
@@ -466,7 +470,21 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		ctl->total = total;
 		ctl->overflow = over ? 1u : 0u;
 	}
-	for (uint32_t idx = block * blockDim.x + t; idx < total; idx += nblocks * blockDim.x) {
+	const uint32_t end = hi_idx < total ? hi_idx : total;
+	// requests an earlier chunk pass of this call left unresolved ride along: they have
+	// lower indices, so they win every reservation they share with this chunk's requests
+	const uint32_t carry = ctl->carry_lo;
+	const uint32_t start = carry < lo_idx ? carry : lo_idx;
+	for (uint32_t idx = start + block * blockDim.x + t; idx < end && idx >= start;
+			idx += nblocks * blockDim.x) {
+		if (idx < lo_idx) {
+			if (state[idx] != ST_PENDING)
+				continue;
+			const uint4 rc = reqc[idx];
+			reserve(owner, rc.y & g.hash_mask, alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask),
+					owner_key(stamp, idx));
+			continue;
+		}
 		const uint32_t *p;
 		if (src.single) {
 			p = src.single + 3ull * idx;
@@ -576,9 +594,10 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 
 template <Op OP>
 __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
-		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap)
+		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
+		uint32_t hi_idx)
 {
-	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap);
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx);
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -588,12 +607,12 @@ template <Op OP>
 __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ in,
 		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n, uint32_t search_blocks,
 		Ctl *ctl, ReqSrc src, DevGeom g, unsigned long long *owner, uint4 *reqc, uint8_t *state,
-		uint32_t req_cap)
+		uint32_t req_cap, uint32_t hi_idx)
 {
 	// mark blocks first: they are few and latency-bound, let them start early
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
-		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap);
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx);
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
 }
@@ -604,18 +623,22 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, unsigned long long *cnt,
-		const uint4 *reqc, uint8_t *state, Undo *undo, ChainLog *chain_logs, int dbg)
+		const uint4 *reqc, uint8_t *state, Undo *undo, ChainLog *chain_logs, int dbg, uint32_t lo_idx,
+		uint32_t hi_idx)
 {
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
-	const uint32_t count = ctl->total;
+	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
 	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
 	const uint32_t span = gridDim.x * blockDim.x;
 	uint32_t ndone = 0;
 	// owner table holding the round-1 registrations of every request of this call
 	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
-	for (uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x; idx < count; idx += span) {
+	const uint32_t carry = ctl->carry_lo;
+	const uint32_t start = carry < lo_idx ? carry : lo_idx;
+	for (uint32_t idx = start + blockIdx.x * blockDim.x + threadIdx.x; idx < count && idx >= start;
+			idx += span) {
 		// first round trip: request and its state -- independent loads
 		const uint8_t st = state[idx];
 		const bool pending = st == (ROUND == 1 ? ST_PENDING : ST_LOSER);
@@ -704,6 +727,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				// a chain that could not be run optimistically: it and everything after it
 				// in the region wait for the tail
 				atomicMin(&ctl->barrier[region], idx);
+				atomicAdd(&ctl->bar_chain, 1u);
 				to_tail = true;
 			} else if (!done) {
 				if (OP == OP_CUCKOO && ROUND == 2) {
@@ -726,8 +750,10 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 									roomP + roomA >= 1u + othP + othA;
 						}
 					}
-					if (!safe)
+					if (!safe) {
 						atomicMin(&ctl->barrier[region], idx);
+						atomicAdd(&ctl->bar_class, 1u);
+					}
 				}
 				if (ROUND == 1 && !blocked) {
 					lose = true;
@@ -961,7 +987,8 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
-		const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds)
+		const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds, uint32_t lo_idx,
+		uint32_t hi_idx, int first_chunk, int last_chunk)
 {
 	__shared__ uint32_t lkeys[kSortCap];
 	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
@@ -969,7 +996,11 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left;
 	const uint32_t t = threadIdx.x;
-	const uint32_t total = ctl->total;
+	const uint32_t total_all = ctl->total;
+	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
+	const uint32_t carry_in = ctl->carry_lo;
+	if (carry_in < lo_idx)
+		lo_idx = carry_in;                        // this pass also covered the carried requests
 	const bool any_tail = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
 	if (t < kMaxRegions)
 		s_bar[t] = t < g.nregions ? ctl->barrier[t] : kNone;
@@ -989,9 +1020,15 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		for (int pass = 0; pass < 2; pass++) {
 			const uint8_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
 			const uint8_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
-			for (uint32_t idx = t; idx < total; idx += blockDim.x) {
-				const uint8_t st = state[idx];
-				if (st != tag && st != ctag)
+			const uint4 *st4r = reinterpret_cast<const uint4 *>(state);
+			for (uint32_t base = (lo_idx & ~15u) + t * 16u; base < total && base >= (lo_idx & ~15u); base += blockDim.x * 16u) {
+				const uint4 v4 = st4r[base >> 4];
+				const uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+				for (int kk = 0; kk < 16; kk++) {
+				const uint8_t st = (uint8_t)((w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu);
+				const uint32_t idx = base + (uint32_t)kk;
+				if (idx < lo_idx || idx >= total || (st != tag && st != ctag))
 					continue;
 				const uint4 rc = reqc[idx];
 				const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
@@ -1010,28 +1047,119 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				}
 				state[idx] = ST_TAIL;
 				atomicAdd(&s_undone, 1u);
+				}
 			}
 			wg_sync();
 		}
 	}
-	// -- gather what is left (tags TAIL, and LOSER if round 2 did not run)
-	if (any_tail || (OP == OP_CUCKOO && any_bar)) {
-		// 16 tags per load (the state array is padded to a multiple of 16)
+	__shared__ uint32_t s_carry;
+	if (t == 0)
+		s_carry = kNone;
+	__syncthreads();
+	const bool work_left = any_tail || (OP == OP_CUCKOO && any_bar);
+	// A non-final chunk hands its unresolved requests to the next chunk's grid-wide
+	// pass instead of working them off in this one work-group -- unless there are too
+	// many to sort in LDS, in which case it behaves like the final chunk.
+	bool full_tail = last_chunk != 0;
+	if (work_left) {
+		// -- gather what is left (tags TAIL / LOSER / PENDING), 16 tags per load
 		const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
-		for (uint32_t base = t * 16u; base < total; base += blockDim.x * 16u) {
+		for (uint32_t base = (lo_idx & ~15u) + t * 16u; base < total && base >= (lo_idx & ~15u); base += blockDim.x * 16u) {
 			const uint4 v = st4[base >> 4];
 			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
 			for (int k = 0; k < 16; k++) {
 				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 				const uint32_t idx = base + (uint32_t)k;
-				if (idx < total && (st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
+				if (idx >= lo_idx && idx < total &&
+						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK)) {
+					if (!last_chunk) {
+						// only what must be resolved here: pending requests up to their
+						// region's barrier index; the rest is carried
+						if (!(OP == OP_CUCKOO && any_bar))
+							continue;
+						const uint4 rc = reqc[idx];
+						if (idx > s_bar[(rc.y & g.hash_mask) >> g.region_shift])
+							continue;
+					}
+					glist[atomicAdd(&s_n, 1u)] = idx;
+				}
+			}
+		}
+		__syncthreads();
+		if (s_n > (uint32_t)kSortCap)
+			full_tail = true;
+	}
+	if (work_left && full_tail && !last_chunk) {
+		// too many to resolve from LDS: fall back to the complete tail; gather everything
+		__syncthreads();
+		if (t == 0)
+			s_n = 0;
+		__syncthreads();
+		const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+		for (uint32_t base = (lo_idx & ~15u) + t * 16u; base < total && base >= (lo_idx & ~15u); base += blockDim.x * 16u) {
+			const uint4 v = st4[base >> 4];
+			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+			for (int k = 0; k < 16; k++) {
+				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+				const uint32_t idx = base + (uint32_t)k;
+				if (idx >= lo_idx && idx < total &&
+						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
 					glist[atomicAdd(&s_n, 1u)] = idx;
 			}
 		}
 		__syncthreads();
 	}
-	const uint32_t m = s_n;
+	if (work_left && !full_tail) {
+		const uint32_t m = s_n;
+		// The requests that raised a region's barrier must not be carried unresolved: next
+		// pass their chain could meet buckets registered by requests stuck behind them,
+		// for ever.  So every pending request of a region up to that region's barrier index
+		// is replayed exactly here, in canonical order (they are few); the rest is carried.
+		if (OP == OP_CUCKOO && any_bar && m != 0) {
+			uint32_t n2 = 1;
+			while (n2 < m)
+				n2 <<= 1;
+			for (uint32_t i = t; i < n2; i += blockDim.x)
+				lkeys[i] = i < m ? glist[i] : kNone;
+			__syncthreads();
+			lds_sort(lkeys, n2);
+			if (t < g.nregions && s_bar[t] != kNone) {
+				const uint32_t bar = s_bar[t];
+				for (uint32_t i = 0; i < m; i++) {
+					const uint32_t idx = lkeys[i];
+					if (idx > bar)
+						break;
+					const uint4 rc = reqc[idx];
+					if (((rc.y & g.hash_mask) >> g.region_shift) != t)
+						continue;
+					apply_serial<OP>(table, g, req_of(rc));
+					state[idx] = ST_DONE;
+					atomicAdd(&s_serial, 1u);
+				}
+			}
+			wg_sync();
+		}
+		// finalise the tags of finished requests (a later roll-back must never see them)
+		// and find the lowest index that stays pending
+		uint32_t mine = kNone;
+		for (uint32_t idx = lo_idx + t; idx < total && idx >= lo_idx; idx += blockDim.x) {
+			const uint8_t st = state[idx];
+			if (st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2) {
+				state[idx] = ST_DONE;
+			} else if (st != ST_DONE) {
+				if (st != ST_PENDING)
+					state[idx] = ST_PENDING;
+				if (idx < mine)
+					mine = idx;
+			}
+		}
+		if (mine != kNone)
+			atomicMin(&s_carry, mine);
+		__syncthreads();
+	}
+	const uint32_t m = (work_left && full_tail) ? s_n : 0u;
 	if (m != 0) {
 		// work list: LDS when it fits, else the global list it was gathered into
 		const bool in_lds = m <= (uint32_t)kSortCap;
@@ -1066,7 +1194,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		} else if (left != 0 && t == 0) {
 			// too much left for LDS: walk the request states in canonical order
 			uint32_t d = 0;
-			for (uint32_t idx = 0; idx < total; idx++) {
+			for (uint32_t idx = lo_idx; idx < total; idx++) {
 				const uint8_t st = state[idx];
 				if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING && st != ST_CHAIN_OK)
 					continue;
@@ -1088,19 +1216,25 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			c2 += __shfl_down(c2, off);
 		}
 		if (t == 0) {
-			ctl->last.round1 = c1;
-			ctl->last.round2 = c2;
+			ctl->last.round1 = (first_chunk ? 0u : ctl->last.round1) + c1;
+			ctl->last.round2 = (first_chunk ? 0u : ctl->last.round2) + c2;
 		}
 	}
 	if (t == 0) {
-		// diagnostics of this call, then the control block of the next one
-		ctl->last.total = total;
-		ctl->last.tail_parallel = s_par;
-		ctl->last.tail_serial = s_serial;
-		ctl->last.undone = s_undone;
-		ctl->last.first_hard = ctl->first_hard;
+		// diagnostics of this call (summed over its chunks), then the control block of the next pass
+		ctl->last.total = total_all;
+		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
+		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + s_serial;
+		ctl->last.undone = (first_chunk ? 0u : ctl->last.undone) + s_undone;
+		const uint32_t fh = ctl->first_hard;
+		ctl->last.first_hard = first_chunk ? fh : (fh < ctl->last.first_hard ? fh : ctl->last.first_hard);
 		ctl->last.overflow = ctl->overflow;
-		ctl->last.chains = ctl->chain_ok;
+		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
+		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + ctl->bar_chain;
+		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->bar_class;
+		ctl->bar_chain = 0;
+		ctl->bar_class = 0;
+		ctl->carry_lo = s_carry;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
@@ -1127,7 +1261,9 @@ __global__ void k_init_ctl(Ctl *ctl)
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k] = ctl->committed[1][k] = 0;
 		ctl->first_hard = kNone;
-		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0};
+		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0};
+		ctl->bar_chain = ctl->bar_class = 0;
+		ctl->carry_lo = kNone;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
 	}
@@ -1243,17 +1379,54 @@ static int64_t ws_need(const ReqSrc &src)
 
 // K1 alone: touches the requests and the workspace, never the table.
 template <Op OP>
-static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream)
+static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream,
+		uint32_t lo = 0, uint32_t hi = kNone)
 {
 	hipLaunchKernelGGL((k_mark<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi);
 }
 
 template <Op OP>
-static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream);
+static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
+		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1);
+
+// Canonical-index chunks of one call.  With a size hint from the caller the
+// pipeline runs chunk after chunk (stream order = canonical order), so a region
+// barrier only ever redoes part of one chunk.  No hint (the plain ABI, whose
+// callers stay below 32 K requests): one pass over everything.
+// Passes of one call: data chunks, plus -- when there are several -- a trailing
+// flush pass over an empty range that only takes what the last data chunk carried.
+// Two-choice insert and delete never raise barriers: always one pass.
+static int chunk_count(long long hint, uint32_t scheme_or_op_is_cuckoo = 1)
+{
+	const long long c = tuning().insert_chunk;
+	if (!scheme_or_op_is_cuckoo || hint <= 0 || c <= 0 || hint <= c)
+		return 1;
+	const long long n = (hint + c - 1) / c;
+	return (n > 255 ? 255 : (int)n) + 1;
+}
+
+static void chunk_range(int c, int nchunks, uint32_t *lo, uint32_t *hi)
+{
+	const uint32_t step = (uint32_t)tuning().insert_chunk;
+	if (nchunks == 1) {
+		*lo = 0;
+		*hi = kNone;
+		return;
+	}
+	const int data = nchunks - 1;                  // the last pass is the flush pass
+	if (c >= data) {
+		*lo = kNone - 15u;                          // empty range: carried requests only
+		*hi = kNone;
+		return;
+	}
+	*lo = (uint32_t)c * step;
+	*hi = c == data - 1 ? kNone : (uint32_t)(c + 1) * step;   // the last data chunk takes any excess
+}
 
 template <Op OP>
-static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipStream_t stream)
+static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipStream_t stream,
+		long long hint = 0)
 {
 	Workspace *w = nullptr;
 	if (src.single_n > kMaxReqCap)
@@ -1261,30 +1434,52 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src), stream);
 	if (rc != MKV_OK)
 		return rc;
-	launch_mark<OP>(w, g, src, stream);
-	return launch_rounds<OP>(w, g, table, stream);
+	if (src.single_n > 0 && hint <= 0)
+		hint = src.single_n;               // delete: the count is a host value
+	const int nchunks = chunk_count(hint, OP == OP_CUCKOO);
+	for (int c = 0; c < nchunks; c++) {
+		uint32_t lo, hi;
+		chunk_range(c, nchunks, &lo, &hi);
+		launch_mark<OP>(w, g, src, stream, lo, hi);
+		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1);
+		if (rc != MKV_OK)
+			return rc;
+	}
+	return MKV_OK;
 }
 
 // K2..K4
 template <Op OP>
-static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream)
+static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
+		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk)
 {
 	int tail_rounds = tuning().tail_rounds;
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, tuning().debug_skip);
+			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, tuning().debug_skip,
+			lo, hi);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0);
+			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0, lo, hi);
 	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds);
+			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
+			last_chunk);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
 }  // namespace mkv
 
+extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
+
 extern "C" int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, void *stream)
+{
+	return mkv_insert_hinted(geom, table, blk_input, blk_elem_num, num_blks, 0, stream);
+}
+
+extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream)
 {
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || num_blks < 0 || num_blks > mkv::kMaxBlocks)
@@ -1301,8 +1496,8 @@ extern "C" int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk
 	src.nblk = (uint32_t)num_blks;
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
-		return mkv::run_update<mkv::OP_2CHOICE>(d, t, src, (hipStream_t)stream);
-	return mkv::run_update<mkv::OP_CUCKOO>(d, t, src, (hipStream_t)stream);
+		return mkv::run_update<mkv::OP_2CHOICE>(d, t, src, (hipStream_t)stream, size_hint);
+	return mkv::run_update<mkv::OP_CUCKOO>(d, t, src, (hipStream_t)stream, size_hint);
 }
 
 // Insert of mkv_cycle, in two halves around the search launch: the mark pass is
@@ -1310,7 +1505,7 @@ extern "C" int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk
 // on `stream` is complete before it starts, this cycle's search is not waited
 // for), the rounds follow on `stream` once mark has joined.
 extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_input, int *blk_elem_num,
-		int num_blks, void *stream)
+		int num_blks, long long size_hint, void *stream)
 {
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || num_blks <= 0 || num_blks > mkv::kMaxBlocks || !blk_input ||
@@ -1329,10 +1524,12 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_inpu
 		return rc;
 	if (hipEventRecord(w->ev_fork, s) != hipSuccess || hipStreamWaitEvent(w->aux, w->ev_fork, 0) != hipSuccess)
 		return MKV_EHIP;
+	uint32_t lo, hi;
+	mkv::chunk_range(0, mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO), &lo, &hi);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
-		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux);
+		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux, lo, hi);
 	else
-		mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, w->aux);
+		mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, w->aux, lo, hi);
 	if (hipEventRecord(w->ev_join, w->aux) != hipSuccess)
 		return MKV_EHIP;
 	return MKV_OK;
@@ -1342,7 +1539,7 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_inpu
 // with mkv_cycle_insert_end(..., joined = 0).
 extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 		const bucket_t *table, int64_t num_search, ielem_t **blk_input, int *blk_elem_num, int num_blks,
-		void *stream)
+		long long size_hint, void *stream)
 {
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || num_blks <= 0 || num_blks > mkv::kMaxBlocks || !blk_input ||
@@ -1366,16 +1563,23 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
 	const uint2 *in2 = reinterpret_cast<const uint2 *>(in);
 	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
+	// the fused launch marks the first chunk only
+	uint32_t lo, hi;
+	{
+		const int nc = mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO);
+		mkv::chunk_range(0, nc, &lo, &hi);
+	}
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, 0, s, in2, out, t4, num_search,
-				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
 	else
 		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, 0, s, in2, out, t4, num_search,
-				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap);
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
-extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, void *stream, int joined)
+extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream, int joined)
 {
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || !table)
@@ -1388,9 +1592,30 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, voi
 	if (joined && hipStreamWaitEvent(s, w->ev_join, 0) != hipSuccess)
 		return MKV_EHIP;
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
-	if (d.scheme == MKV_SCHEME_2CHOICE)
-		return mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s);
-	return mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s);
+	mkv::ReqSrc src;
+	src.blk_input = reinterpret_cast<const uint32_t *const *>(blk_input);
+	src.single = nullptr;
+	src.blk_elem_num = blk_elem_num;
+	src.single_n = 0;
+	src.nblk = (uint32_t)num_blks;
+	// chunk 0 was marked beside (or inside) the search launch; later chunks are marked here
+	const int nchunks = mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO);
+	for (int c = 0; c < nchunks; c++) {
+		uint32_t lo, hi;
+		mkv::chunk_range(c, nchunks, &lo, &hi);
+		if (d.scheme == MKV_SCHEME_2CHOICE) {
+			if (c > 0)
+				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, lo, hi);
+			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+		} else {
+			if (c > 0)
+				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, lo, hi);
+			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+		}
+		if (rc != MKV_OK)
+			return rc;
+	}
+	return MKV_OK;
 }
 
 extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
@@ -1476,5 +1701,7 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->undone = h.last.undone;
 	info->first_hard = h.last.first_hard;
 	info->chains = h.last.chains;
+	info->bar_chain = h.last.bar_chain;
+	info->bar_class = h.last.bar_class;
 	return MKV_OK;
 }

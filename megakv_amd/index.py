@@ -169,17 +169,19 @@ class HashIndex:
         cnts = torch.tensor([b.shape[0] for b in blocks], dtype=torch.int32).to(self.device)
         return ptrs, cnts, blocks
 
-    def insert(self, blocks, stream=None):
+    def insert(self, blocks, stream=None, hint=None):
         ptrs, cnts, keep = self.stage_blocks(blocks)
-        self.insert_staged(ptrs, cnts, len(keep), stream)
+        if hint is None:
+            hint = sum(b.shape[0] for b in keep)      # the host staged them: it knows the size
+        self.insert_staged(ptrs, cnts, len(keep), stream, hint)
         self._keep = [ptrs, cnts, keep]   # alive until the next call (async launch)
 
-    def insert_staged(self, ptrs, cnts, num_blks, stream=None):
-        _check(self.lib.mkv_insert(ctypes.byref(self._g), _dev_ptr(self.table), _dev_ptr(ptrs),
-                                   _dev_ptr(cnts), num_blks, _stream_ptr(stream)), "mkv_insert")
+    def insert_staged(self, ptrs, cnts, num_blks, stream=None, hint=0):
+        _check(self.lib.mkv_insert_hinted(ctypes.byref(self._g), _dev_ptr(self.table), _dev_ptr(ptrs),
+                                          _dev_ptr(cnts), num_blks, int(hint), _stream_ptr(stream)), "mkv_insert")
 
     def cycle(self, selem, out, ptrs=None, cnts=None, num_blks=0, delem=None, memset=False, overlap="fused",
-              stream=None, timer=None, slot=0):
+              stream=None, timer=None, slot=0, insert_hint=0):
         """search -> delete -> insert of one scheduler cycle in one library call.
         overlap: "fused" (mark pass inside the search launch), "side" (side stream), "none"."""
         if overlap is True:
@@ -195,7 +197,7 @@ class HashIndex:
             selem.shape[0] if selem is not None else 0,
             _dev_ptr(delem) if delem is not None else null, delem.shape[0] if delem is not None else 0,
             _dev_ptr(ptrs) if num_blks else null, _dev_ptr(cnts) if num_blks else null, num_blks,
-            flags, _stream_ptr(stream), ctypes.c_void_p(timer) if timer else null, slot), "mkv_cycle")
+            int(insert_hint), flags, _stream_ptr(stream), ctypes.c_void_p(timer) if timer else null, slot), "mkv_cycle")
 
     # -- delete ----------------------------------------------------------------
     def delete(self, delem, stream=None):

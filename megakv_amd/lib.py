@@ -20,7 +20,8 @@ class MkvGeom(ctypes.Structure):
 class MkvUpdateInfo(ctypes.Structure):
     _fields_ = [("total", ctypes.c_uint32), ("round1", ctypes.c_uint32), ("round2", ctypes.c_uint32),
                 ("tail_parallel", ctypes.c_uint32), ("tail_serial", ctypes.c_uint32),
-                ("undone", ctypes.c_uint32), ("first_hard", ctypes.c_uint32), ("chains", ctypes.c_uint32)]
+                ("undone", ctypes.c_uint32), ("first_hard", ctypes.c_uint32), ("chains", ctypes.c_uint32),
+                ("bar_chain", ctypes.c_uint32), ("bar_class", ctypes.c_uint32)]
 
 
 # every symbol include/libgpuhash.h, include/megakv_hip.h and
@@ -29,7 +30,7 @@ ABI_SYMBOLS = [
     "gpu_hash_search", "gpu_hash_insert", "gpu_hash_delete", "gpu_delete_insert",
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
-    "mkv_set_tuning", "mkv_cycle", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
+    "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
     "mkv_search_slots", "mkv_unpack_results", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
@@ -67,7 +68,9 @@ def load_library():
     L.mkv_delete.restype = INT
     L.mkv_delete.argtypes = [G, P, P, I64, P]
     L.mkv_cycle.restype = INT
-    L.mkv_cycle.argtypes = [G, P, P, P, I64, P, I64, P, P, INT, U32, P, P, INT]
+    L.mkv_cycle.argtypes = [G, P, P, P, I64, P, I64, P, P, INT, I64, U32, P, P, INT]
+    L.mkv_insert_hinted.restype = INT
+    L.mkv_insert_hinted.argtypes = [G, P, P, P, INT, ctypes.c_longlong, P]
     L.mkv_timer_create.restype = P
     L.mkv_timer_create.argtypes = [INT]
     L.mkv_timer_elapsed_ms.restype = INT

@@ -91,8 +91,8 @@ class HipOps:
                                          _dev_ptr(out_slots), _dev_ptr(self.idx.table), _dev_ptr(set_counts),
                                          _stream_ptr(None)), "mkv_search_slots")
 
-    def insert_slots(self, ptrs, set_counts, g):
-        self.idx.insert_staged(ptrs, set_counts, g, None)
+    def insert_slots(self, ptrs, set_counts, g, hint=0):
+        self.idx.insert_staged(ptrs, set_counts, g, None, hint)
 
     def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out):
         _check(self.lib.mkv_unpack_results(_dev_ptr(back), _dev_ptr(perm), _dev_ptr(sendbuf), g, cap_get,
@@ -173,7 +173,7 @@ class ShardedIndex:
         if timing:
             timing[0].stop(timing[1])
         if self.cap_set:
-            o.insert_slots(self.set_ptrs, self.set_counts, w)
+            o.insert_slots(self.set_ptrs, self.set_counts, w, self.n_set)
         self.comm.all_to_all(self.back_slots, self.out_slots)
         o.unpack(self.back_slots, self.perm, self.sendbuf, w, self.cap_get, self.cap_set, out)
 

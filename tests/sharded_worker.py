@@ -76,7 +76,7 @@ class CpuOps:
             osl[s, :n] = res
             set_counts[s] = int(rb[s, 1])
 
-    def insert_slots(self, ptrs, set_counts, g):
+    def insert_slots(self, ptrs, set_counts, g, hint=0):
         recvbuf, slot_words, cap_get = self._recv
         rb = recvbuf.numpy().view(np.uint32)
         off = 4 + 2 * cap_get

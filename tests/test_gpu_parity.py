@@ -23,6 +23,7 @@ def set_tuning(name, value):
 def _defaults():
     yield
     set_tuning("tail_rounds", 48)
+    set_tuning("insert_chunk", 65536)
     set_tuning("search_u", 4)
     set_tuning("search_nt", 0)
 
@@ -170,6 +171,32 @@ def test_eviction_chains_commit_in_parallel():
     assert np.array_equal(got, exp), (first_diff(got, exp), info)
     assert info["chains"] > 100, info
     assert info["first_hard"] != 0xFFFFFFFF
+
+
+@pytest.mark.parametrize("chunk", [1024, 4096, 20000])
+@pytest.mark.parametrize("scheme", SCHEMES)
+def test_chunked_insert_equals_single_pass(chunk, scheme):
+    """A size hint makes the library run the batch in canonical-index chunks; the
+    table must not depend on the chunk size (also through mkv_cycle)."""
+    set_tuning("insert_chunk", chunk)
+    g = Geometry(mem_p=18, scheme=scheme)
+    rng = np.random.default_rng(chunk)
+    img = random_table(g, rng, 0.75, 1 << 31)
+    e = random_requests(g, rng, 30000, 1 << 31, hot=0.05, zero_low=0.02)
+    blocks = split_blocks(e, g, rng, "uneven")
+    got, exp, info = run_insert_case(g, img, blocks)
+    assert np.array_equal(got, exp), (first_diff(got, exp), info)
+    assert info["total"] == 30000
+    # and through the fused cycle entry
+    idx = HashIndex(g)
+    idx.load_table(img)
+    q = dev(e[:, :2].copy())
+    out = dev(np.zeros((e.shape[0], 2), np.uint32))
+    ptrs, cnts, keep = idx.stage_blocks([dev(b) for b in blocks])
+    idx.cycle(q, out, ptrs, cnts, len(keep), insert_hint=e.shape[0])
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.table_numpy(), exp)
+    assert np.array_equal(host(out), O.search(ogeom(g), img, e[:, :2].copy()))
 
 
 def test_insert_tail_fallback_beyond_lds_sort():
