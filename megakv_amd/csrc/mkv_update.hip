@@ -411,12 +411,51 @@ __device__ __forceinline__ unsigned long long owner_key(unsigned long long stamp
 	return ((kStampMax - stamp) << kIdxBits) | idx;
 }
 
+// atomicMin(&owner[b], key) for every active lane, but lanes of a wave that target
+// the same bucket as the wave's first pending lane are served by ONE atomic carrying
+// the smallest key among them (two peeling steps, then one atomic per lane).  Under
+// the reference's LOCAL_TEST keying every key of a region has the same alternate
+// bucket (hash ^ sig has no region-local bits, src/mega_recv.c:700-704): without
+// this all registrations of a batch would queue on 8 words.
+__device__ __forceinline__ void atomic_min_dedup(unsigned long long *owner, uint32_t b,
+		unsigned long long key, bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		// smallest key of the group (wave reduction over the group's lanes)
+		unsigned long long k = same ? key : ~0ull;
+		for (int off = 32; off > 0; off >>= 1) {
+			const unsigned long long o = __shfl_xor(k, off);
+			k = o < k ? o : k;
+		}
+		if ((int)(threadIdx.x & 63u) == first)
+			atomicMin(&owner[fb], k);
+		active = active && !same;
+	}
+	if (active)
+		atomicMin(&owner[b], key);
+}
+
 __device__ __forceinline__ void reserve(unsigned long long *owner, uint32_t P, uint32_t A,
 		unsigned long long key)
 {
 	atomicMin(&owner[P], key);
 	if (A != P)
 		atomicMin(&owner[A], key);
+}
+
+// wave-convergent form used by the mark pass: every lane of the wave calls it
+__device__ __forceinline__ void reserve_wave(unsigned long long *owner, uint32_t P, uint32_t A,
+		unsigned long long key, bool active)
+{
+	atomic_min_dedup(owner, P, key, active);
+	atomic_min_dedup(owner, A, key, active && A != P);
 }
 
 // statistics: one atomic per wave, spread over kShards words
@@ -475,43 +514,50 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	// lower indices, so they win every reservation they share with this chunk's requests
 	const uint32_t carry = ctl->carry_lo;
 	const uint32_t start = carry < lo_idx ? carry : lo_idx;
-	for (uint32_t idx = start + block * blockDim.x + t; idx < end && idx >= start;
-			idx += nblocks * blockDim.x) {
-		if (idx < lo_idx) {
-			if (state[idx] != ST_PENDING)
-				continue;
-			const uint4 rc = reqc[idx];
-			reserve(owner, rc.y & g.hash_mask, alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask),
-					owner_key(stamp, idx));
-			continue;
-		}
-		const uint32_t *p;
-		if (src.single) {
-			p = src.single + 3ull * idx;
-		} else {
-			uint32_t lo = 0, hi = nblk;             // block b: prefix[b] <= idx < prefix[b+1]
-			while (hi - lo > 1) {
-				const uint32_t mid = (lo + hi) >> 1;
-				if (s_prefix[mid] <= idx)
-					lo = mid;
-				else
-					hi = mid;
+	// whole waves iterate together: the reservation de-duplication is a wave operation
+	const uint32_t span = nblocks * blockDim.x;
+	const uint32_t first = start + block * blockDim.x;          // this block's first index
+	for (uint32_t base = first; base < end && base >= start; base += span) {
+		const uint32_t idx = base + t;
+		bool live = idx < end && idx >= start;
+		uint32_t P = 0, A = 0;
+		if (live && idx < lo_idx) {
+			live = state[idx] == ST_PENDING;
+			if (live) {
+				const uint4 rc = reqc[idx];
+				P = rc.y & g.hash_mask;
+				A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			}
-			p = s_ptr[lo] + 3ull * (idx - s_prefix[lo]);
+		} else if (live) {
+			const uint32_t *p;
+			if (src.single) {
+				p = src.single + 3ull * idx;
+			} else {
+				uint32_t lo = 0, hi = nblk;             // block b: prefix[b] <= idx < prefix[b+1]
+				while (hi - lo > 1) {
+					const uint32_t mid = (lo + hi) >> 1;
+					if (s_prefix[mid] <= idx)
+						lo = mid;
+					else
+						hi = mid;
+				}
+				p = s_ptr[lo] + 3ull * (idx - s_prefix[lo]);
+			}
+			Req r;
+			r.sig = p[0];
+			r.hash = p[1];
+			r.loc = p[2];
+			reqc[idx] = make_uint4(r.sig, r.hash, r.loc, 0u);
+			if (OP != OP_DELETE && r.sig == 0u && r.loc == 0u) {
+				state[idx] = ST_DONE;               // skipped by the reference too (:259-262)
+				live = false;
+			} else {
+				state[idx] = ST_PENDING;
+				P = r.hash & g.hash_mask;
+				A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+			}
 		}
-		Req r;
-		r.sig = p[0];
-		r.hash = p[1];
-		r.loc = p[2];
-		reqc[idx] = make_uint4(r.sig, r.hash, r.loc, 0u);
-		if (OP != OP_DELETE && r.sig == 0u && r.loc == 0u) {
-			state[idx] = ST_DONE;               // skipped by the reference too (:259-262)
-			continue;
-		}
-		state[idx] = ST_PENDING;
-		const uint32_t P = r.hash & g.hash_mask;
-		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-		reserve(owner, P, A, owner_key(stamp, idx));
+		reserve_wave(owner, P, A, owner_key(stamp, idx), live);
 	}
 }
 
