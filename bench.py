@@ -64,7 +64,8 @@ def parse():
     ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
-    ap.add_argument("--cpu-batches", type=int, default=8)
+    ap.add_argument("--cpu-batches", type=int, default=160,
+                    help="batches of the same workload replayed on the CPU oracle (~10 s single-threaded)")
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: mkv_set_tuning('debug_skip')")
     return ap.parse_args()
@@ -194,7 +195,10 @@ def main():
         avg_s = float(ms.mean()) * 1e-3
         algo_bytes = GET_BYTES * engine.search_requests_per_launch(stream_gen)
         achieved = algo_bytes / avg_s / 1e9
-        roofline = {"bound": "hbm", "kernel": "mkv::k_search", "achieved": round(achieved, 1),
+        fused = world == 1 and args.overlap == "fused" and not args.memset and stream_gen.n_set > 0
+        roofline = {"bound": "hbm",
+                    "kernel": "mkv::k_search_mark (search work-groups + the insert's mark work-groups)" if fused
+                    else ("mkv::k_search_slots" if world > 1 else "mkv::k_search"), "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": load_traffic(args), "algorithmic_bytes_per_launch": algo_bytes,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(len(ms)), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),

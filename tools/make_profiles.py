@@ -18,7 +18,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def find(raw, name, suffix):
     f = glob.glob(os.path.join(raw, name, "*", f"*{suffix}"))
-    return f[0] if f else None
+    return max(f, key=os.path.getmtime) if f else None
 
 
 def main():
