@@ -61,6 +61,8 @@ def parse():
     ap.add_argument("--overlap", default="fused", choices=["fused", "side", "none"],
                     help="where the insert's table-independent mark pass runs: inside the search launch, on a "
                          "side stream, or as its own kernel after the search")
+    ap.add_argument("--no-pipeline", action="store_true",
+                    help="N > 1: run the steps strictly one after the other (no exchange/compute overlap)")
     ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
@@ -175,8 +177,13 @@ def main():
         t_start = time.perf_counter()
         every = max(1, args.events_every)
         timer = engine.make_timer((args.steps + every - 1) // every) if (use_events and not args.graph) else None
-        for i, b in enumerate(batches[args.warmup:]):
-            engine.step(b, run_stream, [timer.h, i // every] if (timer and i % every == 0) else None)
+        timed = batches[args.warmup:]
+        if world > 1 and not args.no_pipeline:
+            # two batches in flight: exchanges of one overlap the local kernels of the other
+            engine.run_pipelined(timed, (lambda i: [timer.h, i // every] if (timer and i % every == 0) else None))
+        else:
+            for i, b in enumerate(timed):
+                engine.step(b, run_stream, [timer.h, i // every] if (timer and i % every == 0) else None)
         t_submit = time.perf_counter() - t_start
         run_stream.synchronize()
     barrier()
@@ -224,7 +231,9 @@ def main():
                        "batch": 1 << args.batch_log2, "gets": stream_gen.n_get, "sets": stream_gen.n_set,
                        "keying": "K-" + args.keying, "set_keys": "S-" + args.sets, "load_factor": args.lf,
                        "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "memset" if args.memset else "by the search kernel", "mark_pass": args.overlap,
-                       "sharding": "single table" if world == 1 else f"{world} shards by top bucket bits, RCCL all-to-all",
+                       "sharding": "single table" if world == 1 else
+                       f"{world} shards by top bucket bits, RCCL all-to-all, "
+                       + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else "eager"},
             "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu,
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),

@@ -122,6 +122,24 @@ class _TorchTimer:
         return [a.elapsed_time(b) for a, b in self.ev]
 
 
+class _Lane:
+    """One set of exchange buffers + a stream: two lanes let the collectives of one
+    batch overlap the local kernels of the neighbouring batch."""
+
+    def __init__(self, sh, device, make_stream):
+        w, ops = sh.world, sh.ops
+        i32 = dict(dtype=torch.int32, device=device)
+        self.sendbuf = torch.zeros((w, sh.slot_words), **i32)
+        self.recvbuf = torch.zeros((w, sh.slot_words), **i32)
+        self.out_slots = torch.zeros((w, max(sh.cap_get, 1), 2), **i32)
+        self.back_slots = torch.zeros((w, max(sh.cap_get, 1), 2), **i32)
+        self.perm = torch.zeros((w * max(sh.cap_get, 1),), **i32)
+        self.scratch = torch.zeros((ops.scratch_bytes(max(sh.n_get, 1), max(sh.n_set, 1), w) // 4 + 16,), **i32)
+        self.set_counts = torch.zeros((w,), **i32)
+        self.set_ptrs = ops.slot_set_pointers(self.recvbuf, w, sh.slot_words, sh.cap_get)
+        self.stream = make_stream() if make_stream else None
+
+
 class ShardedIndex:
     def __init__(self, mem_p_local, world, rank, scheme, device, n_get, n_set, comm, ops=None,
                  cap_factor=None, index=None):
@@ -148,39 +166,83 @@ class ShardedIndex:
         self.cap_get = int(math.ceil(n_get / world * cap_factor / 256.0)) * 256 if n_get else 0
         self.cap_set = int(math.ceil(n_set / world * cap_factor / 16.0)) * 16 + 16 if n_set else 0
         self.slot_words = ops.slot_words(self.cap_get, self.cap_set)
-        i32 = dict(dtype=torch.int32, device=self.device)
-        self.sendbuf = torch.zeros((world, self.slot_words), **i32)
-        self.recvbuf = torch.zeros((world, self.slot_words), **i32)
-        self.out_slots = torch.zeros((world, max(self.cap_get, 1), 2), **i32)
-        self.back_slots = torch.zeros((world, max(self.cap_get, 1), 2), **i32)
-        self.perm = torch.zeros((world * max(self.cap_get, 1),), **i32)
-        self.scratch = torch.zeros((ops.scratch_bytes(max(n_get, 1), max(n_set, 1), world) // 4 + 16,), **i32)
-        self.overflow = torch.zeros((1,), **i32)
-        self.set_counts = torch.zeros((world,), **i32)
-        self.set_ptrs = ops.slot_set_pointers(self.recvbuf, world, self.slot_words, self.cap_get)
+        self.overflow = torch.zeros((1,), dtype=torch.int32, device=self.device)
+        on_gpu = self.device.type == "cuda"
+        mk = (lambda: torch.cuda.Stream(device=self.device)) if on_gpu else None
+        self.lanes = [_Lane(self, self.device, mk), _Lane(self, self.device, mk)]
+        # attributes of lane 0 under their old names (single-lane step_tensors)
+        for name in ("sendbuf", "recvbuf", "out_slots", "back_slots", "perm", "scratch", "set_counts", "set_ptrs"):
+            setattr(self, name, getattr(self.lanes[0], name))
 
     # -- shard of a request ---------------------------------------------------------
     def shard_of(self, hash_np):
         return (hash_np.astype(np.uint64) & np.uint64(self.agg_mask)) >> np.uint64(self.shift)
 
     # -- one step -----------------------------------------------------------------------
-    def step_tensors(self, gets, sets, out):
-        """gets [n,2], sets [m,3] int32 tensors of this rank; out [n,2] receives the
-        search results in request order.  Everything is enqueued on the current stream."""
+    def _forward(self, ln, gets, sets):
+        """pack the local batch into slots and start the forward exchange"""
+        self.ops.pack(gets, sets, self.agg_mask, self.shift, self.world, ln.sendbuf, self.cap_get, self.cap_set,
+                      ln.perm, ln.scratch, self.overflow)
+        self.comm.all_to_all(ln.recvbuf, ln.sendbuf)
+
+    def _local(self, ln, timing=None):
+        """serve what the peers sent: search every slot, then insert (source-rank order)"""
         o, w = self.ops, self.world
-        o.pack(gets, sets, self.agg_mask, self.shift, w, self.sendbuf, self.cap_get, self.cap_set,
-               self.perm, self.scratch, self.overflow)
-        self.comm.all_to_all(self.recvbuf, self.sendbuf)
-        timing = getattr(self, "_timing", None)
         if timing:
             timing[0].start(timing[1])
-        o.search_slots(self.recvbuf, w, self.cap_get, self.cap_set, self.out_slots, self.set_counts)
+        o.search_slots(ln.recvbuf, w, self.cap_get, self.cap_set, ln.out_slots, ln.set_counts)
         if timing:
             timing[0].stop(timing[1])
         if self.cap_set:
-            o.insert_slots(self.set_ptrs, self.set_counts, w, self.n_set)
-        self.comm.all_to_all(self.back_slots, self.out_slots)
-        o.unpack(self.back_slots, self.perm, self.sendbuf, w, self.cap_get, self.cap_set, out)
+            o.insert_slots(ln.set_ptrs, ln.set_counts, w, self.n_set)
+
+    def _backward(self, ln, out):
+        self.comm.all_to_all(ln.back_slots, ln.out_slots)
+        self.ops.unpack(ln.back_slots, ln.perm, ln.sendbuf, self.world, self.cap_get, self.cap_set, out)
+
+    def step_tensors(self, gets, sets, out):
+        """gets [n,2], sets [m,3] int32 tensors of this rank; out [n,2] receives the
+        search results in request order.  Everything is enqueued on the current stream."""
+        ln = self.lanes[0]
+        self._forward(ln, gets, sets)
+        self._local(ln, getattr(self, "_timing", None))
+        self._backward(ln, out)
+
+    def run_pipelined(self, batches, timing_of=None):
+        """All batches, software-pipelined over two lanes: the forward exchange of batch
+        i+1 and the result exchange of batch i-1 overlap the local kernels of batch i.
+        Local phases stay strictly ordered (event chain), so results are those of the
+        batches run one after the other.  Collectives are issued in the same order on
+        every rank: fwd(0), fwd(1), back(0), fwd(2), back(1), ...
+        batches: dicts with "q", "s", "out".  Enqueues on the lanes' streams; the
+        caller's current stream is joined at the end."""
+        if not batches:
+            return
+        main = torch.cuda.current_stream()
+        start = torch.cuda.Event()
+        start.record(main)
+        for ln in self.lanes:
+            ln.stream.wait_event(start)
+        prev_local = None
+        with torch.cuda.stream(self.lanes[0].stream):
+            self._forward(self.lanes[0], batches[0]["q"], batches[0]["s"])
+        for i, b in enumerate(batches):
+            ln = self.lanes[i & 1]
+            if i + 1 < len(batches):
+                nxt = self.lanes[(i + 1) & 1]
+                with torch.cuda.stream(nxt.stream):
+                    self._forward(nxt, batches[i + 1]["q"], batches[i + 1]["s"])
+            with torch.cuda.stream(ln.stream):
+                if prev_local is not None:
+                    ln.stream.wait_event(prev_local)
+                self._local(ln, timing_of(i) if timing_of else None)
+                prev_local = torch.cuda.Event()
+                prev_local.record(ln.stream)
+                self._backward(ln, b["out"])
+        for ln in self.lanes:
+            done = torch.cuda.Event()
+            done.record(ln.stream)
+            main.wait_event(done)
 
     # -- the engine interface bench.py drives --------------------------------------------------
     def preload(self, P, keying):
@@ -203,6 +265,9 @@ class ShardedIndex:
 
     def reserve(self, stream):
         self.idx.reserve(self.world * self.cap_set + 1024, stream)
+        for ln in self.lanes:
+            if ln.stream is not None:
+                self.idx.reserve(self.world * self.cap_set + 1024, ln.stream)
 
     def make_timer(self, slots):
         return _TorchTimer(slots)

@@ -24,13 +24,24 @@ def run_and_check(world, mode, mem_p_local, scheme, seed, steps=4, timeout=600):
     port = free_port()
     with tempfile.TemporaryDirectory() as d:
         env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+        # worker output goes to files: a full pipe on one rank would stall every rank at the next collective
+        logs = [open(os.path.join(d, f"rank{r}.log"), "w") for r in range(world)]
         procs = [subprocess.Popen([sys.executable, "-m", "tests.sharded_worker", str(r), str(world), str(port),
                                    mode, d, str(mem_p_local), str(scheme), str(seed)], cwd=ROOT, env=env,
-                                  stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                                  stdout=logs[r], stderr=subprocess.STDOUT)
                  for r in range(world)]
-        outs = [p.communicate(timeout=timeout)[0] for p in procs]
+        try:
+            for p in procs:
+                p.wait(timeout=timeout)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for f in logs:
+                f.close()
         for r, p in enumerate(procs):
-            assert p.returncode == 0, f"rank {r} failed:\n{outs[r][-3000:]}"
+            tail = open(os.path.join(d, f"rank{r}.log")).read()[-3000:]
+            assert p.returncode == 0, f"rank {r} failed:\n{tail}"
         data = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
         k = world.bit_length() - 1
         og = O.geom(mem_p=mem_p_local + k, scheme=scheme)          # aggregate table, IBLOCK_P = 3

@@ -35,7 +35,7 @@ class CpuOps:
         self.O = O
         self.og = O.geom(mem_p=geom.mem_p, scheme=geom.scheme, iblock_p=geom.iblock_p, max_cuckoo=geom.max_cuckoo)
         self.table = O.new_table(self.og)
-        self._recv = None
+        self._recv = {}
 
     def slot_words(self, cap_get, cap_set):
         return 4 + 2 * cap_get + 3 * cap_set
@@ -44,8 +44,9 @@ class CpuOps:
         return 64
 
     def slot_set_pointers(self, recvbuf, g, slot_words, cap_get):
-        self._recv = (recvbuf, slot_words, cap_get)
-        return torch.zeros(g, dtype=torch.int64)
+        ptrs = torch.zeros(g, dtype=torch.int64)
+        self._recv[ptrs.data_ptr()] = (recvbuf, slot_words, cap_get)     # one entry per lane
+        return ptrs
 
     def pack(self, gets, sets, agg_mask, shift, g, sendbuf, cap_get, cap_set, perm, scratch, overflow):
         sb = sendbuf.numpy().view(np.uint32)
@@ -77,7 +78,7 @@ class CpuOps:
             set_counts[s] = int(rb[s, 1])
 
     def insert_slots(self, ptrs, set_counts, g, hint=0):
-        recvbuf, slot_words, cap_get = self._recv
+        recvbuf, slot_words, cap_get = self._recv[ptrs.data_ptr()]
         rb = recvbuf.numpy().view(np.uint32)
         off = 4 + 2 * cap_get
         blocks = [np.ascontiguousarray(rb[s, off:off + 3 * int(set_counts[s])].reshape(-1, 3)) for s in range(g)]
@@ -125,6 +126,21 @@ def main():
     rng = np.random.default_rng(seed * 100 + rank)
     known = np.zeros((0, 3), np.uint32)
     rec = {}
+    if mode == "gpu-pipe":
+        # all steps through the two-lane software pipeline
+        staged = []
+        for step in range(steps):
+            gets, sets = make_requests(rng, n_get, n_set, 1 << 22, known)
+            known = np.concatenate([known, sets])
+            rec[f"gets{step}"], rec[f"sets{step}"] = gets, sets
+            staged.append({"q": to_t(gets), "s": to_t(sets),
+                           "out": torch.zeros((n_get, 2), dtype=torch.int32, device=sh.device)})
+        sh.run_pipelined(staged)
+        torch.cuda.synchronize()
+        for step in range(steps):
+            rec[f"out{step}"] = staged[step]["out"].cpu().numpy().view(np.uint32)
+        dist.barrier()
+        steps = 0
     for step in range(steps):
         gets, sets = make_requests(rng, n_get, n_set, 1 << 22, known)
         known = np.concatenate([known, sets])

@@ -11,3 +11,10 @@ pytestmark = pytest.mark.gpu
 @pytest.mark.parametrize("world,scheme", [(2, 0), (2, 1), (4, 0)])
 def test_sharded_hip_ranks_on_one_gpu(world, scheme):
     run_and_check(world, "gpu", mem_p_local=16, scheme=scheme, seed=20 + world, timeout=900)
+
+
+@pytest.mark.parametrize("world", [2, 4])
+def test_sharded_pipelined_two_lanes(world):
+    """run_pipelined (two batches in flight, exchanges overlapping local kernels) must
+    give exactly the results of the batches run one after the other."""
+    run_and_check(world, "gpu-pipe", mem_p_local=16, scheme=0, seed=30 + world, timeout=900)
