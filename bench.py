@@ -61,6 +61,9 @@ def parse():
     ap.add_argument("--overlap", default="fused", choices=["fused", "side", "none"],
                     help="where the insert's table-independent mark pass runs: inside the search launch, on a "
                          "side stream, or as its own kernel after the search")
+    ap.add_argument("--force-sharded", action="store_true",
+                    help="use the sharded engine (pack / RCCL all-to-all / slots) even with one rank: a self-test "
+                         "of the multi-GPU code path on a single GPU")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1: run the steps strictly one after the other (no exchange/compute overlap)")
     ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
@@ -110,6 +113,12 @@ class Stream:
 
 
 def main():
+    # Libraries (RCCL prints a version banner) must not share the channel of the one JSON
+    # line: everything written to fd 1 from here on goes to stderr, the line is written
+    # to the saved descriptor at the end.
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
     args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -121,10 +130,14 @@ def main():
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     dist = None
-    if world > 1:
+    sharded = world > 1 or args.force_sharded
+    if sharded:
         import torch.distributed as dist_mod
         dist = dist_mod
-        dist.init_process_group("nccl", device_id=device)
+        if world == 1:
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29517")
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     log2w = world.bit_length() - 1
     assert 1 << log2w == world and world <= 8, "1/2/4/8 GPUs"
@@ -132,7 +145,7 @@ def main():
     scheme = M.SCHEME_CUCKOO if args.scheme == "cuckoo" else M.SCHEME_2CHOICE
 
     stream_gen = Stream(args, rank, world, mem_p_agg)
-    if world == 1:
+    if not sharded:
         from megakv_amd.index import HashIndex
         geom = M.Geometry(mem_p=args.mem_p, scheme=scheme)
         engine = SingleGpu(HashIndex(geom, device=device), args)
@@ -178,7 +191,7 @@ def main():
         every = max(1, args.events_every)
         timer = engine.make_timer((args.steps + every - 1) // every) if (use_events and not args.graph) else None
         timed = batches[args.warmup:]
-        if world > 1 and not args.no_pipeline:
+        if sharded and not args.no_pipeline:
             # two batches in flight: exchanges of one overlap the local kernels of the other
             engine.run_pipelined(timed, (lambda i: [timer.h, i // every] if (timer and i % every == 0) else None))
         else:
@@ -202,20 +215,20 @@ def main():
         avg_s = float(ms.mean()) * 1e-3
         algo_bytes = GET_BYTES * engine.search_requests_per_launch(stream_gen)
         achieved = algo_bytes / avg_s / 1e9
-        fused = world == 1 and args.overlap == "fused" and not args.memset and stream_gen.n_set > 0
+        fused = not sharded and args.overlap == "fused" and not args.memset and stream_gen.n_set > 0
         roofline = {"bound": "hbm",
                     "kernel": "mkv::k_search_mark (search work-groups + the insert's mark work-groups)" if fused
-                    else ("mkv::k_search_slots" if world > 1 else "mkv::k_search"), "achieved": round(achieved, 1),
+                    else ("mkv::k_search_slots" if sharded else "mkv::k_search"), "achieved": round(achieved, 1),
                     "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
                     "traffic": load_traffic(args), "algorithmic_bytes_per_launch": algo_bytes,
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(len(ms)), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
                     "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2)}
 
     cpu = None
-    if rank == 0 and world == 1 and not args.no_cpu:
+    if rank == 0 and not sharded and not args.no_cpu:
         cpu = cpu_baseline(engine, stream_gen, args)
 
-    if world > 1 and engine.overflowed():
+    if sharded and engine.overflowed():
         raise SystemExit("a shard slot overflowed: raise cap_factor (results of this run are invalid)")
     if rank == 0:
         line = {
@@ -231,7 +244,7 @@ def main():
                        "batch": 1 << args.batch_log2, "gets": stream_gen.n_get, "sets": stream_gen.n_set,
                        "keying": "K-" + args.keying, "set_keys": "S-" + args.sets, "load_factor": args.lf,
                        "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "memset" if args.memset else "by the search kernel", "mark_pass": args.overlap,
-                       "sharding": "single table" if world == 1 else
+                       "sharding": "single table" if not sharded else
                        f"{world} shards by top bucket bits, RCCL all-to-all, "
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else "eager"},
@@ -239,7 +252,7 @@ def main():
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
-        print(json.dumps(line), flush=True)
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
 

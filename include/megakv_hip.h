@@ -144,6 +144,14 @@ int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem_t *sets, i
  * n_set into set_counts[nslots] for the insert that follows. */
 int mkv_search_slots(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
 		int64_t cap_set, loc_t *out, const bucket_t *table, int *set_counts, void *stream);
+/* Local phase of a sharded step in one call: search every received slot and insert
+ * what the slots carry -- one insert block per source rank, counts read from the slot
+ * headers on the device, the insert's mark pass fused into the search launch.
+ * set_ptrs: device array of nslots device pointers to the slots' insert regions
+ * (recvbuf + s*slot_words + 4 + 2*cap_get words).  size_hint as in mkv_insert_hinted. */
+int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
+		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
+		void *stream, void *timer, int slot);
 /* out[perm_get[pos]] = back[pos] for every position that carried a request. */
 int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf, int nshards,
 		int64_t cap_get, int64_t cap_set, loc_t *out, void *stream);

@@ -9,6 +9,7 @@
 
 #include "libgpuhash.h"
 #include "megakv_hip.h"
+#include "mkv_common.h"
 
 static const mkv_geom_t kGeom = {
 	MEM_P, IBLOCK_P,
@@ -74,11 +75,6 @@ extern "C" void gpu_delete_insert(bucket_t *hash_table, delem_t *delete_in, uint
 
 // HIP event pairs recorded on the caller's stream around the search launch of
 // mkv_cycle: how bench.py times the dominant kernel inside the timed region.
-struct MkvTimer {
-	int slots;
-	hipEvent_t *ev;
-};
-
 extern "C" void *mkv_timer_create(int slots)
 {
 	if (slots <= 0)

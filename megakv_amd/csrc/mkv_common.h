@@ -7,6 +7,13 @@
 
 #include "megakv_hip.h"
 
+// HIP event pairs recorded on the caller's stream around a search launch
+// (mkv_timer_create / mkv_cycle / mkv_slots_cycle): bench.py's kernel timing.
+struct MkvTimer {
+	int slots;
+	hipEvent_t *ev;
+};
+
 namespace mkv {
 
 constexpr int kWave = 64;

@@ -241,57 +241,47 @@ __global__ __launch_bounds__(256) void k_pack_count(const uint32_t *__restrict__
 		wc[(int64_t)lane * nw + wave] = mine;
 }
 
-// one block: per (kind, shard) exclusive scan over the waves, headers, overflow
+// one block of 16 waves: wave w scans the (kind, shard) segments w, w+16, ...
+// (exclusive scan over that segment's per-wave counts), writes the slot header
+// and raises the overflow flag
 __global__ __launch_bounds__(1024) void k_pack_scan(uint32_t *wc_get, int64_t nw_get, uint32_t *wc_set,
 		int64_t nw_set, int nshards, uint32_t *sendbuf, int64_t slot_words, uint32_t cap_get,
 		uint32_t cap_set, int *overflow)
 {
-	__shared__ uint32_t part[1024];
-	__shared__ uint32_t carry;
-	const uint32_t t = threadIdx.x;
-	for (int kind = 0; kind < 2; kind++) {
-		uint32_t *wc = kind ? wc_set : wc_get;
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t wave = threadIdx.x >> 6;
+	for (uint32_t seg = wave; seg < 2u * (uint32_t)nshards; seg += blockDim.x >> 6) {
+		const int kind = seg >= (uint32_t)nshards;
+		const int s = (int)(kind ? seg - (uint32_t)nshards : seg);
 		const int64_t nw = kind ? nw_set : nw_get;
-		for (int s = 0; s < nshards; s++) {
-			uint32_t *seg = wc + (int64_t)s * nw;
-			if (t == 0)
-				carry = 0;
-			__syncthreads();
-			for (int64_t base = 0; base < nw; base += 1024) {
-				const int64_t i = base + t;
-				const uint32_t v = i < nw ? seg[i] : 0u;
-				part[t] = v;
-				__syncthreads();
-				for (uint32_t off = 1; off < 1024; off <<= 1) {
-					const uint32_t add = t >= off ? part[t - off] : 0u;
-					__syncthreads();
-					part[t] += add;
-					__syncthreads();
-				}
-				const uint32_t incl = part[t];
-				if (i < nw)
-					seg[i] = carry + incl - v;
-				__syncthreads();
-				if (t == 1023)
-					carry += incl;
-				__syncthreads();
+		uint32_t *p = (kind ? wc_set : wc_get) + (int64_t)s * nw;
+		uint32_t carry = 0;
+		for (int64_t base = 0; base < nw; base += 64) {
+			const int64_t i = base + lane;
+			const uint32_t v = i < nw ? p[i] : 0u;
+			uint32_t incl = v;
+			for (int off = 1; off < 64; off <<= 1) {
+				const uint32_t o = __shfl_up(incl, off);
+				if ((int)lane >= off)
+					incl += o;
 			}
-			if (t == 0) {
-				const uint32_t total = carry;
-				const uint32_t cap = kind ? cap_set : cap_get;
-				uint32_t *hdr = sendbuf + (int64_t)s * slot_words;
-				if (total > cap) {
-					*overflow = 1;
-					hdr[kind] = 0;             // nothing of this kind is sent for this slot
-				} else {
-					hdr[kind] = total;
-				}
-				if (kind == 0) {
-					hdr[2] = 0;
-					hdr[3] = 0;
-				}
+			if (i < nw)
+				p[i] = carry + incl - v;
+			carry += __shfl(incl, 63);
+		}
+		if (lane == 0) {
+			const uint32_t cap = kind ? cap_set : cap_get;
+			uint32_t *hdr = sendbuf + (int64_t)s * slot_words;
+			if (carry > cap) {
+				*overflow = 1;
+				hdr[kind] = 0;             // nothing of this kind is sent for this slot
+			} else {
+				hdr[kind] = carry;
 			}
-			__syncthreads();
+			if (kind == 0) {
+				hdr[2] = 0;
+				hdr[3] = 0;
+			}
 		}
 	}
 }
@@ -363,16 +353,10 @@ __global__ __launch_bounds__(256) void k_search_slots(const uint32_t *__restrict
 		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
 		uint32_t hash_mask, uint32_t blk_mask, uint32_t chunks_per_slot, int nslots, int *set_counts)
 {
-	const uint32_t seg = blockIdx.x / chunks_per_slot;
-	const uint32_t chunk = blockIdx.x - seg * chunks_per_slot;
-	const uint32_t *slot = recvbuf + (int64_t)seg * slot_words;
 	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)nslots)
 		set_counts[threadIdx.x] = (int)recvbuf[(int64_t)threadIdx.x * slot_words + 1];
-	const uint32_t n = slot[0];
-	if ((uint64_t)chunk * 256u >= n)
-		return;
-	search_body<4, true, false>(chunk, reinterpret_cast<const uint2 *>(slot + kHdrWords),
-			out + (int64_t)seg * cap_get * 2, table, (int64_t)n, hash_mask, blk_mask);
+	search_slots_body(blockIdx.x, recvbuf, slot_words, cap_get, out, table, hash_mask, blk_mask,
+			chunks_per_slot);
 }
 
 // results come back in the layout they were sent in: result of slot s, position r

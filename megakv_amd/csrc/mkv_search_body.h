@@ -89,4 +89,23 @@ __device__ __forceinline__ void search_body(uint32_t block, const uint2 *__restr
 	}
 }
 
+// Search of the slots a shard received (padded exchange format, mkv_route.hip):
+// linear block index -> (slot, 256-request chunk); the slot's request count is read
+// from its header on the device.
+constexpr int kSlotHdrWords = 4;
+
+__device__ __forceinline__ void search_slots_body(uint32_t block, const uint32_t *__restrict__ recvbuf,
+		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
+		uint32_t hash_mask, uint32_t blk_mask, uint32_t chunks_per_slot)
+{
+	const uint32_t seg = block / chunks_per_slot;
+	const uint32_t chunk = block - seg * chunks_per_slot;
+	const uint32_t *slot = recvbuf + (int64_t)seg * slot_words;
+	const uint32_t n = slot[0];
+	if ((uint64_t)chunk * 256u >= n)
+		return;
+	search_body<4, true, false>(chunk, reinterpret_cast<const uint2 *>(slot + kSlotHdrWords),
+			out + (int64_t)seg * cap_get * 2, table, (int64_t)n, hash_mask, blk_mask);
+}
+
 }  // namespace mkv

@@ -124,6 +124,7 @@ struct ReqSrc {
 	const int *blk_elem_num;
 	long long single_n;
 	uint32_t nblk;
+	uint32_t cnt_stride;                // blk_elem_num[b * cnt_stride] (1 = the ABI's dense int[])
 };
 
 // ---- coherent access helpers ---------------------------------------------------
@@ -487,7 +488,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		}
 	} else {
 		for (uint32_t b = t; b < nblk; b += blockDim.x) {
-			const int c = src.blk_elem_num[b];
+			const int c = src.blk_elem_num[(size_t)b * src.cnt_stride];
 			s_ptr[b] = src.blk_input[b];        // fetched beside the counts: one round trip
 			s_prefix[b + 1] = c > 0 ? (uint32_t)c : 0u;
 		}
@@ -661,6 +662,22 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx);
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
+}
+
+// Sharded index: search of the received slots + mark pass of the inserts they carry,
+// one launch (same horizontal fusion as k_search_mark).
+template <Op OP>
+__global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__restrict__ recvbuf,
+		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
+		uint32_t chunks_per_slot, uint32_t search_blocks, Ctl *ctl, ReqSrc src, DevGeom g,
+		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx)
+{
+	const uint32_t mark_blocks = gridDim.x - search_blocks;
+	if (blockIdx.x < mark_blocks)
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx);
+	else
+		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
+				g.blk_mask, chunks_per_slot);
 }
 
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
@@ -1540,6 +1557,7 @@ extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_
 	src.blk_elem_num = blk_elem_num;
 	src.single_n = 0;
 	src.nblk = (uint32_t)num_blks;
+	src.cnt_stride = 1;
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		return mkv::run_update<mkv::OP_2CHOICE>(d, t, src, (hipStream_t)stream, size_hint);
@@ -1563,6 +1581,7 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_inpu
 	src.blk_elem_num = blk_elem_num;
 	src.single_n = 0;
 	src.nblk = (uint32_t)num_blks;
+	src.cnt_stride = 1;
 	mkv::Workspace *w = nullptr;
 	hipStream_t s = (hipStream_t)stream;
 	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
@@ -1597,6 +1616,7 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	src.blk_elem_num = blk_elem_num;
 	src.single_n = 0;
 	src.nblk = (uint32_t)num_blks;
+	src.cnt_stride = 1;
 	mkv::Workspace *w = nullptr;
 	hipStream_t s = (hipStream_t)stream;
 	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
@@ -1644,6 +1664,7 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 	src.blk_elem_num = blk_elem_num;
 	src.single_n = 0;
 	src.nblk = (uint32_t)num_blks;
+	src.cnt_stride = 1;
 	// chunk 0 was marked beside (or inside) the search launch; later chunks are marked here
 	const int nchunks = mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO);
 	for (int c = 0; c < nchunks; c++) {
@@ -1657,6 +1678,86 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+		}
+		if (rc != MKV_OK)
+			return rc;
+	}
+	return MKV_OK;
+}
+
+// Local phase of a sharded step in one call: search every received slot and insert
+// what the slots carry (one block per source rank, counts read from the slot headers
+// on the device).  set_ptrs: device array of the nslots device pointers to the slots'
+// insert regions (fixed per receive buffer).
+extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
+		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
+		void *stream, void *timer, int slot)
+{
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || nslots < 1 || nslots > mkv::kMaxBlocks || cap_get < 0 ||
+			cap_get > 0x7fffffffLL || cap_set < 0 || !recvbuf || !out_slots || !table)
+		return MKV_EINVAL;
+	MkvTimer *tm = reinterpret_cast<MkvTimer *>(timer);
+	if (tm && (slot < 0 || slot >= tm->slots))
+		return MKV_EINVAL;
+	const int64_t slot_words = mkv::kSlotHdrWords + cap_get * 2 + cap_set * 3;
+	hipStream_t s = (hipStream_t)stream;
+	const uint32_t chunks = (uint32_t)((cap_get + 255) / 256);
+	const uint32_t search_blocks = (chunks ? chunks : 1u) * (uint32_t)nslots;
+	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
+	if (cap_set == 0 || !set_ptrs) {
+		// nothing to insert: plain slot search (mark_blocks = 0)
+		mkv::ReqSrc none = {};
+		if (tm)
+			(void)hipEventRecord(tm->ev[2 * slot], s);
+		hipLaunchKernelGGL((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), 0, s,
+				recvbuf, slot_words, (uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks,
+				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (uint4 *)nullptr,
+				(uint8_t *)nullptr, 0u, 0u);
+		if (tm)
+			(void)hipEventRecord(tm->ev[2 * slot + 1], s);
+		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+	}
+	mkv::ReqSrc src;
+	src.blk_input = reinterpret_cast<const uint32_t *const *>(set_ptrs);
+	src.single = nullptr;
+	src.blk_elem_num = reinterpret_cast<const int *>(recvbuf + 1);     // n_set of slot b: header word 1
+	src.single_n = 0;
+	src.nblk = (uint32_t)nslots;
+	src.cnt_stride = (uint32_t)slot_words;
+	mkv::Workspace *w = nullptr;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
+	if (rc != MKV_OK)
+		return rc;
+	const bool cuckoo = d.scheme == MKV_SCHEME_CUCKOO;
+	const int nchunks = mkv::chunk_count(size_hint, cuckoo);
+	uint32_t lo, hi;
+	mkv::chunk_range(0, nchunks, &lo, &hi);
+	const uint32_t mark_blocks = 256;
+	const dim3 grid(search_blocks + mark_blocks), block(256);
+	if (tm)
+		(void)hipEventRecord(tm->ev[2 * slot], s);
+	if (cuckoo)
+		hipLaunchKernelGGL((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, 0, s, recvbuf, slot_words,
+				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
+				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
+	else
+		hipLaunchKernelGGL((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, 0, s, recvbuf, slot_words,
+				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
+				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
+	if (tm)
+		(void)hipEventRecord(tm->ev[2 * slot + 1], s);
+	uint32_t *t = reinterpret_cast<uint32_t *>(table);
+	for (int c = 0; c < nchunks; c++) {
+		mkv::chunk_range(c, nchunks, &lo, &hi);
+		if (cuckoo) {
+			if (c > 0)
+				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, lo, hi);
+			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+		} else {
+			if (c > 0)
+				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, lo, hi);
+			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
 		}
 		if (rc != MKV_OK)
 			return rc;
@@ -1680,6 +1781,7 @@ extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 	src.blk_elem_num = nullptr;
 	src.single_n = num_elem;
 	src.nblk = 1;
+	src.cnt_stride = 1;
 	return mkv::run_update<mkv::OP_DELETE>(d, reinterpret_cast<uint32_t *>(table), src,
 			(hipStream_t)stream);
 }

@@ -78,25 +78,37 @@ class HipOps:
     def scratch_bytes(self, n_get, n_set, g):
         return int(self.lib.mkv_pack_scratch_bytes(n_get, n_set, g))
 
-    def pack(self, gets, sets, agg_mask, shift, g, sendbuf, cap_get, cap_set, perm, scratch, overflow):
+    @staticmethod
+    def _sp(stream):
+        return _stream_ptr(None) if stream is None else ctypes.c_void_p(stream)
+
+    def pack(self, gets, sets, agg_mask, shift, g, sendbuf, cap_get, cap_set, perm, scratch, overflow, stream=None):
         null = ctypes.c_void_p(0)
         _check(self.lib.mkv_pack_requests(
             _dev_ptr(gets) if gets.shape[0] else null, gets.shape[0],
             _dev_ptr(sets) if sets.shape[0] else null, sets.shape[0],
             agg_mask, shift, g, _dev_ptr(sendbuf), cap_get, cap_set, _dev_ptr(perm), _dev_ptr(scratch),
-            scratch.numel() * scratch.element_size(), _dev_ptr(overflow), _stream_ptr(None)), "mkv_pack_requests")
+            scratch.numel() * scratch.element_size(), _dev_ptr(overflow), self._sp(stream)), "mkv_pack_requests")
 
-    def search_slots(self, recvbuf, g, cap_get, cap_set, out_slots, set_counts):
+    def search_slots(self, recvbuf, g, cap_get, cap_set, out_slots, set_counts, stream=None):
         _check(self.lib.mkv_search_slots(ctypes.byref(self.idx._g), _dev_ptr(recvbuf), g, cap_get, cap_set,
                                          _dev_ptr(out_slots), _dev_ptr(self.idx.table), _dev_ptr(set_counts),
-                                         _stream_ptr(None)), "mkv_search_slots")
+                                         self._sp(stream)), "mkv_search_slots")
 
-    def insert_slots(self, ptrs, set_counts, g, hint=0):
-        self.idx.insert_staged(ptrs, set_counts, g, None, hint)
+    def insert_slots(self, ptrs, set_counts, g, hint=0, stream=None):
+        self.idx.insert_staged(ptrs, set_counts, g, stream, hint)
 
-    def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out):
+    def slots_cycle(self, recvbuf, g, cap_get, cap_set, out_slots, set_ptrs, hint, stream=None, timer=None, slot=0):
+        """search of the received slots + the inserts they carry, one library call"""
+        null = ctypes.c_void_p(0)
+        _check(self.lib.mkv_slots_cycle(ctypes.byref(self.idx._g), _dev_ptr(recvbuf), g, cap_get, cap_set,
+                                        _dev_ptr(out_slots), _dev_ptr(self.idx.table),
+                                        _dev_ptr(set_ptrs) if cap_set else null, int(hint), self._sp(stream),
+                                        ctypes.c_void_p(timer) if timer else null, slot), "mkv_slots_cycle")
+
+    def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out, stream=None):
         _check(self.lib.mkv_unpack_results(_dev_ptr(back), _dev_ptr(perm), _dev_ptr(sendbuf), g, cap_get,
-                                           cap_set, _dev_ptr(out), _stream_ptr(None)), "mkv_unpack_results")
+                                           cap_set, _dev_ptr(out), self._sp(stream)), "mkv_unpack_results")
 
     def slot_set_pointers(self, recvbuf, g, slot_words, cap_get):
         base = recvbuf.data_ptr()
@@ -138,6 +150,10 @@ class _Lane:
         self.set_counts = torch.zeros((w,), **i32)
         self.set_ptrs = ops.slot_set_pointers(self.recvbuf, w, sh.slot_words, sh.cap_get)
         self.stream = make_stream() if make_stream else None
+        self.sptr = self.stream.cuda_stream if self.stream is not None else None
+        if self.stream is not None:
+            self.ev_local = [torch.cuda.Event(), torch.cuda.Event()]   # alternated so a pending wait keeps its event
+            self.ev_done = torch.cuda.Event()
 
 
 class ShardedIndex:
@@ -179,26 +195,28 @@ class ShardedIndex:
         return (hash_np.astype(np.uint64) & np.uint64(self.agg_mask)) >> np.uint64(self.shift)
 
     # -- one step -----------------------------------------------------------------------
-    def _forward(self, ln, gets, sets):
-        """pack the local batch into slots and start the forward exchange"""
+    def _forward(self, ln, gets, sets, sp=None):
+        """pack the local batch into slots and start the forward exchange (sp: raw stream
+        handle = the CURRENT torch stream, which the collective uses)"""
         self.ops.pack(gets, sets, self.agg_mask, self.shift, self.world, ln.sendbuf, self.cap_get, self.cap_set,
-                      ln.perm, ln.scratch, self.overflow)
+                      ln.perm, ln.scratch, self.overflow, sp)
         self.comm.all_to_all(ln.recvbuf, ln.sendbuf)
 
-    def _local(self, ln, timing=None):
+    def _local(self, ln, timing=None, sp=None):
         """serve what the peers sent: search every slot, then insert (source-rank order)"""
         o, w = self.ops, self.world
-        if timing:
-            timing[0].start(timing[1])
+        if hasattr(o, "slots_cycle"):
+            o.slots_cycle(ln.recvbuf, w, self.cap_get, self.cap_set, ln.out_slots, ln.set_ptrs, self.n_set, sp,
+                          (timing[0] if isinstance(timing[0], int) else timing[0].h) if timing else None,
+                          timing[1] if timing else 0)
+            return
         o.search_slots(ln.recvbuf, w, self.cap_get, self.cap_set, ln.out_slots, ln.set_counts)
-        if timing:
-            timing[0].stop(timing[1])
         if self.cap_set:
             o.insert_slots(ln.set_ptrs, ln.set_counts, w, self.n_set)
 
-    def _backward(self, ln, out):
+    def _backward(self, ln, out, sp=None):
         self.comm.all_to_all(ln.back_slots, ln.out_slots)
-        self.ops.unpack(ln.back_slots, ln.perm, ln.sendbuf, self.world, self.cap_get, self.cap_set, out)
+        self.ops.unpack(ln.back_slots, ln.perm, ln.sendbuf, self.world, self.cap_get, self.cap_set, out, sp)
 
     def step_tensors(self, gets, sets, out):
         """gets [n,2], sets [m,3] int32 tensors of this rank; out [n,2] receives the
@@ -224,25 +242,28 @@ class ShardedIndex:
         for ln in self.lanes:
             ln.stream.wait_event(start)
         prev_local = None
-        with torch.cuda.stream(self.lanes[0].stream):
-            self._forward(self.lanes[0], batches[0]["q"], batches[0]["s"])
+        set_stream = torch.cuda.set_stream         # cheaper than the context manager
+        l0 = self.lanes[0]
+        set_stream(l0.stream)
+        self._forward(l0, batches[0]["q"], batches[0]["s"], l0.sptr)
+        n = len(batches)
         for i, b in enumerate(batches):
             ln = self.lanes[i & 1]
-            if i + 1 < len(batches):
+            if i + 1 < n:
                 nxt = self.lanes[(i + 1) & 1]
-                with torch.cuda.stream(nxt.stream):
-                    self._forward(nxt, batches[i + 1]["q"], batches[i + 1]["s"])
-            with torch.cuda.stream(ln.stream):
-                if prev_local is not None:
-                    ln.stream.wait_event(prev_local)
-                self._local(ln, timing_of(i) if timing_of else None)
-                prev_local = torch.cuda.Event()
-                prev_local.record(ln.stream)
-                self._backward(ln, b["out"])
+                set_stream(nxt.stream)
+                self._forward(nxt, batches[i + 1]["q"], batches[i + 1]["s"], nxt.sptr)
+            set_stream(ln.stream)
+            if prev_local is not None:
+                ln.stream.wait_event(prev_local)
+            self._local(ln, timing_of(i) if timing_of else None, ln.sptr)
+            prev_local = ln.ev_local[(i >> 1) & 1]
+            prev_local.record(ln.stream)
+            self._backward(ln, b["out"], ln.sptr)
+        set_stream(main)
         for ln in self.lanes:
-            done = torch.cuda.Event()
-            done.record(ln.stream)
-            main.wait_event(done)
+            ln.ev_done.record(ln.stream)
+            main.wait_event(ln.ev_done)
 
     # -- the engine interface bench.py drives --------------------------------------------------
     def preload(self, P, keying):
@@ -270,7 +291,8 @@ class ShardedIndex:
                 self.idx.reserve(self.world * self.cap_set + 1024, ln.stream)
 
     def make_timer(self, slots):
-        return _TorchTimer(slots)
+        from .index import SearchTimer
+        return SearchTimer(slots)
 
     def step(self, b, stream, pair):
         self._timing = pair            # [timer, slot] or None

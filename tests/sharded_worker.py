@@ -48,7 +48,7 @@ class CpuOps:
         self._recv[ptrs.data_ptr()] = (recvbuf, slot_words, cap_get)     # one entry per lane
         return ptrs
 
-    def pack(self, gets, sets, agg_mask, shift, g, sendbuf, cap_get, cap_set, perm, scratch, overflow):
+    def pack(self, gets, sets, agg_mask, shift, g, sendbuf, cap_get, cap_set, perm, scratch, overflow, stream=None):
         sb = sendbuf.numpy().view(np.uint32)
         pm = perm.numpy()
         G = gets.numpy().view(np.uint32)
@@ -66,7 +66,7 @@ class CpuOps:
             off = 4 + 2 * cap_get
             sb[s, off:off + 3 * len(isx)] = S[isx].reshape(-1)
 
-    def search_slots(self, recvbuf, g, cap_get, cap_set, out_slots, set_counts):
+    def search_slots(self, recvbuf, g, cap_get, cap_set, out_slots, set_counts, stream=None):
         rb = recvbuf.numpy().view(np.uint32)
         osl = out_slots.numpy().view(np.uint32)
         for s in range(g):
@@ -77,14 +77,14 @@ class CpuOps:
             osl[s, :n] = res
             set_counts[s] = int(rb[s, 1])
 
-    def insert_slots(self, ptrs, set_counts, g, hint=0):
+    def insert_slots(self, ptrs, set_counts, g, hint=0, stream=None):
         recvbuf, slot_words, cap_get = self._recv[ptrs.data_ptr()]
         rb = recvbuf.numpy().view(np.uint32)
         off = 4 + 2 * cap_get
         blocks = [np.ascontiguousarray(rb[s, off:off + 3 * int(set_counts[s])].reshape(-1, 3)) for s in range(g)]
         self.O.insert(self.og, self.table, blocks)
 
-    def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out):
+    def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out, stream=None):
         bk = back.numpy().view(np.uint32)
         sb = sendbuf.numpy().view(np.uint32)
         pm = perm.numpy()
