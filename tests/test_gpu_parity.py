@@ -311,3 +311,31 @@ def test_cycle_equals_search_delete_insert(memset, overlap, scheme):
             assert np.array_equal(host(out), exp_out), f"search of cycle {step}"
             got = idx.table_numpy()
             assert np.array_equal(got, exp), (step, first_diff(got, exp))
+
+
+def test_large_preload_with_chunks_and_carries_matches_oracle():
+    """24 M keys into a MEM_P=29 table (load factor 0.36) in 1 M-request calls: every
+    call runs as 64 K chunks with a size hint, barriers appear as the table fills and
+    their unresolved requests are carried from chunk to chunk.  Final table image and a
+    search over all keys equal the oracle's."""
+    from megakv_amd import workload as W
+    g = Geometry(mem_p=29)
+    og = ogeom(g)
+    idx = HashIndex(g)
+    exp = O.new_table(og)
+    n_keys = 24 * (1 << 20)
+    chains = undone = 0
+    for lo in range(1, n_keys, 1 << 20):
+        k = np.arange(lo, lo + (1 << 20), dtype=np.uint32)
+        blocks = W.bin_inserts(W.make_ielem(k, None, W.KEYING_MIX), g.mem_p, g.iblock_p, W.BIN_REGION)
+        idx.insert([dev(b) for b in blocks])
+        O.insert(og, exp, blocks)
+        info = idx.last_update_info()
+        chains += info["chains"]
+        undone += info["undone"]
+        assert info["total"] == 1 << 20
+    got = idx.table_numpy()
+    assert np.array_equal(got, exp), first_diff(got, exp)
+    assert chains > 0 and undone > 0            # the interesting paths were really taken
+    q = W.make_selem(np.arange(1, 1 << 20, dtype=np.uint32), W.KEYING_MIX)
+    assert np.array_equal(host(idx.search(dev(q))), O.search(og, exp, q))
