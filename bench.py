@@ -182,8 +182,11 @@ def main():
         load_library().mkv_set_tuning(b"debug_skip", dbg_skip)
     with torch.cuda.stream(run_stream):
         engine.reserve(run_stream)
-        for b in batches[:args.warmup]:
-            engine.step(b, run_stream, None)
+        if sharded and not args.no_pipeline:
+            engine.run_pipelined(batches[:args.warmup])       # warms both lanes and their workspaces
+        else:
+            for b in batches[:args.warmup]:
+                engine.step(b, run_stream, None)
         run_stream.synchronize()
         hit_rate = engine.hit_rate(batches[args.warmup - 1]) if args.warmup else None
         barrier()

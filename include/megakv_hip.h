@@ -114,6 +114,18 @@ int mkv_last_update_info(void *stream, mkv_update_info_t *info);
 /* cycle_insert != 0: the insert half of the last mkv_cycle on `stream` */
 int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
 
+/* ---- request preparation on the device ------------------
+ * What the reference's receiver does per packet on the CPU, for a batch of
+ * fixed-stride keys: sig64 = first 8 key bytes (src/mega_recv.c:349-350), with
+ * fold != 0 XOR-folded over the rest of the key like the SIGNATURE build
+ * (:351-360); out[i] = {sig = low word, hash = high word[, loc = locs[i]]}
+ * (:361-362).  out_words: 2 = selem_t, 3 = ielem_t.  Bin the insert requests
+ * into blocks with mkv_route_requests: (mask, shift, n) = (0xffffffff,
+ * 32-IBLOCK_P, 2^IBLOCK_P) is the receiver's rule (:476-477), (HASH_MASK,
+ * MEM_P-6-IBLOCK_P, 2^IBLOCK_P) the region rule of libgpuhash/test/insert_test.c. */
+int mkv_derive_requests(const void *keys, int64_t num_keys, int key_len, int64_t key_stride, int fold,
+		const loc_t *locs, void *out, int out_words, void *stream);
+
 /* ---- request routing for the sharded (multi-GPU) index, SURVEY 8(e) -------
  * shard(e) = ((e.hash & hash_mask_agg) >> shard_shift); requests are grouped by
  * shard, stably, on the device.  `perm[j]` = original index of the j-th

@@ -457,3 +457,75 @@ extern "C" int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, co
 			(uint32_t)cap_get, nshards, reinterpret_cast<uint2 *>(out));
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
+
+// ===========================================================================
+// Request preparation on the device: what Mega-KV's receiver
+// does per packet on the CPU -- derive the 64-bit signature word from the key
+// bytes and split it into (sig, hash) -- for a whole batch of fixed-stride keys.
+//
+//   sig64 = first 8 key bytes                         (src/mega_recv.c:349-350)
+//   with `fold` (the reference's SIGNATURE build): XOR of all further 8-byte
+//   words, the 1..7 tail bytes masked              (src/mega_recv.c:351-360)
+//   hash  = sig64 >> 32,  sig = low 32 bits           (src/mega_recv.c:361-362)
+//
+// Binning the resulting insert requests into the 2^IBLOCK_P blocks is
+// mkv_route_requests with (mask, shift) = (0xffffffff, 32-IBLOCK_P) for the
+// receiver's rule (src/mega_recv.c:476-477) or (HASH_MASK, MEM_P-6-IBLOCK_P)
+// for the region rule of libgpuhash/test/insert_test.c:117-124.
+// ===========================================================================
+namespace mkv {
+
+__global__ __launch_bounds__(256) void k_derive(const uint8_t *__restrict__ keys, int64_t n, int key_len,
+		int64_t key_stride, int fold, const uint32_t *__restrict__ locs, uint32_t *__restrict__ out,
+		int out_words)
+{
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+			i += (int64_t)gridDim.x * blockDim.x) {
+		const uint8_t *k = keys + i * key_stride;
+		unsigned long long sig = 0;
+		// keys are at least 8 bytes (src/mega_common.c:37); unaligned strides are read bytewise
+		const bool aligned = (((uintptr_t)k) & 7u) == 0;
+		auto word = [&](int off, int nbytes) {
+			unsigned long long w = 0;
+			if (aligned && nbytes == 8)
+				return *reinterpret_cast<const unsigned long long *>(k + off);
+			for (int b = 0; b < nbytes; b++)
+				w |= (unsigned long long)k[off + b] << (8 * b);
+			return w;
+		};
+		sig = word(0, 8);
+		if (fold) {
+			int off = 8;
+			for (; off <= key_len - 8; off += 8)
+				sig ^= word(off, 8);
+			if (off < key_len)
+				sig ^= word(off, key_len - off);     // tail bytes, masked (:357-360)
+		}
+		uint32_t *o = out + i * out_words;
+		o[0] = (uint32_t)sig;                        // signature: low word
+		o[1] = (uint32_t)(sig >> 32);                // hash: high word
+		if (out_words == 3)
+			o[2] = locs[i];
+	}
+}
+
+}  // namespace mkv
+
+extern "C" int mkv_derive_requests(const void *keys, int64_t num_keys, int key_len, int64_t key_stride,
+		int fold, const loc_t *locs, void *out, int out_words, void *stream)
+{
+	if (num_keys < 0 || key_len < 8 || key_stride < key_len || (out_words != 2 && out_words != 3) ||
+			(out_words == 3 && !locs))
+		return MKV_EINVAL;
+	if (num_keys == 0)
+		return MKV_OK;
+	if (!keys || !out)
+		return MKV_EINVAL;
+	int64_t blocks = (num_keys + 255) / 256;
+	if (blocks > 4096)
+		blocks = 4096;
+	hipLaunchKernelGGL(mkv::k_derive, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
+			reinterpret_cast<const uint8_t *>(keys), num_keys, key_len, key_stride, fold,
+			reinterpret_cast<const uint32_t *>(locs), reinterpret_cast<uint32_t *>(out), out_words);
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
