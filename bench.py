@@ -69,6 +69,7 @@ def parse():
     ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
+    ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
     ap.add_argument("--cpu-batches", type=int, default=160,
                     help="batches of the same workload replayed on the CPU oracle (~10 s single-threaded)")
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
@@ -227,6 +228,10 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(len(ms)), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
                     "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2)}
 
+    pcie = None
+    if rank == 0 and not sharded and not args.no_pcie:
+        pcie = pcie_inclusive(engine, batches[args.warmup:args.warmup + 24], run_stream, args)
+
     cpu = None
     if rank == 0 and not sharded and not args.no_cpu:
         cpu = cpu_baseline(engine, stream_gen, args)
@@ -251,7 +256,7 @@ def main():
                        f"{world} shards by top bucket bits, RCCL all-to-all, "
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else "eager"},
-            "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu,
+            "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
@@ -282,7 +287,11 @@ class SingleGpu:
         b = {"q": dev(gets, self.device),
              "out": torch.empty((gets.shape[0], 2), dtype=torch.int32, device=self.device)}
         if sets.shape[0]:
-            blocks = [dev(x, self.device) for x in W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION)]
+            # the insert blocks of a batch live in ONE device buffer (block order), each block a slice
+            parts = W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION)
+            b["sets_all"] = dev(np.concatenate(parts), self.device)
+            offs = np.concatenate([[0], np.cumsum([p.shape[0] for p in parts])])
+            blocks = [b["sets_all"][offs[i]:offs[i + 1]] for i in range(len(parts))]
             b["ptrs"], b["cnts"], b["keep"] = self.idx.stage_blocks(blocks)
             b["n_set"] = int(sets.shape[0])
         return b
@@ -325,6 +334,47 @@ class SingleGpu:
 
     def table_host(self):
         return self.idx.table_numpy()
+
+
+def pcie_inclusive(engine, batches, stream, args):
+    """Side measurement, never `value`: the same cycles when the boundary hands over HOST
+    buffers the way the reference's scheduler does (pinned staging, H2D of the requests,
+    D2H of the results on the worker's stream, src/mega_scheduler.c:404-419,484-494).
+    The batches are re-run (their SET keys are then updates), which does not change
+    the bytes moved."""
+    if not batches:
+        return None
+    idx = engine.idx
+    host = []
+    for b in batches:
+        h = {"q": b["q"].cpu().pin_memory(), "out": torch.empty_like(b["out"], device="cpu").pin_memory()}
+        if "sets_all" in b:
+            h["sets"] = b["sets_all"].cpu().pin_memory()
+        host.append(h)
+    torch.cuda.synchronize()
+
+    def run(pairs):
+        for b, h in pairs:
+            b["q"].copy_(h["q"], non_blocking=True)
+            if "sets" in h:
+                b["sets_all"].copy_(h["sets"], non_blocking=True)     # one copy for all insert blocks
+            engine._launch(b, stream, None)
+            h["out"].copy_(b["out"], non_blocking=True)
+        stream.synchronize()
+
+    with torch.cuda.stream(stream):
+        run(list(zip(batches, host))[:4])                     # warm the copy paths
+        t0 = time.perf_counter()
+        run(list(zip(batches, host))[4:])
+        dt = time.perf_counter() - t0
+    steps = len(batches) - 4
+    n = steps * (1 << args.batch_log2)
+
+    return {"value": round(n / dt / 1e6, 1), "unit": "Mops", "steps": steps, "us_per_step": round(dt / steps * 1e6, 1),
+            "bytes_per_step_h2d": int(batches[0]["q"].numel() * 4 + (batches[0]["sets_all"].numel() * 4
+                                                                     if "sets_all" in batches[0] else 0)),
+            "bytes_per_step_d2h": int(batches[0]["out"].numel() * 4),
+            "note": "pinned host buffers, H2D requests + D2H results per step on one stream, no copy/compute overlap"}
 
 
 def load_traffic(args):
