@@ -64,6 +64,9 @@ def parse():
     ap.add_argument("--force-sharded", action="store_true",
                     help="use the sharded engine (pack / RCCL all-to-all / slots) even with one rank: a self-test "
                          "of the multi-GPU code path on a single GPU")
+    ap.add_argument("--comm", default="nccl", choices=["nccl", "staged"],
+                    help="staged: gloo collectives through host memory, all ranks on cuda:0 -- only to exercise "
+                         "the multi-rank flow of this script on a one-GPU box")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1: run the steps strictly one after the other (no exchange/compute overlap)")
     ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
@@ -128,6 +131,8 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
+    if args.comm == "staged":
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device(f"cuda:{local_rank}")
     dist = None
@@ -138,7 +143,10 @@ def main():
         if world == 1:
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
             os.environ.setdefault("MASTER_PORT", "29517")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+        if args.comm == "staged":
+            dist.init_process_group("gloo", rank=rank, world_size=world)
+        else:
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
     log2w = world.bit_length() - 1
     assert 1 << log2w == world and world <= 8, "1/2/4/8 GPUs"
@@ -151,9 +159,9 @@ def main():
         geom = M.Geometry(mem_p=args.mem_p, scheme=scheme)
         engine = SingleGpu(HashIndex(geom, device=device), args)
     else:
-        from megakv_amd.sharded import ShardedIndex, NcclComm
+        from megakv_amd.sharded import ShardedIndex, NcclComm, StagedComm
         engine = ShardedIndex(args.mem_p, world, rank, scheme, device, stream_gen.n_get, stream_gen.n_set,
-                              NcclComm(dist))
+                              StagedComm(dist) if args.comm == "staged" else NcclComm(dist))
     dbg_skip = args.debug_skip
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
@@ -206,7 +214,7 @@ def main():
     barrier()
     elapsed = time.perf_counter() - t_start
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
