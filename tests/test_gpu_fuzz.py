@@ -1,0 +1,76 @@
+"""Seeded fuzzing of insert / delete / search parity over random geometries
+(MEM_P, IBLOCK_P, MAX_CUCKOO_NUM, scheme), fills, key distributions, block
+splits and tuning (chunk size, tail rounds).  Every case: GPU result == oracle,
+bit for bit, for a sequence of operations on one table."""
+import numpy as np
+import pytest
+import torch
+
+from megakv_amd import Geometry, HashIndex
+from megakv_amd.lib import load_library
+from oracle import oracle as O
+from tests.gpu_util import dev, host, ogeom, random_table, random_requests, split_blocks, first_diff
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(autouse=True)
+def _defaults():
+    yield
+    L = load_library()
+    L.mkv_set_tuning(b"tail_rounds", 48)
+    L.mkv_set_tuning(b"insert_chunk", 65536)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
+def test_fuzz_sequence(seed):
+    rng = np.random.default_rng(1000 + seed)
+    L = load_library()
+    mem_p = int(rng.integers(10, 19))
+    iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
+    scheme = int(rng.integers(0, 2))
+    max_cuckoo = int(rng.choice([0, 1, 2, 5, 6]))
+    g = Geometry(mem_p=mem_p, scheme=scheme, iblock_p=iblock_p, max_cuckoo=max_cuckoo)
+    og = ogeom(g)
+    L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 1, 3, 48])))
+    L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 2048, 8192, 65536])))
+    fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
+    sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
+    exp = random_table(g, rng, fill, sig_space)
+    idx = HashIndex(g)
+    idx.load_table(exp)
+    nslots = g.nbuckets * 8
+    for step in range(3):
+        op = rng.choice(["insert", "insert", "delete", "search"])
+        n = int(rng.integers(1, max(2, min(40000, nslots))))
+        e = random_requests(g, rng, n, sig_space, hot=float(rng.choice([0.0, 0.1, 0.6])),
+                            zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])))
+        ctx = dict(seed=seed, mem_p=mem_p, iblock_p=iblock_p, scheme=scheme, max_cuckoo=max_cuckoo, fill=fill,
+                   step=step, op=str(op), n=n)
+        if op == "insert":
+            how = str(rng.choice(["single", "region", "app", "uneven"]))
+            if iblock_p == 0 and how == "app":
+                how = "single"
+            blocks = split_blocks(e, g, rng, how)
+            O.insert(og, exp, blocks)
+            idx.insert([dev(b.reshape(-1, 3)) for b in blocks],
+                       hint=None if rng.random() < 0.7 else 0)      # hinted (chunked) or plain single pass
+            got = idx.table_numpy()
+            assert np.array_equal(got, exp), (ctx, how, first_diff(got, exp), idx.last_update_info())
+        elif op == "delete":
+            # make half of the deletes hit stored entries
+            occ = np.argwhere(exp[:, :8] != 0)
+            if len(occ):
+                pick = occ[rng.integers(0, len(occ), size=n // 2)]
+                e[: len(pick), 0] = exp[pick[:, 0], pick[:, 1]]
+                e[: len(pick), 1] = pick[:, 0]
+                e[: len(pick), 2] = exp[pick[:, 0], 8 + pick[:, 1]]
+            O.delete(og, exp, e)
+            idx.delete(dev(e))
+            got = idx.table_numpy()
+            assert np.array_equal(got, exp), (ctx, first_diff(got, exp))
+        else:
+            q = np.ascontiguousarray(e[:, :2])
+            out = host(idx.search(dev(q), zero_miss=bool(rng.integers(0, 2))))
+            ref = O.search(og, exp, q)
+            assert np.array_equal(out, ref), ctx
