@@ -84,6 +84,7 @@ struct Tuning {
 	int tail_rounds;     // reservation rounds inside the tail work-group (0..48)
 	long long req_cap;   // default request capacity of an update workspace
 	long long insert_chunk; // requests per canonical-index chunk when the caller hints the batch size
+	int mark_blocks;        // work-groups of the insert mark pass inside the fused search launch
 	int debug_skip;      // diagnostics only (breaks results): bit0 no table stores, bit1 no undo log,
 	                     // bit2 no owner loads, bit3 no bucket load, bit4 no state store
 };

@@ -78,6 +78,10 @@ Tuning &tuning()
 		v.req_cap = s ? atoll(s) : (1ll << 22);
 		if (v.req_cap < 1024) v.req_cap = 1024;
 		v.debug_skip = 0;
+		s = getenv("MKV_MARK_BLOCKS");
+		v.mark_blocks = s ? atoi(s) : 128;
+		if (v.mark_blocks < 1) v.mark_blocks = 1;
+		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
 		s = getenv("MKV_INSERT_CHUNK");
 		v.insert_chunk = s ? atoll(s) : 65536;
 		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
@@ -131,6 +135,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1024)
 			return MKV_EINVAL;
 		t.insert_chunk = value & ~15ll;
+	} else if (!strcmp(name, "mark_blocks")) {
+		if (value < 1 || value > 1024)
+			return MKV_EINVAL;
+		t.mark_blocks = (int)value;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

@@ -1051,7 +1051,7 @@ template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
 		const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds, uint32_t lo_idx,
-		uint32_t hi_idx, int first_chunk, int last_chunk)
+		uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag)
 {
 	__shared__ uint32_t lkeys[kSortCap];
 	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
@@ -1294,6 +1294,8 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->last.overflow = ctl->overflow;
 		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
 		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + ctl->bar_chain;
+		if (last_chunk && host_flag)
+			*host_flag = (ctl->last.bar_chain + ctl->bar_chain + ctl->last.bar_class + ctl->bar_class) != 0u ? 1u : 0u;
 		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->bar_class;
 		ctl->bar_chain = 0;
 		ctl->bar_class = 0;
@@ -1334,6 +1336,11 @@ __global__ void k_init_ctl(Ctl *ctl)
 		ctl->barrier[t] = kNone;
 }
 
+struct Chunking {
+	int passes;         // data chunks (+ flush pass when more than one)
+	uint32_t step;      // canonical indices per data chunk
+};
+
 // ---- per-stream workspace -----------------------------------------------------
 struct Workspace {
 	int device = -1;
@@ -1351,6 +1358,13 @@ struct Workspace {
 	// insert overlaps the search kernel, and the fork/join events
 	hipStream_t aux = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+	// One word of pinned host memory the tail kernel writes (1 = the call met region
+	// barriers).  The host reads it without synchronising when the next call on this
+	// workspace is set up -- possibly a call late, which is fine: it only steers how
+	// finely the next hinted batch is chunked, never the result.
+	volatile uint32_t *host_flag = nullptr;
+	uint32_t *host_flag_dev = nullptr;
+	Chunking cycle_ck = {1, 65536};    // chunking chosen by the first half of an mkv_cycle insert
 };
 
 static std::mutex g_ws_mutex;
@@ -1367,6 +1381,7 @@ static void free_ws(Workspace *w)
 	if (w->glist) (void)hipFree(w->glist);
 	if (w->chain_logs) (void)hipFree(w->chain_logs);
 	if (w->ctl) (void)hipFree(w->ctl);
+	if (w->host_flag) (void)hipHostFree((void *)w->host_flag);
 	if (w->aux) (void)hipStreamDestroy(w->aux);
 	if (w->ev_fork) (void)hipEventDestroy(w->ev_fork);
 	if (w->ev_join) (void)hipEventDestroy(w->ev_join);
@@ -1409,6 +1424,17 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	ok = ok && hipMalloc(&w->glist, (size_t)rc * 4) == hipSuccess;
 	ok = ok && hipMalloc(&w->chain_logs, (size_t)kChainLogCap * sizeof(ChainLog)) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
+	if (ok) {
+		void *hf = nullptr;
+		ok = hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess;
+		if (ok) {
+			w->host_flag = reinterpret_cast<volatile uint32_t *>(hf);
+			*w->host_flag = 0;
+			void *dp = nullptr;
+			ok = hipHostGetDevicePointer(&dp, hf, 0) == hipSuccess;
+			w->host_flag_dev = reinterpret_cast<uint32_t *>(dp);
+		}
+	}
 	if (ok) {
 		// owner entries start at "no owner" (all ones); counters at zero
 		ok = ok && hipMemsetAsync(w->owner[0], 0xff, nb * 8, stream) == hipSuccess;
@@ -1460,18 +1486,33 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 // Passes of one call: data chunks, plus -- when there are several -- a trailing
 // flush pass over an empty range that only takes what the last data chunk carried.
 // Two-choice insert and delete never raise barriers: always one pass.
-static int chunk_count(long long hint, uint32_t scheme_or_op_is_cuckoo = 1)
+static Chunking pick_chunking(const Workspace *w, long long hint, bool cuckoo)
 {
-	const long long c = tuning().insert_chunk;
-	if (!scheme_or_op_is_cuckoo || hint <= 0 || c <= 0 || hint <= c)
-		return 1;
+	Chunking k;
+	k.passes = 1;
+	k.step = (uint32_t)tuning().insert_chunk;
+	if (!cuckoo || hint <= 0)
+		return k;
+	long long c = tuning().insert_chunk;
+	// the previous call on this workspace met region barriers: a batch that would be one
+	// chunk is cut in four, so a barrier's redo rides through grid-wide passes
+	if (hint <= c && w && w->host_flag && *w->host_flag && hint >= 8192) {
+		c = ((hint + 3) / 4 + 15) & ~15ll;
+		if (c < 2048)
+			c = 2048;
+	}
+	if (hint <= c)
+		return k;
 	const long long n = (hint + c - 1) / c;
-	return (n > 255 ? 255 : (int)n) + 1;
+	k.passes = (n > 255 ? 255 : (int)n) + 1;
+	k.step = (uint32_t)c;
+	return k;
 }
 
-static void chunk_range(int c, int nchunks, uint32_t *lo, uint32_t *hi)
+static void chunk_range(int c, const Chunking &k, uint32_t *lo, uint32_t *hi)
 {
-	const uint32_t step = (uint32_t)tuning().insert_chunk;
+	const uint32_t step = k.step;
+	const int nchunks = k.passes;
 	if (nchunks == 1) {
 		*lo = 0;
 		*hi = kNone;
@@ -1499,10 +1540,11 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		return rc;
 	if (src.single_n > 0 && hint <= 0)
 		hint = src.single_n;               // delete: the count is a host value
-	const int nchunks = chunk_count(hint, OP == OP_CUCKOO);
+	const Chunking ck = pick_chunking(w, hint, OP == OP_CUCKOO);
+	const int nchunks = ck.passes;
 	for (int c = 0; c < nchunks; c++) {
 		uint32_t lo, hi;
-		chunk_range(c, nchunks, &lo, &hi);
+		chunk_range(c, ck, &lo, &hi);
 		launch_mark<OP>(w, g, src, stream, lo, hi);
 		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1);
 		if (rc != MKV_OK)
@@ -1526,7 +1568,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0, lo, hi);
 	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
-			last_chunk);
+			last_chunk, w->host_flag_dev);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -1590,7 +1632,8 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_inpu
 	if (hipEventRecord(w->ev_fork, s) != hipSuccess || hipStreamWaitEvent(w->aux, w->ev_fork, 0) != hipSuccess)
 		return MKV_EHIP;
 	uint32_t lo, hi;
-	mkv::chunk_range(0, mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO), &lo, &hi);
+	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
+	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux, lo, hi);
 	else
@@ -1623,7 +1666,7 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	if (rc != MKV_OK)
 		return rc;
 	const int64_t search_blocks = (num_search + 255) / 256;      // U = 4: 256 requests per block
-	const uint32_t mark_blocks = 256;
+	const uint32_t mark_blocks = (uint32_t)mkv::tuning().mark_blocks;
 	if (search_blocks + mark_blocks > 0x7fffffffLL)
 		return MKV_ETOOBIG;
 	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
@@ -1631,10 +1674,8 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
 	// the fused launch marks the first chunk only
 	uint32_t lo, hi;
-	{
-		const int nc = mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO);
-		mkv::chunk_range(0, nc, &lo, &hi);
-	}
+	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
+	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, 0, s, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
@@ -1666,10 +1707,12 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 	src.nblk = (uint32_t)num_blks;
 	src.cnt_stride = 1;
 	// chunk 0 was marked beside (or inside) the search launch; later chunks are marked here
-	const int nchunks = mkv::chunk_count(size_hint, d.scheme == MKV_SCHEME_CUCKOO);
+	(void)size_hint;
+	const mkv::Chunking ck = w->cycle_ck;
+	const int nchunks = ck.passes;
 	for (int c = 0; c < nchunks; c++) {
 		uint32_t lo, hi;
-		mkv::chunk_range(c, nchunks, &lo, &hi);
+		mkv::chunk_range(c, ck, &lo, &hi);
 		if (d.scheme == MKV_SCHEME_2CHOICE) {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, lo, hi);
@@ -1730,10 +1773,11 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	if (rc != MKV_OK)
 		return rc;
 	const bool cuckoo = d.scheme == MKV_SCHEME_CUCKOO;
-	const int nchunks = mkv::chunk_count(size_hint, cuckoo);
+	const mkv::Chunking ck = mkv::pick_chunking(w, size_hint, cuckoo);
+	const int nchunks = ck.passes;
 	uint32_t lo, hi;
-	mkv::chunk_range(0, nchunks, &lo, &hi);
-	const uint32_t mark_blocks = 256;
+	mkv::chunk_range(0, ck, &lo, &hi);
+	const uint32_t mark_blocks = (uint32_t)mkv::tuning().mark_blocks;
 	const dim3 grid(search_blocks + mark_blocks), block(256);
 	if (tm)
 		(void)hipEventRecord(tm->ev[2 * slot], s);
@@ -1749,7 +1793,7 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 		(void)hipEventRecord(tm->ev[2 * slot + 1], s);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
-		mkv::chunk_range(c, nchunks, &lo, &hi);
+		mkv::chunk_range(c, ck, &lo, &hi);
 		if (cuckoo) {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, lo, hi);
