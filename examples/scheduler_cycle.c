@@ -11,6 +11,7 @@
  * It is the build's own counterpart of the caller (the reference's .c files
  * are not copied) and doubles as the link test of lib/libgpuhash.a:
  *   gcc -Iinclude examples/scheduler_cycle.c -Llib -lgpuhash -lamdhip64 -lstdc++
+ * usage: scheduler_cycle [cycles] [worker streams, default 4]
  * Self-checking: every key inserted in cycle c is found in cycle c+1 with its
  * loc (property P1 of libgpuhash/test/insert_test.c:178-195), deleted keys are
  * gone (P2, :237-244).  Exit code 0 = all checks passed.
@@ -23,7 +24,7 @@
 
 #include "libgpuhash.h"
 
-#define WORKERS 4
+#define MAX_WORKERS 16		/* assert(config->cpu_worker_num <= 16), src/mega_scheduler.c:276 */
 #define MAX_SEARCH 32768	/* config->batch_max_search_job, src/mega.c:136 */
 #define MAX_INSERT 4096		/* per block, src/mega.c:143 */
 #define MAX_DELETE 4096		/* src/mega.c:144 */
@@ -61,8 +62,14 @@ typedef struct worker_s {
 int main(int argc, char **argv)
 {
 	int cycles = argc > 1 ? atoi(argv[1]) : 20;
+	/* Worker streams.  Like the reference, inserts of different workers are not ordered
+	 * against each other (SURVEY B-1): with several workers a lost update between two
+	 * concurrent inserts into one bucket is possible by design.  1 worker = fully defined. */
+	int WORKERS = argc > 2 ? atoi(argv[2]) : 4;
 	uint8_t *table;
-	worker_t w[WORKERS];
+	worker_t w[MAX_WORKERS];
+	if (WORKERS < 1 || WORKERS > MAX_WORKERS)
+		WORKERS = 4;
 	int i, b, c, id, errors = 0;
 
 	CUDA_SAFE_CALL(cudaMalloc((void **)&table, HT_SIZE));

