@@ -1365,6 +1365,7 @@ struct Workspace {
 	volatile uint32_t *host_flag = nullptr;
 	uint32_t *host_flag_dev = nullptr;
 	Chunking cycle_ck = {1, 65536};    // chunking chosen by the first half of an mkv_cycle insert
+	int barrier_score = 0;             // > 0: region barriers were seen within the last few calls
 };
 
 static std::mutex g_ws_mutex;
@@ -1486,7 +1487,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 // Passes of one call: data chunks, plus -- when there are several -- a trailing
 // flush pass over an empty range that only takes what the last data chunk carried.
 // Two-choice insert and delete never raise barriers: always one pass.
-static Chunking pick_chunking(const Workspace *w, long long hint, bool cuckoo)
+static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 {
 	Chunking k;
 	k.passes = 1;
@@ -1494,9 +1495,18 @@ static Chunking pick_chunking(const Workspace *w, long long hint, bool cuckoo)
 	if (!cuckoo || hint <= 0)
 		return k;
 	long long c = tuning().insert_chunk;
-	// the previous call on this workspace met region barriers: a batch that would be one
-	// chunk is cut in four, so a barrier's redo rides through grid-wide passes
-	if (hint <= c && w && w->host_flag && *w->host_flag && hint >= 8192) {
+	// the flag is the previous call's; keep the fine-chunk mode for 16 calls after the last
+	// barrier so an occasional barrier does not meet a huge single pass
+	if (w && w->host_flag) {
+		if (*w->host_flag)
+			w->barrier_score = 16;
+		else if (w->barrier_score > 0)
+			w->barrier_score--;
+	}
+	const bool barriers_lately = w && w->barrier_score > 0;
+	if (barriers_lately && hint <= c && hint >= 8192) {
+		// barriers lately and a batch that would be one chunk: cut it in four, so a
+		// barrier's redo rides through grid-wide passes instead of one work-group
 		c = ((hint + 3) / 4 + 15) & ~15ll;
 		if (c < 2048)
 			c = 2048;
