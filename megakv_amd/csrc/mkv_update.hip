@@ -1337,8 +1337,9 @@ __global__ void k_init_ctl(Ctl *ctl)
 }
 
 struct Chunking {
-	int passes;         // data chunks (+ flush pass when more than one)
+	int passes;         // data chunks + flush passes (when more than one data chunk)
 	uint32_t step;      // canonical indices per data chunk
+	int flush;          // trailing passes over an empty range (carried requests only)
 };
 
 // ---- per-stream workspace -----------------------------------------------------
@@ -1364,7 +1365,7 @@ struct Workspace {
 	// finely the next hinted batch is chunked, never the result.
 	volatile uint32_t *host_flag = nullptr;
 	uint32_t *host_flag_dev = nullptr;
-	Chunking cycle_ck = {1, 65536};    // chunking chosen by the first half of an mkv_cycle insert
+	Chunking cycle_ck = {1, 65536, 0};    // chunking chosen by the first half of an mkv_cycle insert
 	int barrier_score = 0;             // > 0: region barriers were seen within the last few calls
 };
 
@@ -1491,6 +1492,7 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 {
 	Chunking k;
 	k.passes = 1;
+	k.flush = 0;
 	k.step = (uint32_t)tuning().insert_chunk;
 	if (!cuckoo || hint <= 0)
 		return k;
@@ -1514,7 +1516,10 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	if (hint <= c)
 		return k;
 	const long long n = (hint + c - 1) / c;
-	k.passes = (n > 255 ? 255 : (int)n) + 1;
+	// one flush pass takes what the last data chunk carried; with barriers around, a second
+	// one keeps a barrier met in the first from ending up in the single-work-group tail
+	k.flush = barriers_lately ? 2 : 1;
+	k.passes = (n > 250 ? 250 : (int)n) + k.flush;
 	k.step = (uint32_t)c;
 	return k;
 }
@@ -1528,7 +1533,7 @@ static void chunk_range(int c, const Chunking &k, uint32_t *lo, uint32_t *hi)
 		*hi = kNone;
 		return;
 	}
-	const int data = nchunks - 1;                  // the last pass is the flush pass
+	const int data = nchunks - k.flush;            // the last passes are flush passes
 	if (c >= data) {
 		*lo = kNone - 15u;                          // empty range: carried requests only
 		*hi = kNone;
