@@ -126,6 +126,12 @@ int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *i
 int mkv_derive_requests(const void *keys, int64_t num_keys, int key_len, int64_t key_stride, int fold,
 		const loc_t *locs, void *out, int out_words, void *stream);
 
+/* ---- result consumption on the device ---------------------
+ * loc[i] = pairs[2i] ? pairs[2i] : pairs[2i+1]  (src/mega_send.c:408-414; 0 = miss,
+ * :464-466).  counters: device uint64[66], scratch + results: counters[64] = hits,
+ * counters[65] = misses after the call. */
+int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *loc, uint64_t *counters, void *stream);
+
 /* ---- request routing for the sharded (multi-GPU) index, SURVEY 8(e) -------
  * shard(e) = ((e.hash & hash_mask_agg) >> shard_shift); requests are grouped by
  * shard, stably, on the device.  `perm[j]` = original index of the j-th

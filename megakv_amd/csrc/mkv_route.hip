@@ -529,3 +529,67 @@ extern "C" int mkv_derive_requests(const void *keys, int64_t num_keys, int key_l
 			reinterpret_cast<const uint32_t *>(locs), reinterpret_cast<uint32_t *>(out), out_words);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
+
+// ===========================================================================
+// Result consumption on the device: what the reference's
+// sender does with the pair a search returns --
+//     loc = out[2i]; if (loc == 0) loc = out[2i+1];     (src/mega_send.c:408-414)
+//     loc == 0  =>  miss                                 (src/mega_send.c:464-466)
+// for a whole batch: one resolved location per request plus hit / miss totals
+// (the counters the reference aggregates per sender thread, src/mega_scheduler.c:97-116).
+// Turning a location into an item pointer and KEY_MATCH verification need the host
+// slab store and stay out of scope.
+// ===========================================================================
+namespace mkv {
+
+__global__ __launch_bounds__(256) void k_resolve(const uint2 *__restrict__ pairs, int64_t n,
+		uint32_t *__restrict__ loc, unsigned long long *__restrict__ counters)
+{
+	uint32_t hits = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+			i += (int64_t)gridDim.x * blockDim.x) {
+		const uint2 p = pairs[i];
+		const uint32_t l = p.x ? p.x : p.y;
+		loc[i] = l;
+		hits += l != 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1)
+		hits += __shfl_down(hits, off);
+	if ((threadIdx.x & 63u) == 0u && hits)
+		atomicAdd(&counters[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], (unsigned long long)hits);
+}
+
+// folds the 64 sharded partial sums: counters[64] = hits, counters[65] = misses
+__global__ void k_resolve_fold(unsigned long long *counters, long long n)
+{
+	unsigned long long v = counters[threadIdx.x];
+	for (int off = 32; off > 0; off >>= 1)
+		v += __shfl_down(v, off);
+	if (threadIdx.x == 0) {
+		counters[64] = v;
+		counters[65] = (unsigned long long)n - v;
+	}
+}
+
+}  // namespace mkv
+
+extern "C" int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *loc, uint64_t *counters,
+		void *stream)
+{
+	if (num_elem < 0 || !counters || (num_elem && (!pairs || !loc)))
+		return MKV_EINVAL;
+	hipStream_t s = (hipStream_t)stream;
+	if (hipMemsetAsync(counters, 0, 66 * sizeof(uint64_t), s) != hipSuccess)
+		return MKV_EHIP;
+	if (num_elem) {
+		int64_t blocks = (num_elem + 255) / 256;
+		if (blocks > 2048)
+			blocks = 2048;
+		hipLaunchKernelGGL(mkv::k_resolve, dim3((unsigned)blocks), dim3(256), 0, s,
+				reinterpret_cast<const uint2 *>(pairs), num_elem, loc,
+				reinterpret_cast<unsigned long long *>(counters));
+	}
+	hipLaunchKernelGGL(mkv::k_resolve_fold, dim3(1), dim3(64), 0, s,
+			reinterpret_cast<unsigned long long *>(counters), (long long)num_elem);
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}

@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
     "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
-    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -98,6 +98,8 @@ def load_library():
     L.mkv_slots_cycle.argtypes = [G, P, INT, I64, I64, P, P, P, ctypes.c_longlong, P, P, INT]
     L.mkv_derive_requests.restype = INT
     L.mkv_derive_requests.argtypes = [P, I64, INT, I64, INT, P, P, INT, P]
+    L.mkv_resolve_results.restype = INT
+    L.mkv_resolve_results.argtypes = [P, I64, P, P, P]
     L.mkv_unpack_results.restype = INT
     L.mkv_unpack_results.argtypes = [P, P, P, INT, I64, I64, P, P]
     L.mkv_unroute_results.restype = INT

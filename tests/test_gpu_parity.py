@@ -339,3 +339,64 @@ def test_large_preload_with_chunks_and_carries_matches_oracle():
     assert chains > 0 and undone > 0            # the interesting paths were really taken
     q = W.make_selem(np.arange(1, 1 << 20, dtype=np.uint32), W.KEYING_MIX)
     assert np.array_equal(host(idx.search(dev(q))), O.search(og, exp, q))
+
+
+def test_cycle_is_hipgraph_replayable():
+    """One mkv_cycle captured into a hipGraph and replayed on new requests placed in the
+    same buffers: round stamps and request counts live on the device, nothing is
+    allocated or synchronised inside the call, so every replay is a fresh, exact cycle."""
+    g = Geometry(mem_p=16)
+    og = ogeom(g)
+    rng = np.random.default_rng(77)
+    img = random_table(g, rng, 0.4, 1 << 24)
+    idx = HashIndex(g)
+    idx.load_table(img)
+    exp = img.copy()
+    n_q, n_s, cap = 6000, 3000, 3000
+    stream = torch.cuda.Stream()
+    idx.reserve(65536, stream)
+    q_buf = torch.zeros((n_q, 2), dtype=torch.int32, device="cuda")
+    out_buf = torch.zeros((n_q, 2), dtype=torch.int32, device="cuda")
+    set_buf = torch.zeros((8, cap, 3), dtype=torch.int32, device="cuda")      # 8 fixed block slices
+    ptrs = torch.tensor([set_buf[b].data_ptr() for b in range(8)], dtype=torch.int64).cuda()
+    cnts = torch.zeros(8, dtype=torch.int32, device="cuda")
+
+    def load(step_rng):
+        q = random_requests(g, step_rng, n_q, 1 << 24)[:, :2].copy()
+        e = random_requests(g, step_rng, n_s, 1 << 24, hot=0.1)
+        blocks = split_blocks(e, g, step_rng, "region")
+        q_buf.copy_(dev(q))
+        c = []
+        for b, blk in enumerate(blocks):
+            assert blk.shape[0] <= cap
+            if blk.shape[0]:
+                set_buf[b, :blk.shape[0]].copy_(dev(blk))
+            c.append(blk.shape[0])
+        cnts.copy_(torch.tensor(c, dtype=torch.int32))
+        return q, blocks
+
+    # warm-up call outside capture (workspaces exist), then capture one cycle
+    q, blocks = load(np.random.default_rng(1))
+    with torch.cuda.stream(stream):
+        idx.cycle(q_buf, out_buf, ptrs, cnts, 8, stream=stream, insert_hint=n_s)
+    stream.synchronize()
+    ref_out = O.search(og, exp, q)
+    O.insert(og, exp, blocks)
+    assert np.array_equal(host(out_buf), ref_out) and np.array_equal(idx.table_numpy(), exp)
+
+    graph = torch.cuda.CUDAGraph()
+    q, blocks = load(np.random.default_rng(2))
+    torch.cuda.synchronize()
+    with torch.cuda.graph(graph, stream=stream):
+        idx.cycle(q_buf, out_buf, ptrs, cnts, 8, stream=torch.cuda.current_stream(), insert_hint=n_s)
+    for rep in range(4):
+        if rep:
+            q, blocks = load(np.random.default_rng(10 + rep))
+        torch.cuda.synchronize()
+        graph.replay()
+        torch.cuda.synchronize()
+        ref_out = O.search(og, exp, q)
+        O.insert(og, exp, blocks)
+        assert np.array_equal(host(out_buf), ref_out), f"replay {rep}: search"
+        got = idx.table_numpy()
+        assert np.array_equal(got, exp), (rep, first_diff(got, exp))

@@ -132,3 +132,22 @@ def test_keys_to_table_entirely_on_the_device():
     assert L.mkv_derive_requests(_dev_ptr(dk), n, 16, 16, 1, ctypes.c_void_p(0), _dev_ptr(d_q), 2, _stream_ptr(None)) == 0
     out = idx.search(d_q)
     assert np.array_equal(host(out), O.search(ogeom(g), exp, np.ascontiguousarray(req[:, :2])))
+
+
+@pytest.mark.parametrize("n", [0, 1, 1000, 300007])
+def test_resolve_results_like_the_sender(n):
+    """src/mega_send.c:408-414: loc = out[2i], else out[2i+1]; 0 = miss."""
+    L = load_library()
+    rng = np.random.default_rng(n)
+    pairs = rng.integers(0, 2**32, size=(n, 2), dtype=np.uint64).astype(np.uint32)
+    pairs[rng.random(n) < 0.4, 0] = 0
+    pairs[rng.random(n) < 0.5, 1] = 0
+    exp = np.where(pairs[:, 0] != 0, pairs[:, 0], pairs[:, 1]) if n else np.zeros(0, np.uint32)
+    d_pairs = dev(pairs) if n else torch.zeros((1, 2), dtype=torch.int32, device="cuda")
+    loc = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
+    ctr = torch.zeros(66, dtype=torch.int64, device="cuda")
+    assert L.mkv_resolve_results(_dev_ptr(d_pairs), n, _dev_ptr(loc), _dev_ptr(ctr), _stream_ptr(None)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(host(loc)[:n], exp)
+    c = ctr.cpu().numpy()
+    assert int(c[64]) == int((exp != 0).sum()) and int(c[65]) == n - int((exp != 0).sum())
