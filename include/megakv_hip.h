@@ -113,6 +113,10 @@ typedef struct mkv_update_info_s {
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);
 /* cycle_insert != 0: the insert half of the last mkv_cycle on `stream` */
 int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
+/* diagnostics: microseconds the last call's tail kernels spent per phase (roll-back, gather,
+ * exact replay below a barrier, retag, in-group rounds, serial replay; two spare), summed
+ * over the call's passes.  Synchronises the stream. */
+int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[8]);
 
 /* ---- request preparation on the device ------------------
  * What the reference's receiver does per packet on the CPU, for a batch of

@@ -82,6 +82,14 @@ Tuning &tuning()
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
+		s = getenv("MKV_CALM_FACTOR");
+		v.calm_factor = s ? atoi(s) : 4;
+		if (v.calm_factor < 1) v.calm_factor = 1;
+		if (v.calm_factor > 64) v.calm_factor = 64;
+		s = getenv("MKV_TAIL_GROUPS");
+		v.tail_groups = s ? atoi(s) : 32;
+		if (v.tail_groups < 1) v.tail_groups = 1;
+		if (v.tail_groups > 64) v.tail_groups = 64;
 		s = getenv("MKV_INSERT_CHUNK");
 		v.insert_chunk = s ? atoll(s) : 65536;
 		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
@@ -139,6 +147,14 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 1024)
 			return MKV_EINVAL;
 		t.mark_blocks = (int)value;
+	} else if (!strcmp(name, "calm_factor")) {
+		if (value < 1 || value > 64)
+			return MKV_EINVAL;
+		t.calm_factor = (int)value;
+	} else if (!strcmp(name, "tail_groups")) {
+		if (value < 1 || value > 64)
+			return MKV_EINVAL;
+		t.tail_groups = (int)value;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

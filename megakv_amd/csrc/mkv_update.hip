@@ -112,6 +112,11 @@ struct Ctl {
 	uint32_t committed[2][kShards];
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
+	uint32_t sync[2];                // arrival counters of the tail launch's two grid-wide sync points
+	uint32_t glist_n;                // entries of the tail's global work list
+	uint32_t carry_next;             // lowest index the tail leaves pending (next pass's carry_lo)
+	uint32_t undone_acc;             // roll-backs done by the tail's helper work-groups
+	uint32_t tail_phase[8];          // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 };
 
 struct Req {
@@ -523,7 +528,13 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		bool live = idx < end && idx >= start;
 		uint32_t P = 0, A = 0;
 		if (live && idx < lo_idx) {
-			live = state[idx] == ST_PENDING;
+			// carried range: unfinished tags ride along (reset to PENDING); commits of the
+			// earlier pass are closed here, so that a later roll-back never takes them for
+			// commits of its own pass (it starts at the carry index, like this loop)
+			const uint8_t st = state[idx];
+			live = st == ST_PENDING || st == ST_LOSER || st == ST_TAIL || st == ST_CHAIN_OK;
+			if (live ? st != ST_PENDING : st != ST_DONE)
+				state[idx] = live ? ST_PENDING : ST_DONE;
 			if (live) {
 				const uint4 rc = reqc[idx];
 				P = rc.y & g.hash_mask;
@@ -854,6 +865,21 @@ __device__ __forceinline__ void wg_sync()
 	__syncthreads();
 }
 
+// All work-groups of the launch meet here.  They are few (Tuning::tail_groups) and stay resident
+// while they wait, so the others always get to run.  Release before, acquire after.
+__device__ __forceinline__ void grid_sync(uint32_t *counter, uint32_t nwg)
+{
+	wg_sync();                     // the group's stores have been issued and are visible to thread 0
+	if (threadIdx.x == 0) {
+		__threadfence();           // ... which releases them to the other groups (cumulative),
+		atomicAdd(counter, 1u);
+		while (ld_agent32(counter) < nwg)
+			__builtin_amdgcn_s_sleep(2);
+		__threadfence();           // acquires theirs, and hands them on through the barrier below
+	}
+	wg_sync();
+}
+
 // bitonic sort of n2 (power of two) keys in LDS, ascending
 __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 {
@@ -1054,11 +1080,16 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag)
 {
 	__shared__ uint32_t lkeys[kSortCap];
+	__shared__ uint8_t lreg[kSortCap];          // region of a gathered request (exact replay below a barrier)
 	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left;
-	const uint32_t t = threadIdx.x;
+	__shared__ uint32_t s_carry;
+	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+	unsigned long long tick = wall_clock64();
+	uint32_t phase_ticks[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+#define MKV_PHASE(k) do { const unsigned long long now_ = wall_clock64(); phase_ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
 	const uint32_t total_all = ctl->total;
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
 	const uint32_t carry_in = ctl->carry_lo;
@@ -1072,82 +1103,178 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		s_undone = 0;
 		s_par = 0;
 		s_serial = 0;
+		s_carry = kNone;
 	}
 	__syncthreads();
 	bool any_bar = false;
 	for (uint32_t k = 0; k < g.nregions; k++)
 		any_bar |= s_bar[k] != kNone;
+	const bool work_left = any_tail || (OP == OP_CUCKOO && any_bar);
+	// The scans over the request tags (roll-back, gather) are shared by all work-groups of
+	// the launch; everything after them is work-group 0's.  Nothing to scan: the helpers
+	// leave at once (the control block only changes in work-group 0's epilogue, to the
+	// values it has in that case anyway).
+	if (wg != 0 && !work_left)
+		return;
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint32_t gfirst = lo16 + (t * nwg + wg) * 16u;   // neighbouring 16-tag groups go to different work-groups
+	const uint32_t gstride = nwg * blockDim.x * 16u;
+	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+	uint4 *st4 = reinterpret_cast<uint4 *>(state);
 
-	// -- roll back optimistic commits at or beyond the barrier, newest round first
+	// -- roll back optimistic commits at or beyond the barrier, newest round first.  A
+	// thread owns the 16 tags it loads; the loads of a step are issued together.
 	if (OP == OP_CUCKOO && any_bar) {
+		uint32_t undone = 0;
 		for (int pass = 0; pass < 2; pass++) {
-			const uint8_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
-			const uint8_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
-			const uint4 *st4r = reinterpret_cast<const uint4 *>(state);
-			for (uint32_t base = (lo_idx & ~15u) + t * 16u; base < total && base >= (lo_idx & ~15u); base += blockDim.x * 16u) {
-				const uint4 v4 = st4r[base >> 4];
-				const uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
+			const uint32_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
+			const uint32_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
+			for (uint32_t base = gfirst; base < total && base >= lo16; base += gstride) {
+				const uint4 v4 = st4[base >> 4];
+				uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
+				uint32_t need = 0;
 #pragma unroll
 				for (int kk = 0; kk < 16; kk++) {
-				const uint8_t st = (uint8_t)((w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu);
-				const uint32_t idx = base + (uint32_t)kk;
-				if (idx < lo_idx || idx >= total || (st != tag && st != ctag))
-					continue;
-				const uint4 rc = reqc[idx];
-				const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
-				if (idx < s_bar[region])
-					continue;
-				const Undo u = undo[idx];
-				if (st == ctag) {
-					const ChainLog *L = &chain_logs[u.word0];
-					for (uint32_t i = L->n; i-- > 0;)
-						table[L->word[i]] = L->old[i];
-				} else {
-					if (u.word1 != kNoWord)
-						table[u.word1] = u.old1;
-					if (u.word0 != kNoWord)
-						table[u.word0] = u.old0;
+					const uint32_t st = (w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu;
+					const uint32_t idx = base + (uint32_t)kk;
+					if (idx >= lo_idx && idx < total && (st == tag || st == ctag))
+						need |= 1u << kk;
 				}
-				state[idx] = ST_TAIL;
-				atomicAdd(&s_undone, 1u);
+				if (!need)
+					continue;
+				// request hash (for the region) and undo record of every candidate, one batch
+				uint32_t hashes[16];
+				Undo us[16];
+#pragma unroll
+				for (int kk = 0; kk < 16; kk++) {
+					hashes[kk] = (need >> kk) & 1u ? reqw[(size_t)(base + (uint32_t)kk) * 4u + 1u] : 0u;
+					if ((need >> kk) & 1u)
+						us[kk] = undo[base + (uint32_t)kk];
 				}
+#pragma unroll
+				for (int kk = 0; kk < 16; kk++)
+					if (((need >> kk) & 1u) &&
+							base + (uint32_t)kk < s_bar[(hashes[kk] & g.hash_mask) >> g.region_shift])
+						need &= ~(1u << kk);
+				if (!need)
+					continue;
+#pragma unroll
+				for (int kk = 0; kk < 16; kk++) {
+					if (!((need >> kk) & 1u))
+						continue;
+					const uint32_t sh = (uint32_t)(kk & 3) * 8u;
+					const uint32_t st = (w4[kk >> 2] >> sh) & 0xffu;
+					if (st == ctag) {
+						// the whole log record in one batch of loads, then the stores, newest first
+						static_assert(sizeof(ChainLog) == 128, "ChainLog is read as 8 x 16 bytes");
+						const uint4 *lp = reinterpret_cast<const uint4 *>(&chain_logs[us[kk].word0]);
+						uint4 q[8];
+#pragma unroll
+						for (int i = 0; i < 8; i++)
+							q[i] = lp[i];
+						const uint32_t lw[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+								q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
+								q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w,
+								q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
+#pragma unroll
+						for (int i = kChainLogWords - 1; i >= 0; i--)
+							if ((uint32_t)i < lw[0])
+								table[lw[1 + i]] = lw[1 + kChainLogWords + i];
+					} else {
+						if (us[kk].word1 != kNoWord)
+							table[us[kk].word1] = us[kk].old1;
+						if (us[kk].word0 != kNoWord)
+							table[us[kk].word0] = us[kk].old0;
+					}
+					w4[kk >> 2] = (w4[kk >> 2] & ~(0xffu << sh)) | ((uint32_t)ST_TAIL << sh);
+					undone++;
+				}
+				st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 			}
-			wg_sync();
+			if (pass == 0)
+				grid_sync(&ctl->sync[0], nwg);   // every round-2 undo lands before any round-1 undo
 		}
+		if (undone)
+			atomicAdd(&s_undone, undone);
 	}
-	__shared__ uint32_t s_carry;
-	if (t == 0)
-		s_carry = kNone;
-	__syncthreads();
-	const bool work_left = any_tail || (OP == OP_CUCKOO && any_bar);
+	MKV_PHASE(0);
 	// A non-final chunk hands its unresolved requests to the next chunk's grid-wide
 	// pass instead of working them off in this one work-group -- unless there are too
 	// many to sort in LDS, in which case it behaves like the final chunk.
 	bool full_tail = last_chunk != 0;
 	if (work_left) {
-		// -- gather what is left (tags TAIL / LOSER / PENDING), 16 tags per load
-		const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
-		for (uint32_t base = (lo_idx & ~15u) + t * 16u; base < total && base >= (lo_idx & ~15u); base += blockDim.x * 16u) {
+		// -- gather what is left (tags TAIL / LOSER / PENDING / CHAIN_OK) into the global list,
+		// same tag ownership as the roll-back (a thread sees the tags it rewrote).  Of a
+		// non-final chunk only what must be resolved here is listed: pending requests up to
+		// their region's barrier index; the lowest index of the rest is the next carry.
+		uint32_t mine = kNone;
+		for (uint32_t base = gfirst; base < total && base >= lo16; base += gstride) {
 			const uint4 v = st4[base >> 4];
 			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+			uint32_t take = 0;
 #pragma unroll
 			for (int k = 0; k < 16; k++) {
 				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 				const uint32_t idx = base + (uint32_t)k;
 				if (idx >= lo_idx && idx < total &&
-						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK)) {
-					if (!last_chunk) {
-						// only what must be resolved here: pending requests up to their
-						// region's barrier index; the rest is carried
-						if (!(OP == OP_CUCKOO && any_bar))
-							continue;
-						const uint4 rc = reqc[idx];
-						if (idx > s_bar[(rc.y & g.hash_mask) >> g.region_shift])
-							continue;
-					}
-					glist[atomicAdd(&s_n, 1u)] = idx;
-				}
+						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
+					take |= 1u << k;
 			}
+			if (!take)
+				continue;
+			if (!last_chunk) {
+				uint32_t keep = 0;
+				if (OP == OP_CUCKOO && any_bar) {
+					uint32_t hashes[16];
+#pragma unroll
+					for (int k = 0; k < 16; k++)
+						hashes[k] = (take >> k) & 1u ? reqw[(size_t)(base + (uint32_t)k) * 4u + 1u] : 0u;
+#pragma unroll
+					for (int k = 0; k < 16; k++) {
+						const uint32_t bar = s_bar[(hashes[k] & g.hash_mask) >> g.region_shift];
+						if (((take >> k) & 1u) && bar != kNone && base + (uint32_t)k <= bar)
+							keep |= 1u << k;        // (a region without barrier carries all it has left)
+					}
+				}
+				const uint32_t rest = take & ~keep;
+				if (rest) {
+					const uint32_t idx = base + (uint32_t)__ffs((int)rest) - 1u;
+					if (idx < mine)
+						mine = idx;
+				}
+				take = keep;
+				if (!take)
+					continue;
+			}
+			uint32_t at = atomicAdd(&ctl->glist_n, (uint32_t)__popc(take));
+#pragma unroll
+			for (int k = 0; k < 16; k++)
+				if ((take >> k) & 1u)
+					glist[at++] = base + (uint32_t)k;
+		}
+		MKV_PHASE(6);
+		// one global atomic per work-group (same-address atomics are slow): wave, LDS, global
+		for (int off = 32; off > 0; off >>= 1) {
+			const uint32_t o = __shfl_down(mine, off);
+			mine = o < mine ? o : mine;
+		}
+		if ((t & 63u) == 0u && mine != kNone)
+			atomicMin(&s_carry, mine);
+		__syncthreads();
+		if (t == 0) {
+			if (s_carry != kNone)
+				atomicMin(&ctl->carry_next, s_carry);
+			s_carry = kNone;
+			if (wg != 0 && s_undone)
+				atomicAdd(&ctl->undone_acc, s_undone);
+		}
+		grid_sync(&ctl->sync[1], nwg);
+		if (wg != 0)
+			return;
+		MKV_PHASE(7);
+		if (t == 0) {
+			s_n = ctl->glist_n;
+			s_undone += ld_agent32(&ctl->undone_acc);
 		}
 		__syncthreads();
 		if (s_n > (uint32_t)kSortCap)
@@ -1159,8 +1286,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		if (t == 0)
 			s_n = 0;
 		__syncthreads();
-		const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
-		for (uint32_t base = (lo_idx & ~15u) + t * 16u; base < total && base >= (lo_idx & ~15u); base += blockDim.x * 16u) {
+		for (uint32_t base = lo16 + t * 16u; base < total && base >= lo16; base += blockDim.x * 16u) {
 			const uint4 v = st4[base >> 4];
 			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
 #pragma unroll
@@ -1174,6 +1300,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		}
 		__syncthreads();
 	}
+	MKV_PHASE(1);
 	if (work_left && !full_tail) {
 		const uint32_t m = s_n;
 		// The requests that raised a region's barrier must not be carried unresolved: next
@@ -1188,39 +1315,47 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				lkeys[i] = i < m ? glist[i] : kNone;
 			__syncthreads();
 			lds_sort(lkeys, n2);
-			if (t < g.nregions && s_bar[t] != kNone) {
-				const uint32_t bar = s_bar[t];
-				for (uint32_t i = 0; i < m; i++) {
-					const uint32_t idx = lkeys[i];
-					if (idx > bar)
-						break;
-					const uint4 rc = reqc[idx];
-					if (((rc.y & g.hash_mask) >> g.region_shift) != t)
-						continue;
-					apply_serial<OP>(table, g, req_of(rc));
-					state[idx] = ST_DONE;
-					atomicAdd(&s_serial, 1u);
+			// region of every gathered request, fetched by all threads at once (0xff: not
+			// replayed here); then one wave per region walks the sorted list with ballots and
+			// its first lane replays that region's requests in order
+			for (uint32_t i = t; i < m; i += blockDim.x) {
+				const uint32_t idx = lkeys[i];
+				const uint4 rc = reqc[idx];
+				const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
+				lreg[i] = (s_bar[region] != kNone && idx <= s_bar[region]) ? (uint8_t)region : (uint8_t)0xffu;
+			}
+			__syncthreads();
+			const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
+			for (uint32_t region = wave; region < g.nregions; region += nwaves) {
+				if (s_bar[region] == kNone)
+					continue;
+				uint32_t d = 0;
+				for (uint32_t base = 0; base < m; base += 64u) {
+					const uint32_t i = base + lane;
+					unsigned long long todo = __ballot(i < m && lreg[i] == (uint8_t)region);
+					while (todo) {
+						const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+						todo &= todo - 1ull;
+						if (lane == 0) {
+							const uint32_t idx = lkeys[base + j];
+							apply_serial<OP>(table, g, req_of(reqc[idx]));
+							state[idx] = ST_DONE;
+							d++;
+						}
+					}
 				}
+				if (lane == 0 && d)
+					atomicAdd(&s_serial, d);
 			}
 			wg_sync();
 		}
-		// finalise the tags of finished requests (a later roll-back must never see them)
-		// and find the lowest index that stays pending
-		uint32_t mine = kNone;
-		for (uint32_t idx = lo_idx + t; idx < total && idx >= lo_idx; idx += blockDim.x) {
-			const uint8_t st = state[idx];
-			if (st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2) {
-				state[idx] = ST_DONE;
-			} else if (st != ST_DONE) {
-				if (st != ST_PENDING)
-					state[idx] = ST_PENDING;
-				if (idx < mine)
-					mine = idx;
-			}
-		}
-		if (mine != kNone)
-			atomicMin(&s_carry, mine);
+		MKV_PHASE(2);
+		// Tags stay as they are: the mark pass of the next chunk closes the commits and resets
+		// the unfinished ones (it starts at the carry index; nothing below is scanned again).
+		if (t == 0)
+			s_carry = ld_agent32(&ctl->carry_next);
 		__syncthreads();
+		MKV_PHASE(3);
 	}
 	const uint32_t m = (work_left && full_tail) ? s_n : 0u;
 	if (m != 0) {
@@ -1239,6 +1374,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		wg_sync();
 		const uint32_t left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin,
 				&s_progress, &s_par, &s_left, max_rounds);
+		MKV_PHASE(4);
 		if (left != 0 && in_lds) {
 			// what is left: canonical order, one request at a time
 			lds_sort(lkeys, n2);
@@ -1269,6 +1405,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		}
 	}
 	__syncthreads();
+	MKV_PHASE(5);
 	if (t < 64) {
 		// statistics shards: one wave sums and clears them
 		uint32_t c1 = ctl->committed[0][t], c2 = ctl->committed[1][t];
@@ -1285,6 +1422,8 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	}
 	if (t == 0) {
 		// diagnostics of this call (summed over its chunks), then the control block of the next pass
+		for (int k = 0; k < 8; k++)
+			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + phase_ticks[k];
 		ctl->last.total = total_all;
 		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
 		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + s_serial;
@@ -1300,6 +1439,10 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->bar_chain = 0;
 		ctl->bar_class = 0;
 		ctl->carry_lo = s_carry;
+		ctl->sync[0] = ctl->sync[1] = 0;     // the helpers are past both sync points (or never came)
+		ctl->glist_n = 0;
+		ctl->carry_next = kNone;
+		ctl->undone_acc = 0;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
@@ -1331,6 +1474,10 @@ __global__ void k_init_ctl(Ctl *ctl)
 		ctl->carry_lo = kNone;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
+		ctl->sync[0] = ctl->sync[1] = 0;
+		ctl->glist_n = 0;
+		ctl->carry_next = kNone;
+		ctl->undone_acc = 0;
 	}
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
@@ -1506,6 +1653,10 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 			w->barrier_score--;
 	}
 	const bool barriers_lately = w && w->barrier_score > 0;
+	// no barrier for a while: chunks `calm_factor` times the size (fewer passes); the first
+	// barrier switches back (its own redo still rides the following passes)
+	if (!barriers_lately && tuning().calm_factor > 1)
+		c *= tuning().calm_factor;
 	if (barriers_lately && hint <= c && hint >= 8192) {
 		// barriers lately and a batch that would be one chunk: cut it in four, so a
 		// barrier's redo rides through grid-wide passes instead of one work-group
@@ -1581,7 +1732,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 			lo, hi);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0, lo, hi);
-	hipLaunchKernelGGL((k_tail<OP>), dim3(1), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
+	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
@@ -1910,5 +2061,30 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->chains = h.last.chains;
 	info->bar_chain = h.last.bar_chain;
 	info->bar_class = h.last.bar_class;
+	return MKV_OK;
+}
+
+// diagnostics: microseconds the last call's tail kernels spent per phase
+// (roll-back, gather, exact replay, retag, in-group rounds, serial), summed over its passes
+extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[8])
+{
+	int dev = 0;
+	if (!out_us || hipGetDevice(&dev) != hipSuccess)
+		return MKV_EINVAL;
+	mkv::Workspace *w = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+		auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^
+				(cycle_insert ? mkv::kCycleSalt : 0ull));
+		if (it == mkv::g_ws.end() || !it->second->ctl)
+			return MKV_EINVAL;
+		w = it->second;
+	}
+	mkv::Ctl h;
+	if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
+			hipMemcpy(&h, w->ctl, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+		return MKV_EHIP;
+	for (int k = 0; k < 8; k++)
+		out_us[k] = (float)h.tail_phase[k] * 0.01f;
 	return MKV_OK;
 }

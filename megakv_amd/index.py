@@ -217,6 +217,14 @@ class HashIndex:
                                                 ctypes.byref(info)), "mkv_last_update_info")
         return {k: int(getattr(info, k)) for k, _ in info._fields_}
 
+    def tail_phases_us(self, stream=None, cycle_insert=False):
+        """diagnostics: time of the last call's tail kernels per phase (roll-back, gather,
+        exact replay, retag, in-group rounds, serial), microseconds"""
+        out = (ctypes.c_float * 8)()
+        _check(self.lib.mkv_debug_tail_phases(_stream_ptr(stream), 1 if cycle_insert else 0, out),
+               "mkv_debug_tail_phases")
+        return [round(float(x), 1) for x in out]
+
     def table_numpy(self):
         """Table image as uint32 [nbuckets,16] on the host (sig[8] | loc[8])."""
         return self.table.cpu().numpy().view("uint32").reshape(-1, 16)

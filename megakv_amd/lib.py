@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
     "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
-    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -84,6 +84,8 @@ def load_library():
     L.mkv_last_update_info.argtypes = [P, ctypes.POINTER(MkvUpdateInfo)]
     L.mkv_last_update_info_ex.restype = INT
     L.mkv_last_update_info_ex.argtypes = [P, INT, ctypes.POINTER(MkvUpdateInfo)]
+    L.mkv_debug_tail_phases.restype = INT
+    L.mkv_debug_tail_phases.argtypes = [P, INT, ctypes.POINTER(ctypes.c_float)]
     L.mkv_route_requests.restype = INT
     L.mkv_route_requests.argtypes = [P, INT, I64, U32, U32, INT, P, P, P, P, I64, P]
     L.mkv_pack_slot_words.restype = I64
