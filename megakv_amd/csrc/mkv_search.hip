@@ -82,6 +82,9 @@ Tuning &tuning()
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
+		s = getenv("MKV_GRID_MIN");
+		v.grid_min = s ? atoi(s) : 2048;
+		if (v.grid_min < 0) v.grid_min = 0;
 		s = getenv("MKV_CALM_FACTOR");
 		v.calm_factor = s ? atoi(s) : 4;
 		if (v.calm_factor < 1) v.calm_factor = 1;
@@ -147,6 +150,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 1024)
 			return MKV_EINVAL;
 		t.mark_blocks = (int)value;
+	} else if (!strcmp(name, "grid_min")) {
+		if (value < 0 || value > (1ll << 30))
+			return MKV_EINVAL;
+		t.grid_min = (int)value;
 	} else if (!strcmp(name, "calm_factor")) {
 		if (value < 1 || value > 64)
 			return MKV_EINVAL;

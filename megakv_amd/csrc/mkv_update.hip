@@ -58,7 +58,10 @@ namespace mkv {
 constexpr int kMaxBlocks = 1024;    // insert blocks per call
 constexpr int kMaxRegions = 32;
 constexpr int kMaxTailRounds = 48;  // in-work-group rounds of the tail
-constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;
+constexpr uint32_t kMinRoundProgress = 24;   // in-work-group round: ~4 us against ~75 ns per replayed request / 8 regions
+constexpr uint32_t kMinGridProgress = 96;    // grid-wide round: ~15 us against ~200 ns per replayed request
+constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with a long list
+constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
 constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
 constexpr uint32_t kGridAll = 1024;
 constexpr uint32_t kGridList = 256;
@@ -78,7 +81,6 @@ constexpr int kShards = 64;         // statistics counters are spread over this 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
 // (request index in the owner tables, registrant count in the count table).
 constexpr int kIdxBits = 24;
-constexpr unsigned long long kIdxMask = (1ull << kIdxBits) - 1;
 constexpr unsigned long long kStampMax = (1ull << 40) - 1;
 constexpr int64_t kMaxReqCap = (1ll << kIdxBits) - 16;
 
@@ -116,12 +118,19 @@ struct Ctl {
 	uint32_t glist_n;                // entries of the tail's global work list
 	uint32_t carry_next;             // lowest index the tail leaves pending (next pass's carry_lo)
 	uint32_t undone_acc;             // roll-backs done by the tail's helper work-groups
+	uint32_t g_sync;                 // arrivals at the sync points of the tail's grid-wide rounds (monotone)
+	uint32_t g_rbar[2][kMaxRegions]; // grid-wide rounds: round barrier / lowest pending index per region,
+	uint32_t g_rmin[2][kMaxRegions]; //   two sets used alternately (the idle one is reset meanwhile)
+	uint32_t g_progress[2], g_left[2];
+	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t tail_phase[8];          // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 };
 
 struct Req {
 	uint32_t sig, hash, loc;
 };
+
+__device__ __forceinline__ void reset_tail_scratch(Ctl *ctl);
 
 struct ReqSrc {
 	const uint32_t *const *blk_input;   // insert: device array of per-block arrays
@@ -406,9 +415,26 @@ __device__ __forceinline__ void bump(unsigned long long *cnt, uint32_t b, unsign
 	atomicAdd(&cnt[b], 1ull);
 }
 
+// Count entries: stamp | flag "a registrant has this bucket as its ALTERNATE (or only)
+// bucket" | registrant count.  Only such a registrant can ever evict from the bucket
+// (a chain starts at the alternate bucket; the buckets it goes on to are unregistered).
+constexpr unsigned long long kAltFlag = 1ull << (kIdxBits - 1);
+
+__device__ __forceinline__ void bump_alt(unsigned long long *cnt, uint32_t b, unsigned long long stamp)
+{
+	atomicMax(&cnt[b], stamp << kIdxBits);
+	atomicAdd(&cnt[b], 1ull);
+	atomicOr(&cnt[b], kAltFlag);
+}
+
 __device__ __forceinline__ uint32_t cnt_of(unsigned long long v, unsigned long long stamp)
 {
-	return (v >> kIdxBits) == stamp ? (uint32_t)(v & kIdxMask) : 0u;
+	return (v >> kIdxBits) == stamp ? (uint32_t)(v & (kAltFlag - 1ull)) : 0u;
+}
+
+__device__ __forceinline__ bool alt_of(unsigned long long v, unsigned long long stamp)
+{
+	return (v >> kIdxBits) == stamp && (v & kAltFlag) != 0ull;
 }
 
 // owner key of request idx in the round stamped `stamp`: newer rounds compare lower
@@ -702,6 +728,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 {
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
+	if (ROUND == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+		reset_tail_scratch(ctl);
 	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
 	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
@@ -773,7 +801,11 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 							// hard: P and A full without duplicate -> eviction chain
 							atomicMin(&ctl->first_hard, idx);
 							uint32_t log_slot = 0;
-							chained = try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot);
+							// Round 1 only: round 2 classifies the requests still pending by what it
+							// reads in their buckets (a duplicate, free slots), and an eviction running
+							// beside that would pull a duplicate from under it.
+							chained = ROUND == 1 &&
+									try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot);
 							done = chained;
 							hard = !chained;
 							u.word0 = log_slot;
@@ -880,6 +912,40 @@ __device__ __forceinline__ void grid_sync(uint32_t *counter, uint32_t nwg)
 	wg_sync();
 }
 
+// The tail launch's scratch in the control block.  Reset by the kernel BEFORE it in the
+// stream (round 1) -- never by the tail itself: a helper group may still be polling a
+// counter when work-group 0 is already through.
+__device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
+{
+	ctl->sync[0] = ctl->sync[1] = 0;
+	ctl->g_sync = 0;
+	ctl->glist_n = 0;
+	ctl->carry_next = kNone;
+	ctl->undone_acc = 0;
+	ctl->g_progress[0] = ctl->g_progress[1] = 0;
+	ctl->g_left[0] = ctl->g_left[1] = 0;
+	ctl->tail_rounds_used = 0;
+	for (int k = 0; k < kMaxRegions; k++) {
+		ctl->g_rbar[0][k] = ctl->g_rbar[1][k] = kNone;
+		ctl->g_rmin[0][k] = ctl->g_rmin[1][k] = kNone;
+	}
+}
+
+// like grid_sync, on a counter that only grows: the k-th meeting waits for k * nwg arrivals
+__device__ __forceinline__ void grid_sync_nth(uint32_t *counter, uint32_t nwg, uint32_t *nth)
+{
+	const uint32_t target = ++*nth * nwg;
+	wg_sync();
+	if (threadIdx.x == 0) {
+		__threadfence();
+		atomicAdd(counter, 1u);
+		while (ld_agent32(counter) < target)
+			__builtin_amdgcn_s_sleep(2);
+		__threadfence();
+	}
+	wg_sync();
+}
+
 // bitonic sort of n2 (power of two) keys in LDS, ascending
 __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 {
@@ -899,6 +965,140 @@ __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 			__syncthreads();
 		}
 	}
+}
+
+// Replay of the sorted requests lkeys[0..n) one at a time per closed region, regions side
+// by side (one wave each): the region of every request is fetched by all threads at once,
+// then a region's wave walks the list with ballots and its first lane replays.  With
+// below_bar set, only requests up to their region's barrier index are replayed.
+template <Op OP>
+__device__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
+		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const uint32_t *s_bar, bool below_bar,
+		uint32_t *s_count)
+{
+	const uint32_t t = threadIdx.x;
+	for (uint32_t i = t; i < n; i += blockDim.x) {
+		const uint32_t idx = lkeys[i];
+		const uint4 rc = reqc[idx];
+		const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
+		const bool take = !below_bar || (s_bar[region] != kNone && idx <= s_bar[region]);
+		lreg[i] = take ? (uint8_t)region : (uint8_t)0xffu;
+	}
+	__syncthreads();
+	const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
+	for (uint32_t region = wave; region < g.nregions; region += nwaves) {
+		if (below_bar && s_bar[region] == kNone)
+			continue;
+		uint32_t d = 0;
+		for (uint32_t base = 0; base < n; base += 64u) {
+			const uint32_t i = base + lane;
+			unsigned long long todo = __ballot(i < n && lreg[i] == (uint8_t)region);
+			while (todo) {
+				const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+				todo &= todo - 1ull;
+				if (lane == 0) {
+					const uint32_t idx = lkeys[base + j];
+					apply_serial<OP>(table, g, req_of(reqc[idx]));
+					state[idx] = ST_DONE;
+					d++;
+				}
+			}
+		}
+		if (lane == 0 && d)
+			atomicAdd(s_count, d);
+	}
+	wg_sync();
+	return *s_count;
+}
+
+// The same for a list too long for LDS (final pass, one work-group): the pending
+// requests of [lo_idx, total) are first compacted IN INDEX ORDER into the global list
+// (each thread takes a contiguous run of tags: count, scan, write), then every region's
+// wave walks that list 64 entries at a time -- all lanes fetch their entry's hash and
+// touch its buckets (so the replaying lane finds them in L2), lane 0 replays its region's.
+template <Op OP>
+__device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
+		uint32_t *glist, uint32_t *scratch1024, uint32_t lo_idx, uint32_t total, uint32_t *s_count)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint32_t span = total > lo16 ? total - lo16 : 0u;
+	const uint32_t per = (((span + blockDim.x - 1u) / blockDim.x) + 15u) & ~15u;
+	const uint32_t first = lo16 + t * per;
+	const uint32_t last = first + per < total ? first + per : total;
+	const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+	uint32_t c = 0;
+	for (uint32_t base = first; base < last && base >= lo16; base += 16u) {
+		const uint4 v = st4[base >> 4];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+			const uint32_t idx = base + (uint32_t)k;
+			c += (idx >= lo_idx && idx < last &&
+					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK)) ? 1u : 0u;
+		}
+	}
+	scratch1024[t] = c;
+	__syncthreads();
+	for (uint32_t off = 1; off < blockDim.x; off <<= 1) {      // inclusive scan
+		const uint32_t add = t >= off ? scratch1024[t - off] : 0u;
+		__syncthreads();
+		scratch1024[t] += add;
+		__syncthreads();
+	}
+	const uint32_t n = scratch1024[blockDim.x - 1u];
+	uint32_t at = scratch1024[t] - c;
+	for (uint32_t base = first; base < last && base >= lo16; base += 16u) {
+		const uint4 v = st4[base >> 4];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+			const uint32_t idx = base + (uint32_t)k;
+			if (idx >= lo_idx && idx < last &&
+					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
+				glist[at++] = idx;
+		}
+	}
+	wg_sync();
+	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+	const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
+	for (uint32_t region = wave; region < g.nregions; region += nwaves) {
+		uint32_t d = 0;
+		for (uint32_t base = 0; base < n; base += 64u) {
+			const uint32_t i = base + lane;
+			uint32_t idx = 0;
+			bool mine = false;
+			if (i < n) {
+				idx = glist[i];
+				const uint32_t sig = reqw[(size_t)idx * 4u], hash = reqw[(size_t)idx * 4u + 1u];
+				const uint32_t P = hash & g.hash_mask;
+				mine = (P >> g.region_shift) == region;
+				if (mine) {
+					// touch both buckets: the replay below then finds them in L2
+					const uint32_t A = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
+					const uint32_t a = ld_agent32(table + sig_word(P, 0u)), b = ld_agent32(table + sig_word(A, 0u));
+					asm volatile("" ::"v"(a), "v"(b));
+				}
+			}
+			unsigned long long todo = __ballot(mine);
+			while (todo) {
+				const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
+				todo &= todo - 1ull;
+				const uint32_t ridx = __shfl(idx, (int)j);
+				if (lane == 0) {
+					apply_serial<OP>(table, g, req_of(reqc[ridx]));
+					state[ridx] = ST_DONE;
+					d++;
+				}
+			}
+		}
+		if (lane == 0 && d)
+			atomicAdd(s_count, d);
+	}
+	wg_sync();
+	return n;
 }
 
 // Tail rounds, decide phase: read-only walk of the eviction chain of a hard request
@@ -950,12 +1150,13 @@ template <Op OP>
 __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
-		int max_rounds)
+		int max_rounds, uint32_t *rounds_used)
 {
 	const uint32_t t = threadIdx.x;
 	const unsigned long long stamp0 = ctl->stamp_base + 2;
-	uint32_t left = m;
+	uint32_t left = m, recent = 0;
 	for (int round = 0; round < max_rounds && left != 0; round++) {
+		*rounds_used = (uint32_t)round + 1u;
 		const unsigned long long stamp = stamp0 + (unsigned)round;
 		if (t < kMaxRegions) {
 			s_rbar[t] = kNone;
@@ -976,9 +1177,12 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			reserve(owner, P, A, owner_key(stamp, idx));
 			if (OP == OP_CUCKOO) {
-				bump(cnt, P, stamp);
-				if (A != P)
-					bump(cnt, A, stamp);
+				if (A != P) {
+					bump(cnt, P, stamp);
+					bump_alt(cnt, A, stamp);
+				} else {
+					bump_alt(cnt, P, stamp);
+				}
 				atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
 		}
@@ -997,17 +1201,23 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					continue;
 				uint4 lo, hi;
 				load_sig_row<true>(table, P, lo, hi);
-				if (eq_mask(lo, hi, rc.x))
+				const unsigned long long key = owner_key(stamp, idx);
+				const bool ownP = ld_agent(&owner[P]) == key;
+				const bool ownA = A == P || ld_agent(&owner[A]) == key;
+				const unsigned long long cP = ld_agent(&cnt[P]);
+				// A duplicate only counts while nothing can evict it before this request's turn:
+				// the request owns the bucket (every other registrant comes later), or no
+				// registrant has the bucket as its alternate.
+				if (eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
 					continue;
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
-				const unsigned long long key = owner_key(stamp, idx);
-				const bool clean = ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key);
+				const bool clean = ownP && ownA;
 				if (clean && room)
 					continue;
-				uint32_t others = cnt_of(ld_agent(&cnt[P]), stamp) - 1u;
+				uint32_t others = cnt_of(cP, stamp) - 1u;
 				if (A != P) {
 					load_sig_row<true>(table, A, lo, hi);
-					if (eq_mask(lo, hi, rc.x))
+					if (eq_mask(lo, hi, rc.x) && ownA)
 						continue;
 					room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
 					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
@@ -1067,9 +1277,188 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		if (t == 0)
 			*s_par += progress;
 		__syncthreads();
-		if (progress == 0)
+		// a round that resolves less than the one-at-a-time replay would in its time
+		// (duplicates of one key, chains in a row) is not worth another
+		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
+		if (progress == 0 || (round >= 3 && recent < kMinRoundProgress))
 			break;
 	}
+	return left;
+}
+
+// The same rounds run by every work-group of the tail launch over the global list
+// keys[0..m): for a final pass that is left with more than one work-group can chew.
+// Round state lives in the control block; same-address atomics are folded per
+// work-group in LDS first.  Three grid-wide meetings per round.  All groups read the
+// same totals after the third and so leave the loop together.
+template <Op OP>
+__device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
+		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
+		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, int max_rounds,
+		uint32_t *rounds_used, uint32_t *par_total)
+{
+	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
+	const unsigned long long stamp0 = ctl->stamp_base + 2;
+	uint32_t left = m, nth = 0, used = 0, par = 0, recent = 0;
+	for (int round = 0; round < max_rounds && left != 0; round++) {
+		const unsigned long long stamp = stamp0 + (unsigned)round;
+		const uint32_t set = (uint32_t)round & 1u;
+		used = (uint32_t)round + 1u;
+		if (t < kMaxRegions) {
+			s_rbar[t] = kNone;
+			s_rmin[t] = kNone;
+		}
+		if (t == 0) {
+			*s_progress = 0;
+			*s_left = 0;
+		}
+		__syncthreads();
+		// register
+		for (uint32_t i = first; i < m; i += span) {
+			const uint32_t idx = keys[i];
+			if (idx == kNone)
+				continue;
+			const uint4 rc = reqc[idx];
+			const uint32_t P = rc.y & g.hash_mask;
+			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+			reserve(owner, P, A, owner_key(stamp, idx));
+			if (OP == OP_CUCKOO) {
+				if (A != P) {
+					bump(cnt, P, stamp);
+					bump_alt(cnt, A, stamp);
+				} else {
+					bump_alt(cnt, P, stamp);
+				}
+				atomicMin(&s_rmin[P >> g.region_shift], idx);
+			}
+		}
+		__syncthreads();
+		if (OP == OP_CUCKOO && t < g.nregions && s_rmin[t] != kNone)
+			atomicMin(&ctl->g_rmin[set][t], s_rmin[t]);
+		grid_sync_nth(&ctl->g_sync, nwg, &nth);
+		// decide: the lowest index per region that is hard or might turn hard
+		if (OP == OP_CUCKOO) {
+			for (uint32_t i = first; i < m; i += span) {
+				const uint32_t idx = keys[i];
+				if (idx == kNone)
+					continue;
+				const uint4 rc = reqc[idx];
+				const uint32_t P = rc.y & g.hash_mask;
+				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+				const uint32_t region = P >> g.region_shift;
+				if (idx >= s_rbar[region])
+					continue;
+				uint4 lo, hi;
+				load_sig_row<true>(table, P, lo, hi);
+				const unsigned long long key = owner_key(stamp, idx);
+				const bool ownP = ld_agent(&owner[P]) == key;
+				const bool ownA = A == P || ld_agent(&owner[A]) == key;
+				const unsigned long long cP = ld_agent(&cnt[P]);
+				// A duplicate only counts while nothing can evict it before this request's turn:
+				// the request owns the bucket (every other registrant comes later), or no
+				// registrant has the bucket as its alternate.
+				if (eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
+					continue;
+				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
+				const bool clean = ownP && ownA;
+				if (clean && room)
+					continue;
+				uint32_t others = cnt_of(cP, stamp) - 1u;
+				if (A != P) {
+					load_sig_row<true>(table, A, lo, hi);
+					if (eq_mask(lo, hi, rc.x) && ownA)
+						continue;
+					room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
+					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
+				}
+				bool bad = clean ? room == 0u : room < 1u + others;
+				if (bad && clean) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp)) {
+						state[idx] = ST_CHAIN_OK;
+						bad = false;
+					}
+				}
+				if (bad)
+					atomicMin(&s_rbar[region], idx);
+			}
+			__syncthreads();
+			if (t < g.nregions && s_rbar[t] != kNone)
+				atomicMin(&ctl->g_rbar[set][t], s_rbar[t]);
+			grid_sync_nth(&ctl->g_sync, nwg, &nth);
+			if (t < kMaxRegions) {
+				s_rbar[t] = t < g.nregions ? ld_agent32(&ctl->g_rbar[set][t]) : kNone;
+				s_rmin[t] = t < g.nregions ? ld_agent32(&ctl->g_rmin[set][t]) : kNone;
+			}
+			__syncthreads();
+		}
+		// the idle set is made ready for the next round
+		if (wg == 0 && t < kMaxRegions) {
+			ctl->g_rbar[set ^ 1u][t] = kNone;
+			ctl->g_rmin[set ^ 1u][t] = kNone;
+			if (t == 0)
+				ctl->g_progress[set ^ 1u] = ctl->g_left[set ^ 1u] = 0;
+		}
+		// commit
+		uint32_t my_done = 0, my_left = 0;
+		for (uint32_t i = first; i < m; i += span) {
+			const uint32_t idx = keys[i];
+			if (idx == kNone)
+				continue;
+			const Req r = req_of(reqc[idx]);
+			const uint32_t P = r.hash & g.hash_mask;
+			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+			const unsigned long long key = owner_key(stamp, idx);
+			bool done = false;
+			if (OP == OP_CUCKOO) {
+				const uint32_t region = P >> g.region_shift;
+				const uint32_t bar = s_rbar[region];
+				if (idx == bar && idx == s_rmin[region]) {
+					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
+					done = true;
+				} else if (idx >= bar) {
+					if (state[idx] == ST_CHAIN_OK)
+						state[idx] = ST_TAIL;
+					my_left++;
+					continue;
+				} else if (state[idx] == ST_CHAIN_OK) {
+					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
+					done = true;
+				}
+			}
+			if (!done && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
+				done = apply_static<OP, true, false>(table, r, P, A, nullptr);
+			if (done) {
+				state[idx] = ST_DONE;
+				keys[i] = kNone;
+				my_done++;
+			} else {
+				my_left++;
+			}
+		}
+		if (my_done)
+			atomicAdd(s_progress, my_done);
+		if (my_left)
+			atomicAdd(s_left, my_left);
+		__syncthreads();
+		if (t == 0) {
+			if (*s_progress)
+				atomicAdd(&ctl->g_progress[set], *s_progress);
+			if (*s_left)
+				atomicAdd(&ctl->g_left[set], *s_left);
+		}
+		grid_sync_nth(&ctl->g_sync, nwg, &nth);
+		const uint32_t progress = ld_agent32(&ctl->g_progress[set]);
+		left = ld_agent32(&ctl->g_left[set]);
+		par += progress;
+		// rounds go on while they resolve more than the one-at-a-time replay would in their
+		// time, judged over the last few (the round after a chain is often a thin one)
+		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
+		if (progress == 0 || (round >= 3 && recent < kMinGridProgress))
+			break;
+	}
+	*rounds_used = used;
+	*par_total = par;
 	return left;
 }
 
@@ -1077,7 +1466,7 @@ template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
 		const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds, uint32_t lo_idx,
-		uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag)
+		uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min)
 {
 	__shared__ uint32_t lkeys[kSortCap];
 	__shared__ uint8_t lreg[kSortCap];          // region of a gathered request (exact replay below a barrier)
@@ -1202,6 +1591,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	// pass instead of working them off in this one work-group -- unless there are too
 	// many to sort in LDS, in which case it behaves like the final chunk.
 	bool full_tail = last_chunk != 0;
+	bool grid_mode = false;
 	if (work_left) {
 		// -- gather what is left (tags TAIL / LOSER / PENDING / CHAIN_OK) into the global list,
 		// same tag ownership as the roll-back (a thread sees the tags it rewrote).  Of a
@@ -1269,11 +1659,14 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				atomicAdd(&ctl->undone_acc, s_undone);
 		}
 		grid_sync(&ctl->sync[1], nwg);
-		if (wg != 0)
+		// a final pass left with a long list keeps every work-group for its rounds
+		const uint32_t m_all = ld_agent32(&ctl->glist_n);
+		grid_mode = last_chunk != 0 && max_rounds > 0 && nwg > 1u && m_all > grid_min;
+		if (wg != 0 && !grid_mode)
 			return;
 		MKV_PHASE(7);
 		if (t == 0) {
-			s_n = ctl->glist_n;
+			s_n = m_all;
 			s_undone += ld_agent32(&ctl->undone_acc);
 		}
 		__syncthreads();
@@ -1315,39 +1708,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				lkeys[i] = i < m ? glist[i] : kNone;
 			__syncthreads();
 			lds_sort(lkeys, n2);
-			// region of every gathered request, fetched by all threads at once (0xff: not
-			// replayed here); then one wave per region walks the sorted list with ballots and
-			// its first lane replays that region's requests in order
-			for (uint32_t i = t; i < m; i += blockDim.x) {
-				const uint32_t idx = lkeys[i];
-				const uint4 rc = reqc[idx];
-				const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
-				lreg[i] = (s_bar[region] != kNone && idx <= s_bar[region]) ? (uint8_t)region : (uint8_t)0xffu;
-			}
-			__syncthreads();
-			const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
-			for (uint32_t region = wave; region < g.nregions; region += nwaves) {
-				if (s_bar[region] == kNone)
-					continue;
-				uint32_t d = 0;
-				for (uint32_t base = 0; base < m; base += 64u) {
-					const uint32_t i = base + lane;
-					unsigned long long todo = __ballot(i < m && lreg[i] == (uint8_t)region);
-					while (todo) {
-						const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
-						todo &= todo - 1ull;
-						if (lane == 0) {
-							const uint32_t idx = lkeys[base + j];
-							apply_serial<OP>(table, g, req_of(reqc[idx]));
-							state[idx] = ST_DONE;
-							d++;
-						}
-					}
-				}
-				if (lane == 0 && d)
-					atomicAdd(&s_serial, d);
-			}
-			wg_sync();
+			replay_regions<OP>(table, g, reqc, state, lkeys, lreg, m, s_bar, true, &s_serial);
 		}
 		MKV_PHASE(2);
 		// Tags stay as they are: the mark pass of the next chunk closes the commits and resets
@@ -1358,7 +1719,45 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		MKV_PHASE(3);
 	}
 	const uint32_t m = (work_left && full_tail) ? s_n : 0u;
-	if (m != 0) {
+	uint32_t rounds_used = 0;
+	if (m != 0 && grid_mode) {
+		uint32_t par = 0;
+		const uint32_t left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin,
+				&s_progress, &s_left, kGridRoundsMax, &rounds_used, &par);
+		if (wg != 0)
+			return;
+		if (t == 0)
+			s_par += par;
+		MKV_PHASE(4);
+		if (left != 0) {
+			// what the rounds left: into LDS if it fits, then canonical order, one at a time
+			if (t == 0)
+				s_left = 0;
+			__syncthreads();
+			for (uint32_t i = t; i < m; i += blockDim.x) {
+				const uint32_t k = glist[i];
+				if (k != kNone) {
+					const uint32_t at = atomicAdd(&s_left, 1u);
+					if (at < (uint32_t)kSortCap)
+						lkeys[at] = k;
+				}
+			}
+			__syncthreads();
+			const uint32_t nleft = s_left;
+			if (nleft <= (uint32_t)kSortCap) {
+				uint32_t n2 = 1;
+				while (n2 < nleft)
+					n2 <<= 1;
+				for (uint32_t i = nleft + t; i < n2; i += blockDim.x)
+					lkeys[i] = kNone;
+				__syncthreads();
+				lds_sort(lkeys, n2);
+				replay_regions<OP>(table, g, reqc, state, lkeys, lreg, nleft, s_bar, false, &s_serial);
+			} else {
+				replay_pending_scan<OP>(table, g, reqc, state, glist, lkeys, lo_idx, total, &s_serial);
+			}
+		}
+	} else if (m != 0) {
 		// work list: LDS when it fits, else the global list it was gathered into
 		const bool in_lds = m <= (uint32_t)kSortCap;
 		uint32_t *keys = in_lds ? lkeys : glist;
@@ -1373,35 +1772,15 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		}
 		wg_sync();
 		const uint32_t left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin,
-				&s_progress, &s_par, &s_left, max_rounds);
+				&s_progress, &s_par, &s_left, max_rounds, &rounds_used);
 		MKV_PHASE(4);
 		if (left != 0 && in_lds) {
 			// what is left: canonical order, one request at a time
 			lds_sort(lkeys, n2);
-			if (t == 0) {
-				uint32_t d = 0;
-				for (uint32_t i = 0; i < m; i++) {
-					const uint32_t idx = lkeys[i];
-					if (idx == kNone)
-						break;
-					apply_serial<OP>(table, g, req_of(reqc[idx]));
-					state[idx] = ST_DONE;
-					d++;
-				}
-				s_serial = d;
-			}
-		} else if (left != 0 && t == 0) {
-			// too much left for LDS: walk the request states in canonical order
-			uint32_t d = 0;
-			for (uint32_t idx = lo_idx; idx < total; idx++) {
-				const uint8_t st = state[idx];
-				if (st != ST_TAIL && st != ST_LOSER && st != ST_PENDING && st != ST_CHAIN_OK)
-					continue;
-				apply_serial<OP>(table, g, req_of(reqc[idx]));
-				state[idx] = ST_DONE;
-				d++;
-			}
-			s_serial = d;
+			replay_regions<OP>(table, g, reqc, state, lkeys, lreg, left, s_bar, false, &s_serial);
+		} else if (left != 0) {
+			// too much left for LDS
+			replay_pending_scan<OP>(table, g, reqc, state, glist, lkeys, lo_idx, total, &s_serial);
 		}
 	}
 	__syncthreads();
@@ -1439,19 +1818,16 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->bar_chain = 0;
 		ctl->bar_class = 0;
 		ctl->carry_lo = s_carry;
-		ctl->sync[0] = ctl->sync[1] = 0;     // the helpers are past both sync points (or never came)
-		ctl->glist_n = 0;
-		ctl->carry_next = kNone;
-		ctl->undone_acc = 0;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
 		ctl->any_tail = 0;
 		ctl->first_hard = kNone;
 		ctl->total = 0;
-		const unsigned long long st = ctl->next_stamp;
+		// stamps: rounds 1 and 2, what the tail's rounds took, one spare
+		const unsigned long long st = ctl->stamp_base + 3ull + rounds_used;
 		ctl->stamp_base = st;
-		ctl->next_stamp = st + kStampsPerCall;
+		ctl->next_stamp = st;
 	}
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
@@ -1474,10 +1850,7 @@ __global__ void k_init_ctl(Ctl *ctl)
 		ctl->carry_lo = kNone;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
-		ctl->sync[0] = ctl->sync[1] = 0;
-		ctl->glist_n = 0;
-		ctl->carry_next = kNone;
-		ctl->undone_acc = 0;
+		reset_tail_scratch(ctl);
 	}
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
@@ -1734,7 +2107,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0, lo, hi);
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev);
+			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

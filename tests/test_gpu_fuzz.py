@@ -1,6 +1,6 @@
 """Seeded fuzzing of insert / delete / search parity over random geometries
 (MEM_P, IBLOCK_P, MAX_CUCKOO_NUM, scheme), fills, key distributions, block
-splits and tuning (chunk size, tail rounds).  Every case: GPU result == oracle,
+splits and tuning (chunk size, tail rounds, tail work-groups, grid-wide tail rounds).  Every case: GPU result == oracle,
 bit for bit, for a sequence of operations on one table."""
 import numpy as np
 import pytest
@@ -20,10 +20,26 @@ def _defaults():
     L = load_library()
     L.mkv_set_tuning(b"tail_rounds", 48)
     L.mkv_set_tuning(b"insert_chunk", 65536)
+    L.mkv_set_tuning(b"tail_groups", 32)
+    L.mkv_set_tuning(b"grid_min", 2048)
+    L.mkv_set_tuning(b"calm_factor", 4)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
 def test_fuzz_sequence(seed):
+    _run(seed, {})
+
+
+@pytest.mark.parametrize("seed", [194, 429])
+@pytest.mark.parametrize("groups,grid_min", [(1, 1 << 30), (8, 0)])
+def test_duplicate_evicted_before_its_turn(seed, groups, grid_min):
+    """Few distinct signatures: a pending request's duplicate can be evicted by an earlier
+    request's chain, after which it needs a chain of its own.  Found by these two seeds once
+    the tail ran many rounds (a duplicate used to count as 'cannot turn hard')."""
+    _run(seed, {b"tail_rounds": 48, b"tail_groups": groups, b"grid_min": grid_min})
+
+
+def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
     L = load_library()
     mem_p = int(rng.integers(10, 19))
@@ -34,6 +50,16 @@ def test_fuzz_sequence(seed):
     og = ogeom(g)
     L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 1, 3, 48])))
     L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 2048, 8192, 65536])))
+    rng2 = np.random.default_rng(5000 + seed)        # tail shape: work-groups, grid-wide rounds, calm-mode chunks
+    L.mkv_set_tuning(b"tail_groups", int(rng2.choice([1, 2, 5, 32])))
+    L.mkv_set_tuning(b"grid_min", int(rng2.choice([0, 0, 64, 2048])))
+    L.mkv_set_tuning(b"calm_factor", int(rng2.choice([1, 4])))
+    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk"):   # bisecting aid
+        v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
+        if v is not None:
+            L.mkv_set_tuning(name, int(v))
+    for name, v in forced.items():
+        L.mkv_set_tuning(name, int(v))
     fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
     sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
     exp = random_table(g, rng, fill, sig_space)

@@ -1,0 +1,83 @@
+#!/usr/bin/env python3
+"""Replay one seed of tests/test_gpu_fuzz.py and, at the first table mismatch, print the
+requests that touch the first differing bucket (canonical index, sig, P, A, loc).
+usage: fuzz_debug.py <seed> [tuning=value ...]"""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from megakv_amd import Geometry, HashIndex  # noqa: E402
+from megakv_amd.lib import load_library  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+from tests.gpu_util import dev, ogeom, random_table, random_requests, split_blocks  # noqa: E402
+
+
+def main():
+    seed = int(sys.argv[1])
+    over = dict(a.split("=") for a in sys.argv[2:])
+    rng = np.random.default_rng(1000 + seed)
+    L = load_library()
+    mem_p = int(rng.integers(10, 19))
+    iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
+    scheme = int(rng.integers(0, 2))
+    max_cuckoo = int(rng.choice([0, 1, 2, 5, 6]))
+    g = Geometry(mem_p=mem_p, scheme=scheme, iblock_p=iblock_p, max_cuckoo=max_cuckoo)
+    og = ogeom(g)
+    L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 1, 3, 48])))
+    L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 2048, 8192, 65536])))
+    for k, v in over.items():
+        L.mkv_set_tuning(k.encode(), int(v))
+    fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
+    sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
+    exp = random_table(g, rng, fill, sig_space)
+    idx = HashIndex(g)
+    idx.load_table(exp)
+    nslots = g.nbuckets * 8
+    print(dict(mem_p=mem_p, iblock_p=iblock_p, scheme=scheme, max_cuckoo=max_cuckoo, fill=fill, sig_space=sig_space))
+    for step in range(3):
+        op = rng.choice(["insert", "insert", "delete", "search"])
+        n = int(rng.integers(1, max(2, min(40000, nslots))))
+        e = random_requests(g, rng, n, sig_space, hot=float(rng.choice([0.0, 0.1, 0.6])),
+                            zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])))
+        if op == "insert":
+            how = str(rng.choice(["single", "region", "app", "uneven"]))
+            if iblock_p == 0 and how == "app":
+                how = "single"
+            blocks = split_blocks(e, g, rng, how)
+            before = exp.copy()
+            O.insert(og, exp, blocks)
+            idx.insert([dev(b.reshape(-1, 3)) for b in blocks], hint=None if rng.random() < 0.7 else 0)
+            got = idx.table_numpy()
+            print("step", step, op, n, how, idx.last_update_info())
+            if not np.array_equal(got, exp):
+                bad = np.argwhere((got != exp).any(axis=1))[:, 0]
+                print("differing buckets", bad[:10], "of", len(bad))
+                allreq = np.concatenate([b.reshape(-1, 3) for b in blocks if len(b)])
+                hm, bm = g.hash_mask, g.block_hash_mask
+                P = allreq[:, 1] & hm
+                A = (((allreq[:, 1] ^ allreq[:, 0]) & bm) | (allreq[:, 1] & ~np.uint32(bm))) & hm
+                for B in bad[:3]:
+                    print("bucket", B, "\n before", before[B], "\n oracle", exp[B], "\n gpu   ", got[B])
+                    for i in np.argwhere((P == B) | (A == B))[:, 0]:
+                        print("   idx", i, "sig", allreq[i, 0], "P", P[i], "A", A[i], "loc", allreq[i, 2],
+                              "| P row before", before[P[i]][:8], "| A row before", before[A[i]][:8])
+                return
+        elif op == "delete":
+            occ = np.argwhere(exp[:, :8] != 0)
+            if len(occ):
+                pick = occ[rng.integers(0, len(occ), size=n // 2)]
+                e[: len(pick), 0] = exp[pick[:, 0], pick[:, 1]]
+                e[: len(pick), 1] = pick[:, 0]
+                e[: len(pick), 2] = exp[pick[:, 0], 8 + pick[:, 1]]
+            O.delete(og, exp, e)
+            idx.delete(dev(e))
+        else:
+            rng.integers(0, 2)
+    print("no mismatch")
+
+
+if __name__ == "__main__":
+    main()
