@@ -85,6 +85,8 @@ struct Tuning {
 	long long req_cap;   // default request capacity of an update workspace
 	long long insert_chunk; // requests per canonical-index chunk when the caller hints the batch size
 	int mark_blocks;        // work-groups of the insert mark pass inside the fused search launch
+	int barrier_sticky;     // calls for which a call that met a barrier counts as "barriers lately"
+	int barrier_split;      // barriers lately: cut a hinted single-chunk batch into this many chunks (1: off)
 	int grid_min;           // a final tail list longer than this runs its rounds on all work-groups of the launch
 	int calm_factor;        // chunk size multiplier while no region barrier was met lately
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)

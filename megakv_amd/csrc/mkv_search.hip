@@ -82,6 +82,13 @@ Tuning &tuning()
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
+		s = getenv("MKV_BARRIER_STICKY");
+		v.barrier_sticky = s ? atoi(s) : 16;
+		if (v.barrier_sticky < 0) v.barrier_sticky = 0;
+		s = getenv("MKV_BARRIER_SPLIT");
+		v.barrier_split = s ? atoi(s) : 1;
+		if (v.barrier_split < 1) v.barrier_split = 1;
+		if (v.barrier_split > 64) v.barrier_split = 64;
 		s = getenv("MKV_GRID_MIN");
 		v.grid_min = s ? atoi(s) : 2048;
 		if (v.grid_min < 0) v.grid_min = 0;
@@ -150,6 +157,14 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 1024)
 			return MKV_EINVAL;
 		t.mark_blocks = (int)value;
+	} else if (!strcmp(name, "barrier_sticky")) {
+		if (value < 0 || value > 1000000)
+			return MKV_EINVAL;
+		t.barrier_sticky = (int)value;
+	} else if (!strcmp(name, "barrier_split")) {
+		if (value < 1 || value > 64)
+			return MKV_EINVAL;
+		t.barrier_split = (int)value;
 	} else if (!strcmp(name, "grid_min")) {
 		if (value < 0 || value > (1ll << 30))
 			return MKV_EINVAL;

@@ -2021,7 +2021,7 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	// barrier so an occasional barrier does not meet a huge single pass
 	if (w && w->host_flag) {
 		if (*w->host_flag)
-			w->barrier_score = 16;
+			w->barrier_score = tuning().barrier_sticky;
 		else if (w->barrier_score > 0)
 			w->barrier_score--;
 	}
@@ -2030,10 +2030,12 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	// barrier switches back (its own redo still rides the following passes)
 	if (!barriers_lately && tuning().calm_factor > 1)
 		c *= tuning().calm_factor;
-	if (barriers_lately && hint <= c && hint >= 8192) {
-		// barriers lately and a batch that would be one chunk: cut it in four, so a
-		// barrier's redo rides through grid-wide passes instead of one work-group
-		c = ((hint + 3) / 4 + 15) & ~15ll;
+	const int split = tuning().barrier_split;
+	if (barriers_lately && split > 1 && hint <= c && hint >= 8192) {
+		// barriers lately and a batch that would be one chunk: cut it up, so a barrier's redo
+		// rides through grid-wide passes.  Off by default since the tail scans and runs long
+		// lists on all its work-groups: the extra passes cost more than they save.
+		c = ((hint + split - 1) / split + 15) & ~15ll;
 		if (c < 2048)
 			c = 2048;
 	}
