@@ -67,6 +67,8 @@ def parse():
     ap.add_argument("--comm", default="nccl", choices=["nccl", "staged"],
                     help="staged: gloo collectives through host memory, all ranks on cuda:0 -- only to exercise "
                          "the multi-rank flow of this script on a one-GPU box")
+    ap.add_argument("--no-native", action="store_true",
+                    help="sharded path: drive the step from Python/torch.distributed instead of the C engine")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1: run the steps strictly one after the other (no exchange/compute overlap)")
     ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
@@ -162,6 +164,23 @@ def main():
         from megakv_amd.sharded import ShardedIndex, NcclComm, StagedComm
         engine = ShardedIndex(args.mem_p, world, rank, scheme, device, stream_gen.n_get, stream_gen.n_set,
                               StagedComm(dist) if args.comm == "staged" else NcclComm(dist))
+    native = False
+    if sharded and args.comm == "nccl" and not args.no_native and not args.no_pipeline:
+        # the step as ONE library call per run (own RCCL communicator); all ranks agree, or all
+        # fall back to the Python-driven step over torch.distributed
+        ok = 1
+        try:
+            engine.enable_native(dist)
+        except Exception as ex:                                   # noqa: BLE001
+            print(f"[rank {rank}] native sharded engine unavailable, falling back: {ex}", file=sys.stderr)
+            ok = 0
+        flag = torch.tensor([ok], dtype=torch.int32, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        if int(flag.item()) == 0:
+            if engine.native is not None:
+                engine.native.close()
+            engine.native = None
+        native = engine.native is not None
     dbg_skip = args.debug_skip
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
@@ -191,12 +210,32 @@ def main():
         load_library().mkv_set_tuning(b"debug_skip", dbg_skip)
     with torch.cuda.stream(run_stream):
         engine.reserve(run_stream)
+        # a collective that never completes would hang the box: give the warm-up a deadline
+        import threading
+        watchdog = threading.Timer(300.0, lambda: (print("bench.py: warm-up did not finish in 300 s, giving up",
+                                                         file=sys.stderr, flush=True), os._exit(19)))
+        watchdog.daemon = True
+        watchdog.start()
         if sharded and not args.no_pipeline:
             engine.run_pipelined(batches[:args.warmup])       # warms both lanes and their workspaces
         else:
             for b in batches[:args.warmup]:
                 engine.step(b, run_stream, None)
         run_stream.synchronize()
+        watchdog.cancel()
+        if native and args.warmup and args.lf <= 0.5:
+            # every GET key was pre-loaded or set earlier: anything but a full hit rate means the
+            # exchange went wrong -> all ranks drop to the Python-driven step and warm up again
+            good = torch.tensor([1 if engine.hit_rate(batches[args.warmup - 1]) > 0.999 else 0],
+                                dtype=torch.int32, device=device)
+            dist.all_reduce(good, op=dist.ReduceOp.MIN)
+            if int(good.item()) == 0:
+                print(f"[rank {rank}] native sharded engine gave wrong results, falling back", file=sys.stderr)
+                engine.native.close()
+                engine.native = None
+                native = False
+                engine.run_pipelined(batches[:args.warmup])
+                run_stream.synchronize()
         hit_rate = engine.hit_rate(batches[args.warmup - 1]) if args.warmup else None
         barrier()
         t_start = time.perf_counter()
@@ -263,7 +302,8 @@ def main():
                        "sharding": "single table" if not sharded else
                        f"{world} shards by top bucket bits, RCCL all-to-all, "
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
-                       "launch": "hipGraph" if args.graph else "eager"},
+                       "launch": "hipGraph" if args.graph else
+                       ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
             "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},

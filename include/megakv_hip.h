@@ -178,6 +178,30 @@ int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots,
 int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf, int nshards,
 		int64_t cap_get, int64_t cap_set, loc_t *out, void *stream);
 
+/* ---- one rank of the sharded index, driven from C (libmegakv_hip.so only; RCCL is
+ * opened with dlopen(rccl_path), default "librccl.so") -------------------------------
+ * geom: the LOCAL table's geometry, i.e. IBLOCK_P already reduced by log2(world);
+ * n_get / n_set: the largest batch this rank hands in; cap_get / cap_set: slot capacity
+ * per peer.  Create on every rank, make the id on rank 0 (mkv_shard_unique_id), hand the
+ * 128 bytes to all ranks, connect (collective).  mkv_shard_run enqueues a whole run of
+ * batches, two in flight (exchanges of one overlap the local kernels of the other; local
+ * phases in batch order): gets[i] / sets[i] / outs[i] are device pointers (host arrays
+ * of them), outs[i] receives n_get[i] x 2 loc_t in request order.  Nothing synchronises;
+ * the lanes start after what is queued on `stream`, which waits for them at the end.
+ * timer: mkv_timer_* handle bracketing the local search launch of every timer_every-th
+ * batch (slot i / timer_every), or NULL. */
+typedef struct mkv_shard mkv_shard_t;
+int mkv_shard_create(mkv_shard_t **out, const mkv_geom_t *geom, int world, int rank, bucket_t *table,
+		int64_t n_get, int64_t n_set, int64_t cap_get, int64_t cap_set, const char *rccl_path);
+int mkv_shard_unique_id(mkv_shard_t *e, void *id128);
+int mkv_shard_connect(mkv_shard_t *e, const void *id128);
+int mkv_shard_run(mkv_shard_t *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
+		int timer_every);
+int mkv_shard_overflowed(mkv_shard_t *e, int *flag);   /* synchronises the device */
+const char *mkv_shard_error(const mkv_shard_t *e);
+void mkv_shard_destroy(mkv_shard_t *e);
+
 /* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
  * "search_nt" (non-temporal table loads), "tail_rounds" (0..48 reservation
  * rounds inside the tail work-group), "insert_chunk" (requests per chunk of a hinted insert), "req_cap" (default requests per update

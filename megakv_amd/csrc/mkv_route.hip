@@ -347,6 +347,172 @@ __global__ __launch_bounds__(256) void k_pack_scatter(const uint32_t *__restrict
 	}
 }
 
+// ---- one-launch pack ----------------------------------------------------------
+// GET tiles place their requests with atomics (order inside a slot is free: `perm`
+// brings every result home); SET tiles keep batch order -- per-tile counts, one meeting
+// of the SET tiles, prefix over the earlier tiles, ranked scatter.  The last work-group
+// to finish writes the slot headers and clears the control words for the next call.
+constexpr int kPackTile = 2048;      // requests per work-group
+constexpr int kPackBins = 16;        // shards the one-launch pack handles
+constexpr int kPackCtlWords = 32;    // cursors[16], arrive, done, pad; per-tile counts follow
+
+__device__ __forceinline__ uint32_t pack_ld(const uint32_t *p)
+{
+	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__ gets, int64_t n_get,
+		const uint32_t *__restrict__ sets, int64_t n_set, uint32_t hash_mask, uint32_t shift, int nshards,
+		uint32_t *__restrict__ sendbuf, int64_t slot_words, uint32_t cap_get, uint32_t cap_set,
+		int32_t *__restrict__ perm_get, uint32_t *ctl, int *overflow, uint32_t set_tiles, uint32_t get_tiles)
+{
+	__shared__ uint32_t s_cnt[kPackBins], s_base[kPackBins], s_wcnt[4][kPackBins];
+	__shared__ uint32_t s_last;
+	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
+	const uint32_t G = (uint32_t)nshards;
+	uint32_t *cursors = ctl, *arrive = ctl + kPackBins, *done = ctl + kPackBins + 1;
+	uint32_t *tile_counts = ctl + kPackCtlWords;
+	if (blockIdx.x < set_tiles) {
+		const uint32_t tile = blockIdx.x;
+		const int64_t lo = (int64_t)tile * kPackTile + (int64_t)wave * (kPackTile / 4);
+		uint32_t w0[8], w1[8], w2[8], sh[8];
+#pragma unroll
+		for (int it = 0; it < 8; it++) {
+			const int64_t e = lo + it * 64 + lane;
+			const bool live = e < n_set;
+			w0[it] = live ? sets[e * 3] : 0u;
+			w1[it] = live ? sets[e * 3 + 1] : 0u;
+			w2[it] = live ? sets[e * 3 + 2] : 0u;
+			sh[it] = live ? (w1[it] & hash_mask) >> shift : 0xffffffffu;
+		}
+		uint32_t mine = 0;                     // lane k: this wave's count for shard k
+#pragma unroll
+		for (int it = 0; it < 8; it++)
+			for (uint32_t k = 0; k < G; k++) {
+				const uint32_t c = (uint32_t)__popcll(__ballot(sh[it] == k));
+				if (lane == k)
+					mine += c;
+			}
+		if (lane < kPackBins)
+			s_wcnt[wave][lane] = lane < G ? mine : 0u;
+		if (t < kPackBins)
+			s_base[t] = 0;
+		__syncthreads();
+		// counts and the meeting go through agent-scope atomics only: no cache write-back
+		// (an agent-scope fence flushes the L2 the GET tiles are filling -- 100 us of them)
+		if (t < G)
+			__hip_atomic_store(&tile_counts[(size_t)tile * kPackBins + t],
+					s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t], __ATOMIC_RELAXED,
+					__HIP_MEMORY_SCOPE_AGENT);
+		__syncthreads();                       // (waits for those stores)
+		if (t == 0) {
+			atomicAdd(arrive, 1u);
+			while (pack_ld(arrive) < set_tiles)
+				__builtin_amdgcn_s_sleep(1);
+		}
+		__syncthreads();
+		for (uint32_t j = t; j < tile * G; j += blockDim.x)
+			atomicAdd(&s_base[j % G], pack_ld(&tile_counts[(size_t)(j / G) * kPackBins + j % G]));
+		__syncthreads();
+		uint32_t cursor = 0;
+		if (lane < G) {
+			cursor = s_base[lane];
+			for (uint32_t w = 0; w < wave; w++)
+				cursor += s_wcnt[w][lane];
+		}
+		const int64_t region = kHdrWords + (int64_t)cap_get * 2;
+#pragma unroll
+		for (int it = 0; it < 8; it++) {
+			uint32_t dst = 0;
+			for (uint32_t k = 0; k < G; k++) {
+				const unsigned long long m = __ballot(sh[it] == k);
+				const uint32_t base = __shfl(cursor, (int)k);
+				if (sh[it] == k)
+					dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+				if (lane == k)
+					cursor += (uint32_t)__popcll(m);
+			}
+			if (sh[it] != 0xffffffffu && dst < cap_set) {
+				uint32_t *p = sendbuf + (int64_t)sh[it] * slot_words + region + (int64_t)dst * 3;
+				p[0] = w0[it];
+				p[1] = w1[it];
+				p[2] = w2[it];
+			}
+		}
+		if (tile == set_tiles - 1u && t < G) {
+			const uint32_t total = s_base[t] + s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t];
+			uint32_t *hdr = sendbuf + (int64_t)t * slot_words;
+			if (total > cap_set) {
+				*overflow = 1;
+				hdr[1] = 0;                    // nothing of this kind is sent for this slot
+			} else {
+				hdr[1] = total;
+			}
+		}
+	} else if (blockIdx.x < set_tiles + get_tiles) {
+		const uint32_t tile = blockIdx.x - set_tiles;
+		if (t < kPackBins)
+			s_cnt[t] = 0;
+		__syncthreads();
+		const uint2 *g2 = reinterpret_cast<const uint2 *>(gets);
+		uint2 rq[8];
+		uint32_t sh[8], pos[8];
+#pragma unroll
+		for (int it = 0; it < 8; it++) {
+			const int64_t e = (int64_t)tile * kPackTile + it * 256 + t;
+			const bool live = e < n_get;
+			rq[it] = live ? g2[e] : make_uint2(0u, 0u);
+			sh[it] = live ? (rq[it].y & hash_mask) >> shift : 0xffffffffu;
+		}
+#pragma unroll
+		for (int it = 0; it < 8; it++)
+			pos[it] = sh[it] != 0xffffffffu ? atomicAdd(&s_cnt[sh[it]], 1u) : 0u;
+		__syncthreads();
+		if (t < G && s_cnt[t])
+			s_base[t] = atomicAdd(&cursors[t], s_cnt[t]);
+		__syncthreads();
+#pragma unroll
+		for (int it = 0; it < 8; it++) {
+			if (sh[it] == 0xffffffffu)
+				continue;
+			const uint32_t dst = s_base[sh[it]] + pos[it];
+			if (dst < cap_get) {
+				uint2 *p = reinterpret_cast<uint2 *>(sendbuf + (int64_t)sh[it] * slot_words + kHdrWords) + dst;
+				*p = rq[it];
+				perm_get[(int64_t)sh[it] * cap_get + dst] = (int32_t)((int64_t)tile * kPackTile + it * 256 + t);
+			}
+		}
+	}
+	__syncthreads();
+	if (t == 0)
+		s_last = atomicAdd(done, 1u) == gridDim.x - 1u ? 1u : 0u;
+	__syncthreads();
+	if (s_last) {
+		// (the cursors are atomics; the slots' contents need not be visible here)
+		if (t < G) {
+			const uint32_t c = pack_ld(&cursors[t]);
+			uint32_t *hdr = sendbuf + (int64_t)t * slot_words;
+			if (c > cap_get) {
+				*overflow = 1;
+				hdr[0] = 0;
+			} else {
+				hdr[0] = c;
+			}
+			if (set_tiles == 0u)
+				hdr[1] = 0;
+			hdr[2] = 0;
+			hdr[3] = 0;
+		}
+		__syncthreads();
+		if (t < kPackBins)
+			cursors[t] = 0;
+		if (t == 0) {
+			*arrive = 0;
+			*done = 0;
+		}
+	}
+}
+
 // segmented search over received slots; block (seg, chunk).  Block 0 also
 // publishes the per-source insert counts for the insert that follows.
 __global__ __launch_bounds__(256) void k_search_slots(const uint32_t *__restrict__ recvbuf,
@@ -386,7 +552,10 @@ extern "C" int64_t mkv_pack_scratch_bytes(int64_t n_get, int64_t n_set, int nsha
 {
 	const int64_t nw_get = (n_get + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
 	const int64_t nw_set = (n_set + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
-	return (nw_get + nw_set) * nshards * 4 + 64;
+	const int64_t three_pass = (nw_get + nw_set) * nshards * 4 + 64;
+	const int64_t set_tiles = (n_set + mkv::kPackTile - 1) / mkv::kPackTile;
+	const int64_t one_pass = (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4 + 64;
+	return three_pass > one_pass ? three_pass : one_pass;
 }
 
 extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
@@ -409,6 +578,19 @@ extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem
 	const int64_t waves = nw_get + nw_set;
 	const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gets);
 	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sets);
+	const int64_t set_tiles = (n_set + mkv::kPackTile - 1) / mkv::kPackTile;
+	const int64_t get_tiles = (n_get + mkv::kPackTile - 1) / mkv::kPackTile;
+	if (nshards <= mkv::kPackBins && set_tiles <= 1024 && !mkv::tuning().pack_three_pass &&
+			scratch_bytes >= (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4) {
+		// one launch; its control words (the head of `scratch`) are zero between calls: zeroed
+		// by the caller once, cleared again by the kernel's last work-group
+		const int64_t blocks = set_tiles + get_tiles ? set_tiles + get_tiles : 1;
+		hipLaunchKernelGGL(mkv::k_pack_fused, dim3((unsigned)blocks), dim3(256), 0, s, g32, n_get, s32, n_set,
+				hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set,
+				perm_get, reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles,
+				(uint32_t)get_tiles);
+		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+	}
 	if (waves > 0) {
 		dim3 grid((unsigned)((waves + 3) / 4)), block(256);
 		hipLaunchKernelGGL(mkv::k_pack_count, grid, block, 0, s, g32, n_get, s32, n_set, hash_mask_agg,

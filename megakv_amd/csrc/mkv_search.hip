@@ -82,6 +82,8 @@ Tuning &tuning()
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
+		s = getenv("MKV_PACK_THREE_PASS");
+		v.pack_three_pass = s ? atoi(s) != 0 : 0;
 		s = getenv("MKV_BARRIER_STICKY");
 		v.barrier_sticky = s ? atoi(s) : 16;
 		if (v.barrier_sticky < 0) v.barrier_sticky = 0;
@@ -157,6 +159,8 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 1024)
 			return MKV_EINVAL;
 		t.mark_blocks = (int)value;
+	} else if (!strcmp(name, "pack_three_pass")) {
+		t.pack_three_pass = value != 0;
 	} else if (!strcmp(name, "barrier_sticky")) {
 		if (value < 0 || value > 1000000)
 			return MKV_EINVAL;

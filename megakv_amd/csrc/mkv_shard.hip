@@ -1,0 +1,295 @@
+// megakv_amd -- sharded index, one rank's engine in C.
+//
+// A step of the sharded index is  pack -> all-to-all -> search+insert of the
+// received slots -> all-to-all of the results -> unpack  (mkv_route.hip,
+// mkv_update.hip).  This file drives that sequence for a whole run of batches from
+// one C call: two lanes (buffers + stream each) keep two batches in flight, so the
+// exchanges of one batch overlap the local kernels of its neighbour; local phases
+// are chained by events, i.e. results are those of the batches run one after the
+// other.  Collectives go straight to RCCL (ncclAllToAll on the lane's stream) over
+// a communicator of its own; the library is opened with dlopen -- the C ABI of the
+// hot path (libgpuhash.a) does not depend on it.  Collectives are issued in the same
+// order on every rank: fwd(0), fwd(1), back(0), fwd(2), back(1), ...
+//
+// New design: the reference is single-GPU.
+#include <dlfcn.h>
+#include <hip/hip_runtime.h>
+#include <rccl/rccl.h>
+
+#include <cstdio>
+#include <cstring>
+#include <new>
+
+#include "megakv_hip.h"
+
+namespace {
+
+struct Rccl {
+	void *lib = nullptr;
+	ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+	ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+	ncclResult_t (*AllToAll)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
+	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+struct Lane {
+	hipStream_t stream = nullptr;
+	uint32_t *sendbuf = nullptr, *recvbuf = nullptr;
+	loc_t *out_slots = nullptr, *back_slots = nullptr;
+	int32_t *perm = nullptr;
+	uint32_t *scratch = nullptr;
+	ielem_t **set_ptrs = nullptr;
+	hipEvent_t ev_local[2] = {nullptr, nullptr};   // alternated so a pending wait keeps its event
+	hipEvent_t ev_done = nullptr;
+};
+
+}  // namespace
+
+struct mkv_shard {
+	mkv_geom_t geom;
+	int world = 1, rank = 0;
+	bucket_t *table = nullptr;
+	int64_t n_get = 0, n_set = 0, cap_get = 0, cap_set = 0, slot_words = 0, scratch_bytes = 0;
+	uint32_t agg_mask = 0, shift = 0;
+	int *overflow = nullptr;
+	Lane lane[2];
+	hipEvent_t ev_start = nullptr;
+	Rccl api;
+	ncclComm_t comm = nullptr;
+	char err[256] = {0};
+};
+
+static int fail(mkv_shard *e, int code, const char *what, const char *detail)
+{
+	snprintf(e->err, sizeof(e->err), "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+	return code;
+}
+
+#define SH_HIP(e, expr)                                                       \
+	do {                                                                      \
+		hipError_t r_ = (expr);                                               \
+		if (r_ != hipSuccess)                                                 \
+			return fail(e, MKV_EHIP, #expr, hipGetErrorString(r_));           \
+	} while (0)
+
+#define SH_NCCL(e, expr)                                                                          \
+	do {                                                                                          \
+		ncclResult_t r_ = (expr);                                                                 \
+		if (r_ != ncclSuccess)                                                                    \
+			return fail(e, MKV_EHIP, #expr, e->api.GetErrorString ? e->api.GetErrorString(r_) : nullptr); \
+	} while (0)
+
+extern "C" const char *mkv_shard_error(const mkv_shard *e)
+{
+	return e ? e->err : "no engine";
+}
+
+extern "C" void mkv_shard_destroy(mkv_shard *e)
+{
+	if (!e)
+		return;
+	(void)hipDeviceSynchronize();
+	if (e->comm && e->api.CommDestroy)
+		(void)e->api.CommDestroy(e->comm);
+	for (Lane &l : e->lane) {
+		if (l.sendbuf) (void)hipFree(l.sendbuf);
+		if (l.recvbuf) (void)hipFree(l.recvbuf);
+		if (l.out_slots) (void)hipFree(l.out_slots);
+		if (l.back_slots) (void)hipFree(l.back_slots);
+		if (l.perm) (void)hipFree(l.perm);
+		if (l.scratch) (void)hipFree(l.scratch);
+		if (l.set_ptrs) (void)hipFree(l.set_ptrs);
+		for (hipEvent_t ev : l.ev_local)
+			if (ev) (void)hipEventDestroy(ev);
+		if (l.ev_done) (void)hipEventDestroy(l.ev_done);
+		if (l.stream) (void)hipStreamDestroy(l.stream);
+	}
+	if (e->overflow) (void)hipFree(e->overflow);
+	if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+	// the RCCL handle stays open: the host framework usually holds the same library
+	delete e;
+}
+
+// geom: the LOCAL table's geometry (region split = aggregate IBLOCK_P - log2 world);
+// n_get / n_set: the largest batch a rank hands in; cap_*: slot capacities per peer.
+extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int world, int rank, bucket_t *table,
+		int64_t n_get, int64_t n_set, int64_t cap_get, int64_t cap_set, const char *rccl_path)
+{
+	if (!out || !geom || !table || world < 1 || world > 64 || (world & (world - 1)) || rank < 0 || rank >= world ||
+			n_get < 0 || n_set < 0 || cap_get < 0 || cap_set < 0)
+		return MKV_EINVAL;
+	mkv_shard *e = new (std::nothrow) mkv_shard();
+	if (!e)
+		return MKV_ENOMEM;
+	*out = e;                       // the caller reads mkv_shard_error() and destroys it on failure
+	e->geom = *geom;
+	e->world = world;
+	e->rank = rank;
+	e->table = table;
+	e->n_get = n_get;
+	e->n_set = n_set;
+	e->cap_get = cap_get;
+	e->cap_set = cap_set;
+	int k = 0;
+	while ((1 << k) < world)
+		k++;
+	e->agg_mask = (uint32_t)((1ull << (geom->mem_p + k - 6)) - 1ull);
+	e->shift = (uint32_t)(geom->mem_p - 6);
+	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
+	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
+
+	e->api.lib = dlopen(rccl_path && *rccl_path ? rccl_path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
+	if (!e->api.lib)
+		return fail(e, MKV_EHIP, "dlopen(rccl)", dlerror());
+#define SH_SYM(field, name)                                                              \
+	do {                                                                                 \
+		*reinterpret_cast<void **>(&e->api.field) = dlsym(e->api.lib, name);             \
+		if (!e->api.field)                                                               \
+			return fail(e, MKV_EHIP, "dlsym", name);                                     \
+	} while (0)
+	SH_SYM(GetUniqueId, "ncclGetUniqueId");
+	SH_SYM(CommInitRank, "ncclCommInitRank");
+	SH_SYM(CommDestroy, "ncclCommDestroy");
+	SH_SYM(AllToAll, "ncclAllToAll");
+	SH_SYM(GetErrorString, "ncclGetErrorString");
+#undef SH_SYM
+
+	SH_HIP(e, hipMalloc(&e->overflow, sizeof(int)));
+	SH_HIP(e, hipMemset(e->overflow, 0, sizeof(int)));
+	SH_HIP(e, hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming));
+	const size_t slot_bytes = (size_t)world * (size_t)e->slot_words * 4u;
+	const size_t res_bytes = (size_t)world * (size_t)(cap_get ? cap_get : 1) * sizeof(loc_t) * 2u;
+	for (Lane &l : e->lane) {
+		SH_HIP(e, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+		SH_HIP(e, hipMalloc(&l.sendbuf, slot_bytes));
+		SH_HIP(e, hipMalloc(&l.recvbuf, slot_bytes));
+		SH_HIP(e, hipMalloc(&l.out_slots, res_bytes));
+		SH_HIP(e, hipMalloc(&l.back_slots, res_bytes));
+		SH_HIP(e, hipMalloc(&l.perm, (size_t)world * (size_t)(cap_get ? cap_get : 1) * sizeof(int32_t)));
+		SH_HIP(e, hipMalloc(&l.scratch, (size_t)e->scratch_bytes + 64));
+		SH_HIP(e, hipMemset(l.sendbuf, 0, slot_bytes));
+		SH_HIP(e, hipMemset(l.recvbuf, 0, slot_bytes));
+		SH_HIP(e, hipMemset(l.out_slots, 0, res_bytes));
+		SH_HIP(e, hipMemset(l.back_slots, 0, res_bytes));
+		SH_HIP(e, hipMemset(l.scratch, 0, (size_t)e->scratch_bytes + 64));   // the pack's control words start at zero
+		SH_HIP(e, hipMalloc(&l.set_ptrs, (size_t)world * sizeof(ielem_t *)));
+		ielem_t *ptrs[64];
+		for (int s = 0; s < world; s++)
+			ptrs[s] = reinterpret_cast<ielem_t *>(l.recvbuf + (size_t)s * (size_t)e->slot_words + 4 + 2 * (size_t)cap_get);
+		SH_HIP(e, hipMemcpy(l.set_ptrs, ptrs, (size_t)world * sizeof(ielem_t *), hipMemcpyHostToDevice));
+		for (hipEvent_t &ev : l.ev_local)
+			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		SH_HIP(e, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
+		if (cap_set) {
+			const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, l.stream);
+			if (rc != MKV_OK)
+				return fail(e, rc, "mkv_reserve", nullptr);
+		}
+	}
+	SH_HIP(e, hipDeviceSynchronize());
+	return MKV_OK;
+}
+
+// rank 0 makes the 128-byte id; the host framework hands it to every rank
+extern "C" int mkv_shard_unique_id(mkv_shard *e, void *id128)
+{
+	if (!e || !id128)
+		return MKV_EINVAL;
+	ncclUniqueId id;
+	SH_NCCL(e, e->api.GetUniqueId(&id));
+	memcpy(id128, &id, sizeof(id));
+	return MKV_OK;
+}
+
+// collective over all ranks of the job
+extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
+{
+	if (!e || !id128 || e->comm)
+		return MKV_EINVAL;
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof(id));
+	SH_NCCL(e, e->api.CommInitRank(&e->comm, e->world, id, e->rank));
+	return MKV_OK;
+}
+
+static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set)
+{
+	if (n_get > e->n_get || n_set > e->n_set)
+		return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
+	const int rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
+			e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
+	if (rc != MKV_OK)
+		return fail(e, rc, "mkv_pack_requests", nullptr);
+	SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
+	return MKV_OK;
+}
+
+static int backward(mkv_shard *e, Lane &l, loc_t *out)
+{
+	SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
+	const int rc = mkv_unpack_results(l.back_slots, l.perm, l.sendbuf, e->world, e->cap_get, e->cap_set, out,
+			l.stream);
+	if (rc != MKV_OK)
+		return fail(e, rc, "mkv_unpack_results", nullptr);
+	return MKV_OK;
+}
+
+// nbatches batches of this rank: gets[i] (n_get[i] x selem_t), sets[i] (n_set[i] x ielem_t),
+// outs[i] (n_get[i] x 2 loc_t, request order) -- all device pointers, host arrays of them.
+// Everything is enqueued (no host synchronisation); the lanes start after what is queued
+// on `stream` and `stream` waits for them at the end.  timer (mkv_timer_*) brackets the
+// local search launch of every timer_every-th batch, slot = i / timer_every.
+extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
+		int timer_every)
+{
+	if (!e || !e->comm || nbatches < 0 || (nbatches && (!gets || !n_get || !sets || !n_set || !outs)))
+		return MKV_EINVAL;
+	if (nbatches == 0)
+		return MKV_OK;
+	hipStream_t main = (hipStream_t)stream;
+	SH_HIP(e, hipEventRecord(e->ev_start, main));
+	for (Lane &l : e->lane)
+		SH_HIP(e, hipStreamWaitEvent(l.stream, e->ev_start, 0));
+	int rc = forward(e, e->lane[0], gets[0], n_get[0], sets[0], n_set[0]);
+	if (rc != MKV_OK)
+		return rc;
+	hipEvent_t prev_local = nullptr;
+	for (int i = 0; i < nbatches; i++) {
+		Lane &l = e->lane[i & 1];
+		if (i + 1 < nbatches) {
+			rc = forward(e, e->lane[(i + 1) & 1], gets[i + 1], n_get[i + 1], sets[i + 1], n_set[i + 1]);
+			if (rc != MKV_OK)
+				return rc;
+		}
+		if (prev_local)
+			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
+		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
+		rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
+				e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, l.stream, timed ? timer : nullptr,
+				timed ? i / timer_every : 0);
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_slots_cycle", nullptr);
+		prev_local = l.ev_local[(i >> 1) & 1];
+		SH_HIP(e, hipEventRecord(prev_local, l.stream));
+		rc = backward(e, l, outs[i]);
+		if (rc != MKV_OK)
+			return rc;
+	}
+	for (Lane &l : e->lane) {
+		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
+		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
+	}
+	return MKV_OK;
+}
+
+// synchronises; *flag = a slot overflowed since the engine was created (results invalid)
+extern "C" int mkv_shard_overflowed(mkv_shard *e, int *flag)
+{
+	if (!e || !flag)
+		return MKV_EINVAL;
+	SH_HIP(e, hipDeviceSynchronize());
+	SH_HIP(e, hipMemcpy(flag, e->overflow, sizeof(int), hipMemcpyDeviceToHost));
+	return MKV_OK;
+}

@@ -32,6 +32,8 @@ ABI_SYMBOLS = [
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
     "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
+    "mkv_shard_error", "mkv_shard_destroy",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -96,6 +98,20 @@ def load_library():
     L.mkv_pack_requests.argtypes = [P, I64, P, I64, U32, U32, INT, P, I64, I64, P, P, I64, P, P]
     L.mkv_search_slots.restype = INT
     L.mkv_search_slots.argtypes = [G, P, INT, I64, I64, P, P, P, P]
+    L.mkv_shard_create.restype = INT
+    L.mkv_shard_create.argtypes = [ctypes.POINTER(P), G, INT, INT, P, I64, I64, I64, I64, ctypes.c_char_p]
+    L.mkv_shard_unique_id.restype = INT
+    L.mkv_shard_unique_id.argtypes = [P, P]
+    L.mkv_shard_connect.restype = INT
+    L.mkv_shard_connect.argtypes = [P, P]
+    L.mkv_shard_run.restype = INT
+    L.mkv_shard_run.argtypes = [P, INT, P, P, P, P, P, P, P, INT]
+    L.mkv_shard_overflowed.restype = INT
+    L.mkv_shard_overflowed.argtypes = [P, ctypes.POINTER(INT)]
+    L.mkv_shard_error.restype = ctypes.c_char_p
+    L.mkv_shard_error.argtypes = [P]
+    L.mkv_shard_destroy.restype = None
+    L.mkv_shard_destroy.argtypes = [P]
     L.mkv_slots_cycle.restype = INT
     L.mkv_slots_cycle.argtypes = [G, P, INT, I64, I64, P, P, P, ctypes.c_longlong, P, P, INT]
     L.mkv_derive_requests.restype = INT

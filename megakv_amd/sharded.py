@@ -116,6 +116,61 @@ class HipOps:
                             dtype=torch.int64).to(recvbuf.device)
 
 
+class NativeEngine:
+    """One rank's sharded step driven by the C library (mkv_shard_*): pack, RCCL
+    all-to-all, local search+insert, result exchange, unpack -- a whole run of batches,
+    two in flight, enqueued by ONE library call.  The communicator is the library's own;
+    `dist` (torch.distributed, any backend) only carries the 128-byte id to the ranks."""
+
+    def __init__(self, sh, dist):
+        import os
+        self.sh, self.lib = sh, sh.idx.lib
+        self.h = ctypes.c_void_p(0)
+        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        rc = self.lib.mkv_shard_create(ctypes.byref(self.h), ctypes.byref(sh.idx._g), sh.world, sh.rank,
+                                       _dev_ptr(sh.idx.table), sh.n_get, sh.n_set, sh.cap_get, sh.cap_set,
+                                       rccl.encode() if os.path.exists(rccl) else None)
+        self._check(rc, "mkv_shard_create")
+        ident = [None]
+        if sh.rank == 0:
+            buf = ctypes.create_string_buffer(128)
+            self._check(self.lib.mkv_shard_unique_id(self.h, buf), "mkv_shard_unique_id")
+            ident = [buf.raw]
+        if sh.world > 1:
+            dist.broadcast_object_list(ident, src=0)
+        self._check(self.lib.mkv_shard_connect(self.h, ctypes.create_string_buffer(ident[0], 128)),
+                    "mkv_shard_connect")
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.lib.mkv_shard_error(self.h) if self.h else b""
+            raise RuntimeError(f"{what} failed ({rc}): {(msg or b'').decode(errors='replace')}")
+
+    def run(self, batches, stream=None, timer=None, timer_every=0):
+        n = len(batches)
+        if n == 0:
+            return
+        P, I64 = ctypes.c_void_p, ctypes.c_int64
+        gets = (P * n)(*[b["q"].data_ptr() if b["q"].shape[0] else None for b in batches])
+        sets = (P * n)(*[b["s"].data_ptr() if b["s"].shape[0] else None for b in batches])
+        outs = (P * n)(*[b["out"].data_ptr() for b in batches])
+        ng = (I64 * n)(*[b["q"].shape[0] for b in batches])
+        ns = (I64 * n)(*[b["s"].shape[0] for b in batches])
+        self._check(self.lib.mkv_shard_run(self.h, n, gets, ng, sets, ns, outs, _stream_ptr(stream),
+                                           ctypes.c_void_p(timer) if timer else None, int(timer_every)),
+                    "mkv_shard_run")
+
+    def overflowed(self):
+        flag = ctypes.c_int(0)
+        self._check(self.lib.mkv_shard_overflowed(self.h, ctypes.byref(flag)), "mkv_shard_overflowed")
+        return bool(flag.value)
+
+    def close(self):
+        if self.h:
+            self.lib.mkv_shard_destroy(self.h)
+            self.h = ctypes.c_void_p(0)
+
+
 class _TorchTimer:
     """event pairs around the local search launch (bench.py roofline at N > 1)"""
 
@@ -160,6 +215,7 @@ class ShardedIndex:
     def __init__(self, mem_p_local, world, rank, scheme, device, n_get, n_set, comm, ops=None,
                  cap_factor=None, index=None):
         self.world, self.rank = world, rank
+        self.native = None
         self.device = torch.device(device)
         self.geom = shard_geometry(mem_p_local, world, scheme)
         self.k = world.bit_length() - 1
@@ -236,6 +292,16 @@ class ShardedIndex:
         caller's current stream is joined at the end."""
         if not batches:
             return
+        if self.native is not None:
+            timer, every = None, 0
+            if timing_of is not None:
+                # (timing_of(i) -> [timer handle, slot] on every `every`-th batch, slot = i // every)
+                hits = [i for i in range(len(batches)) if timing_of(i)]
+                if hits:
+                    timer = timing_of(hits[0])[0]
+                    every = hits[1] - hits[0] if len(hits) > 1 else len(batches)
+            self.native.run(batches, None, timer if isinstance(timer, int) or timer is None else timer.h, every)
+            return
         main = torch.cuda.current_stream()
         start = torch.cuda.Event()
         start.record(main)
@@ -307,4 +373,12 @@ class ShardedIndex:
         return sg.n_get
 
     def overflowed(self):
+        if self.native is not None and self.native.overflowed():
+            return True
         return bool(self.overflow.item())
+
+    def enable_native(self, dist):
+        """Switch run_pipelined to the C engine (its own RCCL communicator).  Collective:
+        call on every rank.  Raises if the library cannot open RCCL or connect."""
+        self.native = NativeEngine(self, dist)
+        return self.native

@@ -18,3 +18,103 @@ def test_sharded_pipelined_two_lanes(world):
     """run_pipelined (two batches in flight, exchanges overlapping local kernels) must
     give exactly the results of the batches run one after the other."""
     run_and_check(world, "gpu-pipe", mem_p_local=16, scheme=0, seed=30 + world, timeout=900)
+
+
+@pytest.mark.parametrize("g,n_get,n_set,three_pass", [(1, 5000, 300, 0), (2, 70001, 4099, 0), (8, 200000, 30000, 0),
+                                                        (4, 0, 2500, 0), (4, 3000, 0, 0), (8, 50000, 5000, 1)])
+def test_pack_layout(g, n_get, n_set, three_pass):
+    """mkv_pack_requests: every request lands in the slot of its shard; SET slots keep
+    batch order (the canonical insert order of a shard is source rank, then index); GET
+    slots hold the right requests in any order with `perm` pointing home; headers count."""
+    import ctypes
+    import numpy as np
+    import torch
+    from megakv_amd.lib import load_library
+    from megakv_amd.index import _dev_ptr, _stream_ptr
+    L = load_library()
+    L.mkv_set_tuning(b"pack_three_pass", three_pass)
+    try:
+        rng = np.random.default_rng(g * 1000 + n_get % 97)
+        mem_p_agg = 20
+        mask, shift = (1 << (mem_p_agg - 6)) - 1, mem_p_agg - 6 - (g.bit_length() - 1)
+        gets = rng.integers(0, 2**32, size=(n_get, 2), dtype=np.uint64).astype(np.uint32)
+        sets = rng.integers(0, 2**32, size=(n_set, 3), dtype=np.uint64).astype(np.uint32)
+        cap_get = (int(n_get / g * 1.5) + 255) // 256 * 256 if n_get else 0
+        cap_set = (int(n_set / g * 1.5) + 15) // 16 * 16 + 16 if n_set else 0
+        sw = int(L.mkv_pack_slot_words(cap_get, cap_set))
+        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).cuda()
+        dg, ds = dev(gets), dev(sets)
+        sendbuf = torch.zeros((g, sw), dtype=torch.int32, device="cuda")
+        perm = torch.full((g * max(cap_get, 1),), -1, dtype=torch.int32, device="cuda")
+        nbytes = int(L.mkv_pack_scratch_bytes(max(n_get, 1), max(n_set, 1), g))
+        scratch = torch.zeros((nbytes // 4 + 16,), dtype=torch.int32, device="cuda")
+        overflow = torch.zeros((1,), dtype=torch.int32, device="cuda")
+        null = ctypes.c_void_p(0)
+        for rep in range(2):          # twice: the kernel leaves its control words clean
+            sendbuf.zero_()
+            rc = L.mkv_pack_requests(_dev_ptr(dg) if n_get else null, n_get, _dev_ptr(ds) if n_set else null, n_set,
+                                     mask, shift, g, _dev_ptr(sendbuf), cap_get, cap_set, _dev_ptr(perm),
+                                     _dev_ptr(scratch), scratch.numel() * 4, _dev_ptr(overflow), _stream_ptr(None))
+            assert rc == 0
+            torch.cuda.synchronize()
+            sb = sendbuf.cpu().numpy().view(np.uint32)
+            pm = perm.cpu().numpy()
+            assert int(overflow.item()) == 0
+            gsh = (gets[:, 1] & mask) >> shift
+            ssh = (sets[:, 1] & mask) >> shift
+            for s in range(g):
+                want_g = np.flatnonzero(gsh == s)
+                want_s = np.flatnonzero(ssh == s)
+                assert sb[s, 0] == len(want_g) and sb[s, 1] == len(want_s) and sb[s, 2] == 0 and sb[s, 3] == 0
+                got_g = sb[s, 4:4 + 2 * len(want_g)].reshape(-1, 2)
+                home = pm[s * cap_get:s * cap_get + len(want_g)]
+                assert np.array_equal(np.sort(home), want_g)
+                assert np.array_equal(got_g, gets[home])
+                got_s = sb[s, 4 + 2 * cap_get:4 + 2 * cap_get + 3 * len(want_s)].reshape(-1, 3)
+                assert np.array_equal(got_s, sets[want_s])
+    finally:
+        L.mkv_set_tuning(b"pack_three_pass", 0)
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_native_engine_one_rank_through_rccl(scheme):
+    """The C engine (mkv_shard_*: pack, ncclAllToAll, local search+insert, result exchange,
+    unpack; two batches in flight) with a one-rank communicator -- the only RCCL shape a
+    one-GPU box can run -- against the oracle, results and final table."""
+    import numpy as np
+    import torch
+    from megakv_amd.sharded import ShardedIndex
+    from oracle import oracle as O
+    mem_p = 16
+    rng = np.random.default_rng(77 + scheme)
+    n_get, n_set = 6000, 900
+    sh = ShardedIndex(mem_p, 1, 0, scheme, "cuda:0", n_get, n_set, comm=None)
+    sh.enable_native(None)
+    try:
+        og = O.geom(mem_p=mem_p, scheme=scheme)
+        table = O.new_table(og)
+        batches, host = [], []
+        for step in range(7):
+            ng = n_get if step != 3 else 1234          # a smaller batch in between
+            ns = n_set if step != 4 else 0
+            keys = rng.integers(1, 40000, size=ng + ns, dtype=np.uint64)
+            z = (keys * np.uint64(0x9E3779B97F4A7C15)) ^ (keys >> np.uint64(7))
+            sig = (z & np.uint64(0xffffffff)).astype(np.uint32)
+            sig[sig == 0] = 1
+            hsh = (z >> np.uint64(32)).astype(np.uint32)
+            gets = np.stack([sig[:ng], hsh[:ng]], axis=1)
+            sets = np.stack([sig[ng:], hsh[ng:], rng.integers(1, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)],
+                            axis=1).reshape(-1, 3)
+            host.append((gets, sets))
+            batches.append(sh.stage(gets, sets))
+        sh.run_pipelined(batches)
+        torch.cuda.synchronize()
+        assert not sh.overflowed()
+        for (gets, sets), b in zip(host, batches):
+            exp = O.search(og, table, np.ascontiguousarray(gets))
+            got = b["out"].cpu().numpy().view(np.uint32)
+            assert np.array_equal(got, exp)
+            O.insert(og, table, [np.ascontiguousarray(sets)])
+        assert np.array_equal(sh.idx.table_numpy(), table)
+    finally:
+        sh.native.close()
