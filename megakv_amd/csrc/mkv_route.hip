@@ -456,7 +456,7 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 		__syncthreads();
 		const uint2 *g2 = reinterpret_cast<const uint2 *>(gets);
 		uint2 rq[8];
-		uint32_t sh[8], pos[8];
+		uint32_t sh[8];
 #pragma unroll
 		for (int it = 0; it < 8; it++) {
 			const int64_t e = (int64_t)tile * kPackTile + it * 256 + t;
@@ -464,19 +464,38 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 			rq[it] = live ? g2[e] : make_uint2(0u, 0u);
 			sh[it] = live ? (rq[it].y & hash_mask) >> shift : 0xffffffffu;
 		}
+		// ranks by ballots (no per-request atomics): lane k counts shard k for its wave, takes
+		// the wave's range in the work-group's count (one LDS atomic), the work-group takes
+		// its range in the slot (one global atomic per shard)
+		uint32_t mine = 0;
 #pragma unroll
 		for (int it = 0; it < 8; it++)
-			pos[it] = sh[it] != 0xffffffffu ? atomicAdd(&s_cnt[sh[it]], 1u) : 0u;
+			for (uint32_t k = 0; k < G; k++) {
+				const uint32_t c = (uint32_t)__popcll(__ballot(sh[it] == k));
+				if (lane == k)
+					mine += c;
+			}
+		uint32_t cursor = 0;
+		if (lane < G && mine)
+			cursor = atomicAdd(&s_cnt[lane], mine);
 		__syncthreads();
 		if (t < G && s_cnt[t])
 			s_base[t] = atomicAdd(&cursors[t], s_cnt[t]);
 		__syncthreads();
+		if (lane < G)
+			cursor += s_base[lane];
 #pragma unroll
 		for (int it = 0; it < 8; it++) {
-			if (sh[it] == 0xffffffffu)
-				continue;
-			const uint32_t dst = s_base[sh[it]] + pos[it];
-			if (dst < cap_get) {
+			uint32_t dst = 0;
+			for (uint32_t k = 0; k < G; k++) {
+				const unsigned long long m = __ballot(sh[it] == k);
+				const uint32_t base = __shfl(cursor, (int)k);
+				if (sh[it] == k)
+					dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+				if (lane == k)
+					cursor += (uint32_t)__popcll(m);
+			}
+			if (sh[it] != 0xffffffffu && dst < cap_get) {
 				uint2 *p = reinterpret_cast<uint2 *>(sendbuf + (int64_t)sh[it] * slot_words + kHdrWords) + dst;
 				*p = rq[it];
 				perm_get[(int64_t)sh[it] * cap_get + dst] = (int32_t)((int64_t)tile * kPackTile + it * 256 + t);

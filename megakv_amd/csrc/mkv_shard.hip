@@ -3,13 +3,13 @@
 // A step of the sharded index is  pack -> all-to-all -> search+insert of the
 // received slots -> all-to-all of the results -> unpack  (mkv_route.hip,
 // mkv_update.hip).  This file drives that sequence for a whole run of batches from
-// one C call: two lanes (buffers + stream each) keep two batches in flight, so the
+// one C call: a few lanes (buffers + stream each) keep as many batches in flight, so the
 // exchanges of one batch overlap the local kernels of its neighbour; local phases
 // are chained by events, i.e. results are those of the batches run one after the
 // other.  Collectives go straight to RCCL (ncclAllToAll on the lane's stream) over
 // a communicator of its own; the library is opened with dlopen -- the C ABI of the
 // hot path (libgpuhash.a) does not depend on it.  Collectives are issued in the same
-// order on every rank: fwd(0), fwd(1), back(0), fwd(2), back(1), ...
+// order on every rank (2 lanes): fwd(0), fwd(1), back(0), fwd(2), back(1), ...
 //
 // New design: the reference is single-GPU.
 #include <dlfcn.h>
@@ -17,6 +17,7 @@
 #include <rccl/rccl.h>
 
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <new>
 
@@ -53,7 +54,8 @@ struct mkv_shard {
 	int64_t n_get = 0, n_set = 0, cap_get = 0, cap_set = 0, slot_words = 0, scratch_bytes = 0;
 	uint32_t agg_mask = 0, shift = 0;
 	int *overflow = nullptr;
-	Lane lane[2];
+	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
+	Lane lane[4];
 	hipEvent_t ev_start = nullptr;
 	Rccl api;
 	ncclComm_t comm = nullptr;
@@ -93,6 +95,8 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 	if (e->comm && e->api.CommDestroy)
 		(void)e->api.CommDestroy(e->comm);
 	for (Lane &l : e->lane) {
+		if (!l.stream)
+			continue;
 		if (l.sendbuf) (void)hipFree(l.sendbuf);
 		if (l.recvbuf) (void)hipFree(l.recvbuf);
 		if (l.out_slots) (void)hipFree(l.out_slots);
@@ -136,6 +140,11 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		k++;
 	e->agg_mask = (uint32_t)((1ull << (geom->mem_p + k - 6)) - 1ull);
 	e->shift = (uint32_t)(geom->mem_p - 6);
+	if (const char *v = getenv("MKV_SHARD_LANES")) {
+		const int n = atoi(v);
+		if (n >= 2 && n <= 4)
+			e->nlanes = n;
+	}
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
 	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
 
@@ -160,7 +169,8 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	SH_HIP(e, hipEventCreateWithFlags(&e->ev_start, hipEventDisableTiming));
 	const size_t slot_bytes = (size_t)world * (size_t)e->slot_words * 4u;
 	const size_t res_bytes = (size_t)world * (size_t)(cap_get ? cap_get : 1) * sizeof(loc_t) * 2u;
-	for (Lane &l : e->lane) {
+	for (int li = 0; li < e->nlanes; li++) {
+		Lane &l = e->lane[li];
 		SH_HIP(e, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
 		SH_HIP(e, hipMalloc(&l.sendbuf, slot_bytes));
 		SH_HIP(e, hipMalloc(&l.recvbuf, slot_bytes));
@@ -249,17 +259,24 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	if (nbatches == 0)
 		return MKV_OK;
 	hipStream_t main = (hipStream_t)stream;
+	const int L = e->nlanes;
 	SH_HIP(e, hipEventRecord(e->ev_start, main));
-	for (Lane &l : e->lane)
-		SH_HIP(e, hipStreamWaitEvent(l.stream, e->ev_start, 0));
-	int rc = forward(e, e->lane[0], gets[0], n_get[0], sets[0], n_set[0]);
-	if (rc != MKV_OK)
-		return rc;
+	for (int li = 0; li < L; li++)
+		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
+	int rc = MKV_OK;
+	// L batches in flight: the forward half of batch i+L-1 is queued before the local phase
+	// of batch i, so a lane has the time of L-1 local phases for its exchanges
+	for (int j = 0; j < L - 1 && j < nbatches; j++) {
+		rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j]);
+		if (rc != MKV_OK)
+			return rc;
+	}
 	hipEvent_t prev_local = nullptr;
 	for (int i = 0; i < nbatches; i++) {
-		Lane &l = e->lane[i & 1];
-		if (i + 1 < nbatches) {
-			rc = forward(e, e->lane[(i + 1) & 1], gets[i + 1], n_get[i + 1], sets[i + 1], n_set[i + 1]);
+		Lane &l = e->lane[i % L];
+		const int j = i + L - 1;
+		if (j < nbatches) {
+			rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j]);
 			if (rc != MKV_OK)
 				return rc;
 		}
@@ -271,13 +288,14 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 				timed ? i / timer_every : 0);
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_slots_cycle", nullptr);
-		prev_local = l.ev_local[(i >> 1) & 1];
+		prev_local = l.ev_local[(i / L) & 1];
 		SH_HIP(e, hipEventRecord(prev_local, l.stream));
 		rc = backward(e, l, outs[i]);
 		if (rc != MKV_OK)
 			return rc;
 	}
-	for (Lane &l : e->lane) {
+	for (int li = 0; li < L; li++) {
+		Lane &l = e->lane[li];
 		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
 		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
 	}
