@@ -117,11 +117,11 @@ def main():
     geom = shard_geometry(mem_p_local, world, scheme)
     if mode == "cpu":
         ops = CpuOps(geom)
-        sh = ShardedIndex(mem_p_local, world, rank, scheme, "cpu", n_get, n_set, GlooComm(), ops=ops)
+        sh = ShardedIndex(mem_p_local, world, rank, scheme, "cpu", n_get, n_set, GlooComm(), ops=ops, cap_factor=2.0)
         to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32))
     else:
         torch.cuda.set_device(0)
-        sh = ShardedIndex(mem_p_local, world, rank, scheme, "cuda:0", n_get, n_set, StagedComm(dist))
+        sh = ShardedIndex(mem_p_local, world, rank, scheme, "cuda:0", n_get, n_set, StagedComm(dist), cap_factor=2.0)
         to_t = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).cuda()
     rng = np.random.default_rng(seed * 100 + rank)
     known = np.zeros((0, 3), np.uint32)
