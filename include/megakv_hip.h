@@ -178,6 +178,22 @@ int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots,
 int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf, int nshards,
 		int64_t cap_get, int64_t cap_set, loc_t *out, void *stream);
 
+/* Request packets of the reference's protocol on the device (src/mega_recv.c:292-545,
+ * README.md:70-81): payloads = npackets UDP payloads at `stride` bytes (a multiple of 4,
+ * at most 2048 are looked at), payload_len = their lengths (device int32[], or NULL: all
+ * `stride`).  GET requests go to gets ({sig, hash}, arrival order: packet, then job) with
+ * get_packet[i] = their packet (may be NULL), SET requests to sets with loc = packet *
+ * 2048 + byte offset of the key in its payload (the host replaces it by the item it
+ * allocates).  Jobs whose key/value length differs from key_len/value_len are skipped
+ * like the reference does.  counts (device u64[4]) = n_get, n_set, bad packets, skipped
+ * jobs; requests beyond cap_get / cap_set are dropped (compare counts with the caps).
+ * fold: XOR-fold key bytes beyond the first 8 (the reference's SIGNATURE build). */
+int64_t mkv_parse_scratch_bytes(int64_t npackets);
+int mkv_parse_packets(const void *payloads, int64_t stride, const int32_t *payload_len, int64_t npackets,
+		int key_len, int value_len, int fold, selem_t *gets, int32_t *get_packet, ielem_t *sets,
+		int64_t cap_get, int64_t cap_set, unsigned long long *counts, void *scratch, int64_t scratch_bytes,
+		void *stream);
+
 /* ---- one rank of the sharded index, driven from C (libmegakv_hip.so only; RCCL is
  * opened with dlopen(rccl_path), default "librccl.so") -------------------------------
  * geom: the LOCAL table's geometry, i.e. IBLOCK_P already reduced by log2(world);

@@ -794,3 +794,243 @@ extern "C" int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *
 			reinterpret_cast<unsigned long long *>(counters), (long long)num_elem);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
+
+// ===========================================================================
+// Request packets on the device: the reference's receiver walks
+// every UDP payload on a CPU core (src/mega_recv.c:292-545): 16-bit magic 0x1234, then
+// jobs  GET = u16 0x2, u16 key_len, key   SET = u16 0x3, u16 key_len, u32 value_len,
+// key, value,  until the 16-bit end mark 0xFFFF (README.md:70-81).  Here a wave takes a
+// packet: all lanes copy it into LDS, lane 0 walks the job headers (the only sequential
+// part), all lanes derive (sig, hash) of the jobs side by side (:349-362, the XOR fold of
+// the SIGNATURE build optional).  Two passes -- count, then emit at the scanned offsets --
+// keep the reference's arrival order: packet order, job order inside a packet.
+//   * a GET whose key length differs from key_len is skipped (:312-315), a SET whose
+//     key or value length differs likewise (:449-453); both count as bad jobs
+//   * a wrong magic drops the packet (:293-296); an unknown job type ends it, keeping the
+//     jobs before it (:535-537); so does reaching the end of the payload (:540-543)
+//   * SET requests leave here with loc = packet * 2048 + byte offset of the key in the
+//     payload: the real location is the slab item the host allocates for it (:447,
+//     src/slabs.c), which is outside the hot path.
+// ===========================================================================
+namespace mkv {
+
+constexpr int kPktBytes = 2048;          // payload bytes a wave stages (frames are <= 1514)
+constexpr int kPktJobs = 512;            // (2048 - 4) / 4: no payload holds more jobs
+
+struct PktWalk {
+	uint32_t njobs, ngets, nsets, nbad, bad_packet;
+};
+
+__device__ __forceinline__ uint32_t pkt_u16(const uint8_t *b, uint32_t off, uint32_t len)
+{
+	return (off < len ? b[off] : 0u) | ((off + 1u < len ? b[off + 1u] : 0u) << 8);
+}
+
+// lane 0 of a wave: job table (kind 1 = GET, 2 = SET, 0 = skipped; offset of the key)
+__device__ PktWalk walk_packet(const uint8_t *b, uint32_t len, uint32_t key_len, uint32_t value_len,
+		uint16_t *job_off, uint8_t *job_kind)
+{
+	PktWalk w = {0u, 0u, 0u, 0u, 0u};
+	if (len < 4u || pkt_u16(b, 0u, len) != 0x1234u) {
+		w.bad_packet = 1u;
+		return w;
+	}
+	uint32_t ptr = 2u;
+	while (w.njobs < (uint32_t)kPktJobs) {
+		const uint32_t type = pkt_u16(b, ptr, len);
+		ptr += 2u;
+		if (type == 0xFFFFu)
+			break;
+		if (type == 0x2u) {
+			const uint32_t nkey = pkt_u16(b, ptr, len);
+			ptr += 2u;
+			const bool ok = nkey == key_len;
+			job_off[w.njobs] = (uint16_t)ptr;
+			job_kind[w.njobs] = ok ? 1u : 0u;
+			w.njobs++;
+			w.ngets += ok ? 1u : 0u;
+			w.nbad += ok ? 0u : 1u;
+			ptr += nkey;
+		} else if (type == 0x3u) {
+			const uint32_t nkey = pkt_u16(b, ptr, len);
+			const uint32_t nbyte = pkt_u16(b, ptr + 2u, len) | (pkt_u16(b, ptr + 4u, len) << 16);
+			ptr += 6u;
+			const bool ok = nkey == key_len && nbyte == value_len;
+			job_off[w.njobs] = (uint16_t)ptr;
+			job_kind[w.njobs] = ok ? 2u : 0u;
+			w.njobs++;
+			w.nsets += ok ? 1u : 0u;
+			w.nbad += ok ? 0u : 1u;
+			if (nbyte > (uint32_t)kPktBytes) {
+				w.bad_packet = 1u;
+				break;
+			}
+			ptr += nkey + nbyte;
+		} else {
+			w.bad_packet = 1u;               // wrong job type: what came before stays
+			break;
+		}
+		if (ptr >= len) {                    // "Exceed payload length"
+			w.bad_packet = 1u;
+			break;
+		}
+	}
+	return w;
+}
+
+// EMIT = false: counts per packet.  EMIT = true: requests at the scanned offsets.
+template <bool EMIT>
+__global__ __launch_bounds__(256) void k_parse(const uint8_t *__restrict__ payloads, int64_t stride,
+		const int32_t *__restrict__ payload_len, int64_t npackets, uint32_t key_len, uint32_t value_len, int fold,
+		uint32_t *__restrict__ cnt_get, uint32_t *__restrict__ cnt_set, uint32_t *__restrict__ gets,
+		int32_t *__restrict__ get_packet, uint32_t *__restrict__ sets, int64_t cap_get, int64_t cap_set,
+		unsigned long long *counts)
+{
+	__shared__ uint32_t s_pay[4][kPktBytes / 4];
+	__shared__ uint16_t s_off[4][kPktJobs];
+	__shared__ uint8_t s_kind[4][kPktJobs];
+	__shared__ PktWalk s_walk[4];
+	const uint32_t wave = threadIdx.x >> 6, lane = threadIdx.x & 63u;
+	const int64_t p = (int64_t)blockIdx.x * 4 + wave;
+	if (p >= npackets)
+		return;                                   // (whole waves leave: no block-wide barrier below)
+	int64_t len64 = payload_len ? (int64_t)payload_len[p] : stride;
+	if (len64 > stride)
+		len64 = stride;
+	if (len64 > kPktBytes)
+		len64 = kPktBytes;
+	const uint32_t len = len64 > 0 ? (uint32_t)len64 : 0u;
+	const uint32_t *src = reinterpret_cast<const uint32_t *>(payloads + p * stride);
+	for (uint32_t i = lane; i < (len + 3u) / 4u; i += 64u)
+		s_pay[wave][i] = src[i];
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	const uint8_t *b = reinterpret_cast<const uint8_t *>(s_pay[wave]);
+	if (lane == 0)
+		s_walk[wave] = walk_packet(b, len, key_len, value_len, s_off[wave], s_kind[wave]);
+	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
+	__builtin_amdgcn_wave_barrier();
+	const PktWalk w = s_walk[wave];
+	if (!EMIT) {
+		if (lane == 0) {
+			cnt_get[p] = w.ngets;
+			cnt_set[p] = w.nsets;
+			if (w.nbad)
+				atomicAdd(&counts[3], (unsigned long long)w.nbad);
+			if (w.bad_packet)
+				atomicAdd(&counts[2], 1ull);
+		}
+		return;
+	}
+	uint32_t at_get = cnt_get[p], at_set = cnt_set[p];      // exclusive offsets after the scan
+	for (uint32_t base = 0; base < w.njobs; base += 64u) {
+		const uint32_t j = base + lane;
+		const uint32_t kind = j < w.njobs ? s_kind[wave][j] : 0u;
+		const unsigned long long mg = __ballot(kind == 1u), ms = __ballot(kind == 2u);
+		const unsigned long long below = (1ull << lane) - 1ull;
+		if (kind) {
+			const uint32_t off = s_off[wave][j];
+			// signature word: first 8 key bytes, the rest XOR-folded in the SIGNATURE build
+			uint64_t sig = 0;
+			for (uint32_t i = 0; i < 8u; i++)
+				sig |= (uint64_t)(off + i < len ? b[off + i] : 0u) << (8u * i);
+			if (fold) {
+				for (uint32_t i = 8u; i < key_len; i++)
+					sig ^= (uint64_t)(off + i < len ? b[off + i] : 0u) << (8u * (i & 7u));
+			}
+			if (kind == 1u) {
+				const int64_t dst = (int64_t)at_get + __popcll(mg & below);
+				if (dst < cap_get) {
+					gets[dst * 2] = (uint32_t)sig;
+					gets[dst * 2 + 1] = (uint32_t)(sig >> 32);
+					if (get_packet)
+						get_packet[dst] = (int32_t)p;
+				}
+			} else {
+				const int64_t dst = (int64_t)at_set + __popcll(ms & below);
+				if (dst < cap_set) {
+					sets[dst * 3] = (uint32_t)sig;
+					sets[dst * 3 + 1] = (uint32_t)(sig >> 32);
+					sets[dst * 3 + 2] = (uint32_t)p * (uint32_t)kPktBytes + off;
+				}
+			}
+		}
+		at_get += (uint32_t)__popcll(mg);
+		at_set += (uint32_t)__popcll(ms);
+	}
+}
+
+// exclusive scan of the per-packet counts (one work-group), totals into counts[0..1]
+__global__ __launch_bounds__(1024) void k_parse_scan(uint32_t *cnt_get, uint32_t *cnt_set, int64_t npackets,
+		unsigned long long *counts)
+{
+	__shared__ unsigned long long s_part[2][1024];
+	const uint32_t t = threadIdx.x;
+	const int64_t per = (npackets + blockDim.x - 1) / blockDim.x;
+	const int64_t lo = (int64_t)t * per, hi = lo + per < npackets ? lo + per : npackets;
+	unsigned long long g = 0, s = 0;
+	for (int64_t i = lo; i < hi; i++) {
+		g += cnt_get[i];
+		s += cnt_set[i];
+	}
+	s_part[0][t] = g;
+	s_part[1][t] = s;
+	__syncthreads();
+	for (uint32_t off = 1; off < blockDim.x; off <<= 1) {
+		const unsigned long long ag = t >= off ? s_part[0][t - off] : 0ull, as = t >= off ? s_part[1][t - off] : 0ull;
+		__syncthreads();
+		s_part[0][t] += ag;
+		s_part[1][t] += as;
+		__syncthreads();
+	}
+	unsigned long long rg = s_part[0][t] - g, rs = s_part[1][t] - s;
+	for (int64_t i = lo; i < hi; i++) {
+		const uint32_t cg = cnt_get[i], cs = cnt_set[i];
+		cnt_get[i] = (uint32_t)rg;
+		cnt_set[i] = (uint32_t)rs;
+		rg += cg;
+		rs += cs;
+	}
+	if (t == blockDim.x - 1u) {
+		counts[0] = s_part[0][t];
+		counts[1] = s_part[1][t];
+	}
+}
+
+}  // namespace mkv
+
+extern "C" int64_t mkv_parse_scratch_bytes(int64_t npackets)
+{
+	return (npackets > 0 ? npackets : 1) * 8 + 64;
+}
+
+// counts (device, 4 x u64): requests found n_get, n_set (compare with the capacities: what
+// does not fit is dropped), bad packets, skipped jobs.
+extern "C" int mkv_parse_packets(const void *payloads, int64_t stride, const int32_t *payload_len,
+		int64_t npackets, int key_len, int value_len, int fold, selem_t *gets, int32_t *get_packet,
+		ielem_t *sets, int64_t cap_get, int64_t cap_set, unsigned long long *counts, void *scratch,
+		int64_t scratch_bytes, void *stream)
+{
+	if (npackets < 0 || stride < 4 || (stride & 3) || key_len < 8 || key_len > 1024 || value_len < 0 ||
+			cap_get < 0 || cap_set < 0 || !counts || (npackets && (!payloads || !scratch)) ||
+			(cap_get && !gets) || (cap_set && !sets) || scratch_bytes < mkv_parse_scratch_bytes(npackets))
+		return MKV_EINVAL;
+	hipStream_t s = (hipStream_t)stream;
+	if (hipMemsetAsync(counts, 0, 4 * sizeof(unsigned long long), s) != hipSuccess)
+		return MKV_EHIP;
+	if (npackets == 0)
+		return MKV_OK;
+	if ((npackets + 3) / 4 > 0x7fffffffLL)
+		return MKV_ETOOBIG;
+	uint32_t *cnt_get = reinterpret_cast<uint32_t *>(scratch), *cnt_set = cnt_get + npackets;
+	const dim3 grid((unsigned)((npackets + 3) / 4)), block(256);
+	const uint8_t *pl = reinterpret_cast<const uint8_t *>(payloads);
+	hipLaunchKernelGGL((mkv::k_parse<false>), grid, block, 0, s, pl, stride, payload_len, npackets,
+			(uint32_t)key_len, (uint32_t)value_len, fold, cnt_get, cnt_set, nullptr, nullptr, nullptr, cap_get,
+			cap_set, counts);
+	hipLaunchKernelGGL(mkv::k_parse_scan, dim3(1), dim3(1024), 0, s, cnt_get, cnt_set, npackets, counts);
+	hipLaunchKernelGGL((mkv::k_parse<true>), grid, block, 0, s, pl, stride, payload_len, npackets,
+			(uint32_t)key_len, (uint32_t)value_len, fold, cnt_get, cnt_set, reinterpret_cast<uint32_t *>(gets),
+			get_packet, reinterpret_cast<uint32_t *>(sets), cap_get, cap_set, counts);
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}

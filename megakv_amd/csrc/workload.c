@@ -216,3 +216,129 @@ void mkv_bin_inserts(const uint32_t *ielem, int64_t n, uint32_t mem_p, uint32_t 
 	}
 	free(off);
 }
+
+/* ---- LOCAL_TEST packet synthesis ---------------------------------
+ * The reference's receiver builds its own request packets when compiled with LOCAL_TEST
+ * and feeds them to its parser (src/mega_recv.c:633-768).  This restates the payload it
+ * writes -- 16-bit magic 0x1234, jobs, 16-bit end mark 0xFFFF (README.md:70-81):
+ *   GET: u16 0x2, u16 key_len, key            SET: u16 0x3, u16 key_len, u32 value_len, key, value
+ * Keys: first 4 bytes = key id, next 4 = (bswap32(id & 0xff) << (8 - bits_insert_buf)) | id
+ * (:700-704, :733-737); the rest of a longer key and the value are not written by the
+ * reference (stale buffer contents) and are zero here.  GET ids come from the Zipf stream
+ * (rank + 1, :691), SET ids count up (:727); NUM_DEFINED_GET GETs alternate with
+ * NUM_DEFINED_SET SETs across packet borders (:681-749); a packet is closed when the next
+ * job would push the frame beyond 1514 bytes including the 42-byte Ethernet/IP/UDP header. */
+typedef struct mkv_synth_s {
+	mkv_zipf_t zipf;
+	uint32_t set_key;          /* last SET id handed out (the next one is +1) */
+	int num_get, num_set;      /* jobs left in the current run of GETs / SETs */
+	int def_get, def_set;      /* NUM_DEFINED_GET / NUM_DEFINED_SET (src/macros.h:88-97) */
+	int key_len, value_len;    /* KEY_LEN / VALUE_LEN (src/macros.h:58-74) */
+	int bits_insert_buf;       /* IBLOCK_P */
+} mkv_synth_t;
+
+int mkv_synth_init(mkv_synth_t *s, uint64_t zipf_n, double theta, uint64_t seed, uint32_t first_set_key,
+		int def_get, int def_set, int key_len, int value_len, int bits_insert_buf)
+{
+	if (key_len < 8 || value_len < 0 || def_get < 0 || def_set < 0 || def_get + def_set == 0 ||
+			bits_insert_buf < 0 || bits_insert_buf > 8)
+		return -1;
+	if (mkv_zipf_init(&s->zipf, zipf_n, theta, seed) != 0)
+		return -1;
+	s->set_key = first_set_key - 1u;
+	s->def_get = def_get;
+	s->def_set = def_set;
+	s->num_get = def_get;              /* :645-646 */
+	s->num_set = def_set;
+	s->key_len = key_len;
+	s->value_len = value_len;
+	s->bits_insert_buf = bits_insert_buf;
+	return 0;
+}
+
+static void synth_key(uint8_t *p, uint32_t id, int key_len, int bits)
+{
+	uint32_t hi = id;
+	if (bits)
+		hi = (uint32_t)(((id & 0xffu) << 24) << (8 - bits)) | id;
+	memset(p, 0, (size_t)key_len);
+	memcpy(p, &id, 4);
+	memcpy(p + 4, &hi, 4);
+}
+
+/* Writes npackets payloads of at most `stride` bytes each (stride >= 1472); payload_len[p] =
+ * bytes of packet p (magic + jobs + end mark).  get_keys / set_keys, if not NULL, receive the
+ * ids in job order (capacity: the caller's; counts are returned through n_get / n_set). */
+int64_t mkv_synth_packets(mkv_synth_t *s, uint8_t *payloads, int64_t stride, int64_t npackets,
+		int32_t *payload_len, uint32_t *get_keys, uint32_t *set_keys, int64_t *n_get, int64_t *n_set)
+{
+	const int hdr = 42, frame_max = 1514;
+	const int get_len = s->key_len + 4, set_len = s->key_len + s->value_len + 8;
+	int64_t ng = 0, ns = 0;
+	if (stride < frame_max - hdr)
+		return -1;
+	for (int64_t p = 0; p < npackets; p++) {
+		uint8_t *base = payloads + p * stride, *ptr = base;
+		int frame = hdr + 2 + 2;                   /* reserved_len (:639) */
+		const uint16_t magic = 0x1234, end = 0xFFFF, jget = 0x2, jset = 0x3;
+		memcpy(ptr, &magic, 2);
+		ptr += 2;
+		for (;;) {
+			if (s->num_get > 0) {
+				if (frame + get_len > frame_max)
+					break;
+				const uint16_t kl = (uint16_t)s->key_len;
+				memcpy(ptr, &jget, 2);
+				memcpy(ptr + 2, &kl, 2);
+				ptr += 4;
+				const uint32_t id = (uint32_t)mkv_zipf_next(&s->zipf) + 1u;
+				synth_key(ptr, id, s->key_len, s->bits_insert_buf);
+				if (get_keys)
+					get_keys[ng] = id;
+				ng++;
+				ptr += s->key_len;
+				frame += get_len;
+				if (--s->num_get == 0) {
+					if (s->def_set > 0)
+						s->num_set = s->def_set;
+					else
+						s->num_get = s->def_get;
+				}
+			} else if (s->num_set > 0) {
+				if (frame + set_len > frame_max)
+					break;
+				const uint16_t kl = (uint16_t)s->key_len;
+				const uint32_t vl = (uint32_t)s->value_len;
+				memcpy(ptr, &jset, 2);
+				memcpy(ptr + 2, &kl, 2);
+				memcpy(ptr + 4, &vl, 4);
+				ptr += 8;
+				const uint32_t id = ++s->set_key;
+				synth_key(ptr, id, s->key_len, s->bits_insert_buf);
+				memset(ptr + s->key_len, 0, (size_t)s->value_len);
+				if (set_keys)
+					set_keys[ns] = id;
+				ns++;
+				ptr += s->key_len + s->value_len;
+				frame += set_len;
+				if (--s->num_set == 0) {
+					if (s->def_get > 0)
+						s->num_get = s->def_get;
+					else
+						s->num_set = s->def_set;
+				}
+			} else {
+				return -1;
+			}
+		}
+		memcpy(ptr, &end, 2);
+		ptr += 2;
+		if (payload_len)
+			payload_len[p] = (int32_t)(ptr - base);
+	}
+	if (n_get)
+		*n_get = ng;
+	if (n_set)
+		*n_set = ns;
+	return ng + ns;
+}

@@ -33,7 +33,7 @@ ABI_SYMBOLS = [
     "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
-    "mkv_shard_error", "mkv_shard_destroy",
+    "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -98,6 +98,10 @@ def load_library():
     L.mkv_pack_requests.argtypes = [P, I64, P, I64, U32, U32, INT, P, I64, I64, P, P, I64, P, P]
     L.mkv_search_slots.restype = INT
     L.mkv_search_slots.argtypes = [G, P, INT, I64, I64, P, P, P, P]
+    L.mkv_parse_scratch_bytes.restype = I64
+    L.mkv_parse_scratch_bytes.argtypes = [I64]
+    L.mkv_parse_packets.restype = INT
+    L.mkv_parse_packets.argtypes = [P, I64, P, I64, INT, INT, INT, P, P, P, I64, I64, P, P, I64, P]
     L.mkv_shard_create.restype = INT
     L.mkv_shard_create.argtypes = [ctypes.POINTER(P), G, INT, INT, P, I64, I64, I64, I64, ctypes.c_char_p]
     L.mkv_shard_unique_id.restype = INT

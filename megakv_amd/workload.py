@@ -26,6 +26,12 @@ class _Zipf(ctypes.Structure):
                 ("zetan", ctypes.c_double), ("eta", ctypes.c_double), ("rand_state", ctypes.c_uint64)]
 
 
+class _Synth(ctypes.Structure):
+    _fields_ = [("zipf", _Zipf), ("set_key", ctypes.c_uint32), ("num_get", ctypes.c_int),
+                ("num_set", ctypes.c_int), ("def_get", ctypes.c_int), ("def_set", ctypes.c_int),
+                ("key_len", ctypes.c_int), ("value_len", ctypes.c_int), ("bits_insert_buf", ctypes.c_int)]
+
+
 _lib = None
 
 
@@ -46,6 +52,13 @@ def _L():
         L.mkv_make_selem.argtypes = [P, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, P]
         L.mkv_make_ielem.restype = None
         L.mkv_make_ielem.argtypes = [P, P, ctypes.c_int64, ctypes.c_int, ctypes.c_uint32, P]
+        L.mkv_synth_init.restype = ctypes.c_int
+        L.mkv_synth_init.argtypes = [ctypes.POINTER(_Synth), ctypes.c_uint64, ctypes.c_double, ctypes.c_uint64,
+                                     ctypes.c_uint32, ctypes.c_int, ctypes.c_int, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int]
+        L.mkv_synth_packets.restype = ctypes.c_int64
+        L.mkv_synth_packets.argtypes = [ctypes.POINTER(_Synth), P, ctypes.c_int64, ctypes.c_int64, P, P, P,
+                                        ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
         L.mkv_bin_inserts.restype = None
         L.mkv_bin_inserts.argtypes = [P, ctypes.c_int64, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_int, P, P]
         _lib = L
@@ -75,6 +88,35 @@ class ZipfKeys:
 
     def params(self):
         return {"zetan": self.s.zetan, "eta": self.s.eta, "thres": self.s.thres}
+
+
+class PacketSynth:
+    """Request packets as the reference's LOCAL_TEST receiver builds them
+    (src/mega_recv.c:633-768): NUM_DEFINED_GET Zipf GETs alternating with NUM_DEFINED_SET
+    fresh-key SETs, packed into 1514-byte frames; only the UDP payloads are produced."""
+
+    STRIDE = 1472
+
+    def __init__(self, zipf_n, theta, seed, first_set_key, num_get, num_set, key_len=8, value_len=8, iblock_p=3):
+        self.s = _Synth()
+        if _L().mkv_synth_init(ctypes.byref(self.s), zipf_n, float(theta), seed, first_set_key, num_get, num_set,
+                               key_len, value_len, iblock_p) != 0:
+            raise ValueError("packet synthesis parameters rejected")
+
+    def packets(self, npackets):
+        """-> payloads uint8 [npackets, 1472], lengths int32 [npackets], GET ids, SET ids (job order)"""
+        pay = np.zeros((npackets, self.STRIDE), dtype=np.uint8)
+        lens = np.zeros(npackets, dtype=np.int32)
+        gk = np.zeros(npackets * 368, dtype=np.uint32)
+        sk = np.zeros(npackets * 368, dtype=np.uint32)
+        ng, ns = ctypes.c_int64(0), ctypes.c_int64(0)
+        P = ctypes.c_void_p
+        rc = _L().mkv_synth_packets(ctypes.byref(self.s), pay.ctypes.data_as(P), self.STRIDE, npackets,
+                                    lens.ctypes.data_as(P), gk.ctypes.data_as(P), sk.ctypes.data_as(P),
+                                    ctypes.byref(ng), ctypes.byref(ns))
+        if rc < 0:
+            raise RuntimeError("mkv_synth_packets failed")
+        return pay, lens, gk[:ng.value].copy(), sk[:ns.value].copy()
 
 
 def make_selem(keys, keying=KEYING_REF, iblock_p=3):

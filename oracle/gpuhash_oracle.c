@@ -321,3 +321,75 @@ void orc_delete(const orc_geom_t *g, orc_bucket_t *table,
 		}
 	}
 }
+
+/* ---- request packets -------------------------------------------------
+ * The receiver's parser, src/mega_recv.c:292-545, without its batch bookkeeping: walks one
+ * UDP payload (magic 0x1234, jobs, end mark 0xFFFF), appends the GET requests to gets
+ * ({sig, hash} pairs, :349-362) and the SET requests to sets ({sig, hash, loc}); loc is
+ * what the device parser puts there (packet * 2048 + offset of the key) -- the reference
+ * stores the slab item's location (:447, :503), which only exists on its host.
+ * Bytes beyond the payload read as zero (the reference reads whatever follows).
+ * Returns 0, or -1 where the reference returns -1 (wrong magic / job type / end reached). */
+static uint32_t pk16(const uint8_t *b, uint32_t off, uint32_t len)
+{
+	return (off < len ? b[off] : 0u) | ((off + 1u < len ? (uint32_t)b[off + 1u] : 0u) << 8);
+}
+
+static uint64_t pk_sig(const uint8_t *b, uint32_t off, uint32_t len, uint32_t nkey, int fold)
+{
+	uint64_t sig = 0;
+	for (uint32_t i = 0; i < 8u; i++)
+		sig |= (uint64_t)(off + i < len ? b[off + i] : 0u) << (8u * i);      /* :349-350 */
+	if (fold)                                                                /* :351-360 */
+		for (uint32_t i = 8u; i < nkey; i++)
+			sig ^= (uint64_t)(off + i < len ? b[off + i] : 0u) << (8u * (i & 7u));
+	return sig;
+}
+
+int orc_parse_packet(const uint8_t *b, uint32_t len, uint32_t packet, uint32_t key_len, uint32_t value_len,
+		int fold, uint32_t *gets, int64_t *n_get, uint32_t *sets, int64_t *n_set, int64_t *n_bad)
+{
+	if (len < 4u || pk16(b, 0u, len) != 0x1234u)                             /* :293-296 */
+		return -1;
+	uint32_t ptr = 2u;
+	for (int jobs = 0; jobs < 512; jobs++) {
+		const uint32_t type = pk16(b, ptr, len);
+		ptr += 2u;
+		if (type == 0xFFFFu)                                                 /* :305-307 */
+			return 0;
+		if (type == 0x2u) {                                                  /* :309-434 */
+			const uint32_t nkey = pk16(b, ptr, len);
+			ptr += 2u;
+			if (nkey == key_len) {
+				const uint64_t sig = pk_sig(b, ptr, len, nkey, fold);
+				gets[*n_get * 2] = (uint32_t)sig;
+				gets[*n_get * 2 + 1] = (uint32_t)(sig >> 32);
+				(*n_get)++;
+			} else {
+				(*n_bad)++;                                                  /* :312-315 */
+			}
+			ptr += nkey;
+		} else if (type == 0x3u) {                                           /* :436-532 */
+			const uint32_t nkey = pk16(b, ptr, len);
+			const uint32_t nbyte = pk16(b, ptr + 2u, len) | (pk16(b, ptr + 4u, len) << 16);
+			ptr += 6u;
+			if (nkey == key_len && nbyte == value_len) {
+				const uint64_t sig = pk_sig(b, ptr, len, nkey, fold);
+				sets[*n_set * 3] = (uint32_t)sig;
+				sets[*n_set * 3 + 1] = (uint32_t)(sig >> 32);
+				sets[*n_set * 3 + 2] = packet * 2048u + ptr;
+				(*n_set)++;
+			} else {
+				(*n_bad)++;                                                  /* :449-453 */
+			}
+			if (nbyte > 2048u)
+				return -1;
+			ptr += nkey + nbyte;
+		} else {
+			return -1;                                                       /* :535-537 */
+		}
+		if (ptr >= len)                                                      /* :540-543 */
+			return -1;
+	}
+	return 0;
+}

@@ -62,6 +62,13 @@ void orc_delete(const orc_geom_t *g, orc_bucket_t *table,
 void orc_search_mt(const orc_geom_t *g, const orc_bucket_t *table,
 		const orc_selem_t *in, uint32_t *out, int64_t n, int nthreads);
 
+/* One UDP payload of the reference's request protocol (src/mega_recv.c:292-545,
+ * README.md:70-81): appends its GETs ({sig, hash}) and SETs ({sig, hash, packet * 2048 + key
+ * offset}); returns 0 or -1 like the reference's parser. */
+int orc_parse_packet(const uint8_t *payload, uint32_t len, uint32_t packet, uint32_t key_len,
+		uint32_t value_len, int fold, uint32_t *gets, int64_t *n_get, uint32_t *sets, int64_t *n_set,
+		int64_t *n_bad);
+
 #ifdef __cplusplus
 }
 #endif

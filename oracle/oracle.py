@@ -133,3 +133,27 @@ def delete(g, table, delem):
     st = Stats()
     lib().orc_delete(ctypes.byref(g), _ptr(table), _ptr(delem), delem.shape[0], ctypes.byref(st))
     return st.as_dict()
+
+
+def parse_packets(payloads, lens, key_len, value_len, fold=False):
+    """payloads: uint8 [npackets, stride]; lens: int32 [npackets].  Returns (gets [n,2],
+    sets [n,3], bad_packets, bad_jobs) as the reference's receiver would batch them."""
+    L = lib()
+    L.orc_parse_packet.restype = ctypes.c_int
+    L.orc_parse_packet.argtypes = [ctypes.c_void_p, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32,
+                                   ctypes.c_uint32, ctypes.c_int, ctypes.c_void_p,
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.c_void_p,
+                                   ctypes.POINTER(ctypes.c_int64), ctypes.POINTER(ctypes.c_int64)]
+    payloads = np.ascontiguousarray(payloads, dtype=np.uint8)
+    npk, stride = payloads.shape
+    gets = np.zeros((npk * 512, 2), np.uint32)
+    sets = np.zeros((npk * 512, 3), np.uint32)
+    ng, ns, nb = ctypes.c_int64(0), ctypes.c_int64(0), ctypes.c_int64(0)
+    bad_packets = 0
+    for p in range(npk):
+        n = int(min(int(lens[p]), stride, 2048))
+        rc = L.orc_parse_packet(payloads[p].ctypes.data, max(n, 0), p, key_len, value_len, 1 if fold else 0,
+                                gets.ctypes.data, ctypes.byref(ng), sets.ctypes.data, ctypes.byref(ns),
+                                ctypes.byref(nb))
+        bad_packets += 1 if rc != 0 else 0
+    return gets[:ng.value].copy(), sets[:ns.value].copy(), bad_packets, nb.value
