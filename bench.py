@@ -169,11 +169,17 @@ def main():
         # the step as ONE library call per run (own RCCL communicator); all ranks agree, or all
         # fall back to the Python-driven step over torch.distributed
         ok = 1
+        import threading
+        wd = threading.Timer(300.0, lambda: (print("bench.py: RCCL communicator setup did not finish in 300 s",
+                                                   file=sys.stderr, flush=True), os._exit(19)))
+        wd.daemon = True
+        wd.start()
         try:
             engine.enable_native(dist)
         except Exception as ex:                                   # noqa: BLE001
             print(f"[rank {rank}] native sharded engine unavailable, falling back: {ex}", file=sys.stderr)
             ok = 0
+        wd.cancel()
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         if int(flag.item()) == 0:

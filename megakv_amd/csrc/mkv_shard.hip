@@ -220,6 +220,27 @@ extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
 	ncclUniqueId id;
 	memcpy(&id, id128, sizeof(id));
 	SH_NCCL(e, e->api.CommInitRank(&e->comm, e->world, id, e->rank));
+	// Self-check of the exchange before anything relies on it: block j of rank i must arrive
+	// as block i of rank j.  (With one rank every layout looks right, so this is the only
+	// place a wrong assumption about the collective would show before the results do.)
+	const int w = e->world;
+	uint32_t host[64 * 4], *dsend = nullptr, *drecv = nullptr;
+	for (int j = 0; j < w; j++)
+		for (int k = 0; k < 4; k++)
+			host[j * 4 + k] = ((uint32_t)e->rank << 16) | ((uint32_t)j << 8) | (uint32_t)k;
+	SH_HIP(e, hipMalloc(&dsend, (size_t)w * 16));
+	SH_HIP(e, hipMalloc(&drecv, (size_t)w * 16));
+	SH_HIP(e, hipMemcpy(dsend, host, (size_t)w * 16, hipMemcpyHostToDevice));
+	SH_HIP(e, hipMemset(drecv, 0xff, (size_t)w * 16));
+	SH_NCCL(e, e->api.AllToAll(dsend, drecv, 4, ncclInt32, e->comm, e->lane[0].stream));
+	SH_HIP(e, hipStreamSynchronize(e->lane[0].stream));
+	SH_HIP(e, hipMemcpy(host, drecv, (size_t)w * 16, hipMemcpyDeviceToHost));
+	(void)hipFree(dsend);
+	(void)hipFree(drecv);
+	for (int i = 0; i < w; i++)
+		for (int k = 0; k < 4; k++)
+			if (host[i * 4 + k] != (((uint32_t)i << 16) | ((uint32_t)e->rank << 8) | (uint32_t)k))
+				return fail(e, MKV_EHIP, "all-to-all self-check", "block from a peer is not where it belongs");
 	return MKV_OK;
 }
 
