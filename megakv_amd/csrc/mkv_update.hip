@@ -842,7 +842,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					// turn?  Not if it holds a duplicate, or if P (or A, or both together)
 					// has more empty slots than other round-1 registrants (each takes at
 					// most one).  Otherwise it becomes the region's barrier.
-					bool safe = eq_mask(kP.s0, kP.s1, r.sig) != 0u;
+					// (signature 0 "matches" empty slots, which anybody may fill: no duplicate to rely on)
+					bool safe = r.sig != 0u && eq_mask(kP.s0, kP.s1, r.sig) != 0u;
 					if (!safe) {
 						const uint32_t roomP = (uint32_t)__popc(eq_mask(kP.s0, kP.s1, 0u));
 						const uint32_t othP = cnt_of(cP, stamp1);
@@ -852,7 +853,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 							load_sig_row<false>(table, A, lo, hi);
 							const uint32_t roomA = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 							const uint32_t othA = cnt_of(cA, stamp1);
-							safe = eq_mask(lo, hi, r.sig) != 0u || roomA >= 1u + othA ||
+							safe = (r.sig != 0u && eq_mask(lo, hi, r.sig) != 0u) || roomA >= 1u + othA ||
 									roomP + roomA >= 1u + othP + othA;
 						}
 					}
@@ -1205,10 +1206,11 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				const bool ownP = ld_agent(&owner[P]) == key;
 				const bool ownA = A == P || ld_agent(&owner[A]) == key;
 				const unsigned long long cP = ld_agent(&cnt[P]);
-				// A duplicate only counts while nothing can evict it before this request's turn:
+				// A duplicate only counts while nothing can evict it before this request's turn
+				// (and never for signature 0, which "matches" empty slots anybody may fill):
 				// the request owns the bucket (every other registrant comes later), or no
 				// registrant has the bucket as its alternate.
-				if (eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
+				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
 					continue;
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 				const bool clean = ownP && ownA;
@@ -1217,7 +1219,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				uint32_t others = cnt_of(cP, stamp) - 1u;
 				if (A != P) {
 					load_sig_row<true>(table, A, lo, hi);
-					if (eq_mask(lo, hi, rc.x) && ownA)
+					if (rc.x != 0u && eq_mask(lo, hi, rc.x) && ownA)
 						continue;
 					room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
 					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
@@ -1355,10 +1357,11 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				const bool ownP = ld_agent(&owner[P]) == key;
 				const bool ownA = A == P || ld_agent(&owner[A]) == key;
 				const unsigned long long cP = ld_agent(&cnt[P]);
-				// A duplicate only counts while nothing can evict it before this request's turn:
+				// A duplicate only counts while nothing can evict it before this request's turn
+				// (and never for signature 0, which "matches" empty slots anybody may fill):
 				// the request owns the bucket (every other registrant comes later), or no
 				// registrant has the bucket as its alternate.
-				if (eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
+				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
 					continue;
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 				const bool clean = ownP && ownA;
@@ -1367,7 +1370,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				uint32_t others = cnt_of(cP, stamp) - 1u;
 				if (A != P) {
 					load_sig_row<true>(table, A, lo, hi);
-					if (eq_mask(lo, hi, rc.x) && ownA)
+					if (rc.x != 0u && eq_mask(lo, hi, rc.x) && ownA)
 						continue;
 					room += (uint32_t)__popc(eq_mask(lo, hi, 0u));
 					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;

@@ -39,6 +39,15 @@ def test_duplicate_evicted_before_its_turn(seed, groups, grid_min):
     _run(seed, {b"tail_rounds": 48, b"tail_groups": groups, b"grid_min": grid_min})
 
 
+def test_signature_zero_request_turns_hard_behind_others():
+    """A request with signature 0 "finds its duplicate" in any empty slot -- which the requests
+    before it may fill, after which it needs an eviction chain.  Such a match must not count
+    as a duplicate that keeps the request harmless (seed found by the fuzz campaign, chunked
+    insert of 13 519 requests with hot keys into a 60 % full table of 32 regions)."""
+    _run(2136, {b"tail_groups": 1})
+    _run(2136, {b"tail_groups": 32, b"grid_min": 0, b"tail_rounds": 48})
+
+
 def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
     L = load_library()

@@ -1,0 +1,12 @@
+#!/bin/bash
+# Runs on the GPU box: the seeded fuzz test over many seeds and forced tail shapes.
+# usage: fuzz_campaign.sh [cases]
+n=${1:-2000}
+export MKV_FUZZ_CASES=$n
+run() { echo -n "$*: "; env "$@" timeout 1200 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | grep -E "passed|failed" | tail -1; }
+run MKV_X=0
+run MKV_FUZZ_TAIL_GROUPS=1 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=1000000000
+run MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=0
+run MKV_FUZZ_TAIL_GROUPS=7 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=16 MKV_FUZZ_INSERT_CHUNK=1024
+run MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=3 MKV_FUZZ_INSERT_CHUNK=2048 MKV_FUZZ_CALM_FACTOR=1
+run MKV_FUZZ_TAIL_GROUPS=2 MKV_FUZZ_TAIL_ROUNDS=0 MKV_FUZZ_INSERT_CHUNK=65536

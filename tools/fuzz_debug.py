@@ -59,6 +59,15 @@ def main():
                 hm, bm = g.hash_mask, g.block_hash_mask
                 P = allreq[:, 1] & hm
                 A = (((allreq[:, 1] ^ allreq[:, 0]) & bm) | (allreq[:, 1] & ~np.uint32(bm))) & hm
+                # where did foreign signatures in the differing bucket come from?
+                for B in bad[:1]:
+                    for sg in set(int(x) for x in exp[B][:8]) - set(int(x) for x in before[B][:8]) - {0}:
+                        src = np.argwhere(before[:, :8] == sg)
+                        print("   sig", sg, "was at (bucket, slot)", src.tolist(), "before; requests with that sig:",
+                              np.flatnonzero(allreq[:, 0] == sg).tolist())
+                        for (b0, s0) in src.tolist():
+                            for i in np.argwhere((P == b0) | (A == b0))[:, 0]:
+                                print("      touches origin bucket", b0, ": idx", i, "sig", allreq[i, 0], "sig&7", allreq[i, 0] & 7, "P", P[i], "A", A[i])
                 for B in bad[:3]:
                     print("bucket", B, "\n before", before[B], "\n oracle", exp[B], "\n gpu   ", got[B])
                     for i in np.argwhere((P == B) | (A == B))[:, 0]:
