@@ -109,3 +109,66 @@ def _run(seed, forced):
             out = host(idx.search(dev(q), zero_miss=bool(rng.integers(0, 2))))
             ref = O.search(og, exp, q)
             assert np.array_equal(out, ref), ctx
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CYCLE_CASES", "24"))))
+def test_fuzz_cycles(seed):
+    """mkv_cycle (search + delete + insert of one worker in one call, the insert's mark pass
+    inside the search launch: the path bench.py measures) over random geometries, tables,
+    request mixes and launch variants, several cycles in a row against the oracle."""
+    rng = np.random.default_rng(9000 + seed)
+    L = load_library()
+    mem_p = int(rng.integers(10, 19))
+    iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
+    scheme = int(rng.integers(0, 2))
+    g = Geometry(mem_p=mem_p, scheme=scheme, iblock_p=iblock_p, max_cuckoo=int(rng.choice([1, 2, 5])))
+    og = ogeom(g)
+    L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 3, 48])))
+    L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 8192, 65536])))
+    L.mkv_set_tuning(b"tail_groups", int(rng.choice([1, 5, 32])))
+    L.mkv_set_tuning(b"grid_min", int(rng.choice([0, 64, 2048])))
+    sig_space = int(rng.choice([40, 5000, 1 << 20]))
+    exp = random_table(g, rng, float(rng.choice([0.0, 0.3, 0.7, 0.9])), sig_space)
+    idx = HashIndex(g)
+    idx.load_table(exp)
+    nslots = g.nbuckets * 8
+    memset = bool(rng.integers(0, 2))
+    overlap = str(rng.choice(["fused", "fused", "side", "none"]))
+    stream = torch.cuda.Stream()
+    with torch.cuda.stream(stream):
+        for step in range(3):
+            nq = int(rng.integers(0, 20000))
+            nd = int(rng.integers(0, 3000))
+            ni = int(rng.integers(0, max(2, min(30000, nslots))))
+            hot = float(rng.choice([0.0, 0.1, 0.5]))
+            q = random_requests(g, rng, nq, sig_space, hot=hot, zeros=float(rng.choice([0.0, 0.03])))[:, :2].copy()
+            d = random_requests(g, rng, nd, sig_space)
+            e = random_requests(g, rng, ni, sig_space, hot=hot, zero_low=float(rng.choice([0.0, 0.1])),
+                                zeros=float(rng.choice([0.0, 0.03])))
+            occ = np.argwhere(exp[:, :8] != 0)
+            if len(occ):
+                pick = occ[rng.integers(0, len(occ), size=min(nq, nd) // 2)]
+                q[: len(pick), 0] = exp[pick[:, 0], pick[:, 1]]
+                q[: len(pick), 1] = pick[:, 0]
+                d[: len(pick), 0] = exp[pick[:, 0], pick[:, 1]]
+                d[: len(pick), 1] = pick[:, 0]
+                d[: len(pick), 2] = exp[pick[:, 0], 8 + pick[:, 1]]
+            how = str(rng.choice(["single", "region", "uneven"]))
+            blocks = split_blocks(e, g, rng, how)
+            dblocks = [dev(b.reshape(-1, 3)) for b in blocks]
+            ptrs, cnts, keep = idx.stage_blocks(dblocks)
+            out = dev(np.full((max(nq, 1), 2), 0x5555AAAA, np.uint32))
+            dq, dd = (dev(q) if nq else None), (dev(d) if nd else None)
+            idx.cycle(dq, out if nq else None, ptrs, cnts, len(keep), delem=dd, memset=memset, overlap=overlap,
+                      stream=stream, insert_hint=int(rng.choice([0, ni])))
+            exp_out = O.search(og, exp, q)
+            if nd:
+                O.delete(og, exp, d)
+            O.insert(og, exp, blocks)
+            stream.synchronize()
+            ctx = dict(seed=seed, step=step, mem_p=mem_p, iblock_p=iblock_p, scheme=scheme, nq=nq, nd=nd, ni=ni,
+                       memset=memset, overlap=overlap, how=how)
+            if nq:
+                assert np.array_equal(host(out)[:nq], exp_out), ctx
+            got = idx.table_numpy()
+            assert np.array_equal(got, exp), (ctx, first_diff(got, exp))
