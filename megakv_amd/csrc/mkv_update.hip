@@ -62,6 +62,8 @@ constexpr uint32_t kMinRoundProgress = 24;   // in-work-group round: ~4 us again
 constexpr uint32_t kMinGridProgress = 96;    // grid-wide round: ~15 us against ~200 ns per replayed request
 constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with a long list
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
+constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished requests in order without trying rounds
+constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
 constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
 constexpr uint32_t kGridAll = 1024;
 constexpr uint32_t kGridList = 256;
@@ -541,6 +543,12 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		ctl->total = total;
 		ctl->overflow = over ? 1u : 0u;
 	}
+	if (block == 0 && t < (uint32_t)kShards) {
+		// commit counters of the rounds that follow (the tail reads them: statistics, and how
+		// much it will have to gather); cleared here, by the kernel before them in the stream
+		ctl->committed[0][t] = 0;
+		ctl->committed[1][t] = 0;
+	}
 	const uint32_t end = hi_idx < total ? hi_idx : total;
 	// requests an earlier chunk pass of this call left unresolved ride along: they have
 	// lower indices, so they win every reservation they share with this chunk's requests
@@ -902,6 +910,10 @@ __device__ __forceinline__ void wg_sync()
 // while they wait, so the others always get to run.  Release before, acquire after.
 __device__ __forceinline__ void grid_sync(uint32_t *counter, uint32_t nwg)
 {
+	if (nwg == 1u) {
+		wg_sync();
+		return;
+	}
 	wg_sync();                     // the group's stores have been issued and are visible to thread 0
 	if (threadIdx.x == 0) {
 		__threadfence();           // ... which releases them to the other groups (cumulative),
@@ -1502,15 +1514,29 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	for (uint32_t k = 0; k < g.nregions; k++)
 		any_bar |= s_bar[k] != kNone;
 	const bool work_left = any_tail || (OP == OP_CUCKOO && any_bar);
-	// The scans over the request tags (roll-back, gather) are shared by all work-groups of
-	// the launch; everything after them is work-group 0's.  Nothing to scan: the helpers
-	// leave at once (the control block only changes in work-group 0's epilogue, to the
-	// values it has in that case anyway).
-	if (wg != 0 && !work_left)
+	// The scans over the request tags (roll-back, gather) can be shared by all work-groups
+	// of the launch; everything after them is work-group 0's.  The helpers only stay when
+	// there is something to roll back or much left to gather -- judged by what every
+	// work-group reads alike: the barriers and the rounds' commit counters (both final, and
+	// only changed by the kernels before this one in the stream).
+	__shared__ uint32_t s_done12;
+	if (t < 64u) {
+		uint32_t c = ctl->committed[0][t] + ctl->committed[1][t];
+		for (int off = 32; off > 0; off >>= 1)
+			c += __shfl_down(c, off);
+		if (t == 0)
+			s_done12 = c;
+	}
+	__syncthreads();
+	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
+	const uint32_t pending_est = span > s_done12 ? span - s_done12 : 0u;
+	const bool use_helpers = nwg > 1u && ((OP == OP_CUCKOO && any_bar) || pending_est > (uint32_t)kTailAloneMax);
+	if (wg != 0 && (!work_left || !use_helpers))
 		return;
+	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
 	const uint32_t lo16 = lo_idx & ~15u;
-	const uint32_t gfirst = lo16 + (t * nwg + wg) * 16u;   // neighbouring 16-tag groups go to different work-groups
-	const uint32_t gstride = nwg * blockDim.x * 16u;
+	const uint32_t gfirst = lo16 + (t * nwg_eff + wg) * 16u;   // neighbouring 16-tag groups go to different work-groups
+	const uint32_t gstride = nwg_eff * blockDim.x * 16u;
 	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
 	uint4 *st4 = reinterpret_cast<uint4 *>(state);
 
@@ -1584,7 +1610,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
 			}
 			if (pass == 0)
-				grid_sync(&ctl->sync[0], nwg);   // every round-2 undo lands before any round-1 undo
+				grid_sync(&ctl->sync[0], nwg_eff);   // every round-2 undo lands before any round-1 undo
 		}
 		if (undone)
 			atomicAdd(&s_undone, undone);
@@ -1661,10 +1687,10 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			if (wg != 0 && s_undone)
 				atomicAdd(&ctl->undone_acc, s_undone);
 		}
-		grid_sync(&ctl->sync[1], nwg);
+		grid_sync(&ctl->sync[1], nwg_eff);
 		// a final pass left with a long list keeps every work-group for its rounds
 		const uint32_t m_all = ld_agent32(&ctl->glist_n);
-		grid_mode = last_chunk != 0 && max_rounds > 0 && nwg > 1u && m_all > grid_min;
+		grid_mode = last_chunk != 0 && max_rounds > 0 && nwg_eff > 1u && m_all > grid_min;
 		if (wg != 0 && !grid_mode)
 			return;
 		MKV_PHASE(7);
@@ -1774,8 +1800,9 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				lkeys[i] = kNone;
 		}
 		wg_sync();
+		// a handful of requests: the in-order replay is done before a round would be
 		const uint32_t left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin,
-				&s_progress, &s_par, &s_left, max_rounds, &rounds_used);
+				&s_progress, &s_par, &s_left, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &rounds_used);
 		MKV_PHASE(4);
 		if (left != 0 && in_lds) {
 			// what is left: canonical order, one request at a time
@@ -1790,9 +1817,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	MKV_PHASE(5);
 	if (t < 64) {
 		// statistics shards: one wave sums and clears them
-		uint32_t c1 = ctl->committed[0][t], c2 = ctl->committed[1][t];
-		ctl->committed[0][t] = 0;
-		ctl->committed[1][t] = 0;
+		uint32_t c1 = ctl->committed[0][t], c2 = ctl->committed[1][t];      // (cleared by the next mark pass)
 		for (int off = 32; off > 0; off >>= 1) {
 			c1 += __shfl_down(c1, off);
 			c2 += __shfl_down(c2, off);
