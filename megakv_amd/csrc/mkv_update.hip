@@ -63,6 +63,7 @@ constexpr uint32_t kMinGridProgress = 96;    // grid-wide round: ~15 us against 
 constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with a long list
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
 constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished requests in order without trying rounds
+constexpr int kTailAloneSpan = 131072; // ... or beyond this many request tags to scan
 constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
 constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
 constexpr uint32_t kGridAll = 1024;
@@ -1530,7 +1531,8 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	__syncthreads();
 	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
 	const uint32_t pending_est = span > s_done12 ? span - s_done12 : 0u;
-	const bool use_helpers = nwg > 1u && ((OP == OP_CUCKOO && any_bar) || pending_est > (uint32_t)kTailAloneMax);
+	const bool use_helpers = nwg > 1u && ((OP == OP_CUCKOO && any_bar) || pending_est > (uint32_t)kTailAloneMax ||
+			span > (uint32_t)kTailAloneSpan);     // (a long tag range is worth sharing even if little is left in it)
 	if (wg != 0 && (!work_left || !use_helpers))
 		return;
 	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
