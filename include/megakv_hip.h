@@ -117,6 +117,10 @@ int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *i
  * exact replay below a barrier, retag, in-group rounds, serial replay; two spare), summed
  * over the call's passes.  Synchronises the stream. */
 int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[8]);
+/* diagnostics: times this stream's workspace cleared its reservation tables because the
+ * 40-bit round stamps ran low (the tail kernel flags it, a later call acts on it); -1: no
+ * such workspace. */
+int mkv_debug_stamp_resets(void *stream, int cycle_insert);
 
 /* ---- request preparation on the device ------------------
  * What the reference's receiver does per packet on the CPU, for a batch of

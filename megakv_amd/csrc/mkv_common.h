@@ -91,6 +91,7 @@ struct Tuning {
 	int grid_min;           // a final tail list longer than this runs its rounds on all work-groups of the launch
 	int calm_factor;        // chunk size multiplier while no region barrier was met lately
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)
+	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)
 	int debug_skip;      // diagnostics only (breaks results): bit0 no table stores, bit1 no undo log,
 	                     // bit2 no owner loads, bit3 no bucket load, bit4 no state store
 };

@@ -78,6 +78,7 @@ Tuning &tuning()
 		v.req_cap = s ? atoll(s) : (1ll << 22);
 		if (v.req_cap < 1024) v.req_cap = 1024;
 		v.debug_skip = 0;
+		v.debug_first_stamp = 0;
 		s = getenv("MKV_MARK_BLOCKS");
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
@@ -181,6 +182,8 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 64)
 			return MKV_EINVAL;
 		t.tail_groups = (int)value;
+	} else if (!strcmp(name, "debug_first_stamp")) {
+		t.debug_first_stamp = value;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

@@ -85,6 +85,7 @@ constexpr int kShards = 64;         // statistics counters are spread over this 
 // (request index in the owner tables, registrant count in the count table).
 constexpr int kIdxBits = 24;
 constexpr unsigned long long kStampMax = (1ull << 40) - 1;
+constexpr unsigned long long kStampReserve = 1ull << 24;   // stamps left when the tables are asked to be cleared
 constexpr int64_t kMaxReqCap = (1ll << kIdxBits) - 16;
 
 struct Info {
@@ -1842,8 +1843,11 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->last.overflow = ctl->overflow;
 		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
 		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + ctl->bar_chain;
+		// bit 0: this call met region barriers; bit 1: the 40-bit round stamps are nearly used
+		// up -- the host clears the reservation tables before a later call (ensure_ws)
 		if (last_chunk && host_flag)
-			*host_flag = (ctl->last.bar_chain + ctl->bar_chain + ctl->last.bar_class + ctl->bar_class) != 0u ? 1u : 0u;
+			*host_flag = ((ctl->last.bar_chain + ctl->bar_chain + ctl->last.bar_class + ctl->bar_class) != 0u ? 1u : 0u) |
+					(ctl->stamp_base > kStampMax - kStampReserve ? 2u : 0u);
 		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->bar_class;
 		ctl->bar_chain = 0;
 		ctl->bar_class = 0;
@@ -1863,12 +1867,12 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->barrier[t] = kNone;
 }
 
-__global__ void k_init_ctl(Ctl *ctl)
+__global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
 {
 	const uint32_t t = threadIdx.x;
 	if (t == 0) {
-		ctl->stamp_base = 1;
-		ctl->next_stamp = 1 + kStampsPerCall;
+		ctl->stamp_base = first_stamp;
+		ctl->next_stamp = first_stamp + kStampsPerCall;
 		ctl->total = 0;
 		ctl->overflow = 0;
 		ctl->any_loser = ctl->any_tail = 0;
@@ -1917,6 +1921,7 @@ struct Workspace {
 	uint32_t *host_flag_dev = nullptr;
 	Chunking cycle_ck = {1, 65536, 0};    // chunking chosen by the first half of an mkv_cycle insert
 	int barrier_score = 0;             // > 0: region barriers were seen within the last few calls
+	int stamp_resets = 0;              // times the reservation tables were cleared because the stamps ran low
 };
 
 static std::mutex g_ws_mutex;
@@ -1954,6 +1959,18 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	if (!w)
 		w = new Workspace();
 	if (w->device == dev && w->nbuckets >= nbuckets && w->req_cap >= req_cap) {
+		if (w->host_flag && (*w->host_flag & 2u)) {
+			// round stamps nearly used up (tail kernel's flag, read a call or two late: the
+			// reserve covers that): start over with cleared reservation tables, in stream order
+			bool ok = hipMemsetAsync(w->owner[0], 0xff, w->nbuckets * 8, stream) == hipSuccess;
+			ok = ok && hipMemsetAsync(w->owner[1], 0xff, w->nbuckets * 8, stream) == hipSuccess;
+			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 8, stream) == hipSuccess;
+			if (!ok)
+				return MKV_EHIP;
+			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull);
+			*w->host_flag &= ~2u;
+			w->stamp_resets++;
+		}
 		*out = w;
 		return MKV_OK;
 	}
@@ -1993,7 +2010,8 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = ok && hipMemsetAsync(w->owner[1], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 8, stream) == hipSuccess;
 		if (ok)
-			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl);
+			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
+					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1));
 	}
 	if (ok && salt == kCycleSalt) {
 		ok = ok && hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking) == hipSuccess;
@@ -2050,7 +2068,7 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	// the flag is the previous call's; keep the fine-chunk mode for 16 calls after the last
 	// barrier so an occasional barrier does not meet a huge single pass
 	if (w && w->host_flag) {
-		if (*w->host_flag)
+		if (*w->host_flag & 1u)
 			w->barrier_score = tuning().barrier_sticky;
 		else if (w->barrier_score > 0)
 			w->barrier_score--;
@@ -2467,6 +2485,19 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->bar_chain = h.last.bar_chain;
 	info->bar_class = h.last.bar_class;
 	return MKV_OK;
+}
+
+// diagnostics: how often this stream's workspace cleared its reservation tables because
+// the round stamps ran low (-1: no such workspace)
+extern "C" int mkv_debug_stamp_resets(void *stream, int cycle_insert)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return -1;
+	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+	auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^
+			(cycle_insert ? mkv::kCycleSalt : 0ull));
+	return it == mkv::g_ws.end() ? -1 : it->second->stamp_resets;
 }
 
 // diagnostics: microseconds the last call's tail kernels spent per phase

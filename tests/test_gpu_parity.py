@@ -400,3 +400,36 @@ def test_cycle_is_hipgraph_replayable():
         assert np.array_equal(host(out_buf), ref_out), f"replay {rep}: search"
         got = idx.table_numpy()
         assert np.array_equal(got, exp), (rep, first_diff(got, exp))
+
+
+def test_round_stamps_running_low_clear_the_reservation_tables():
+    """The reservation tables carry 40-bit round stamps that only grow.  A workspace started
+    close to the end of that range (tests-only tuning) must ask the host to clear its tables
+    (flag written by the tail kernel, acted on by a later call) and carry on with identical
+    results -- here across a few dozen insert/delete calls, most of them with chains."""
+    L = load_library()
+    g = Geometry(mem_p=14, scheme=0)
+    og = ogeom(g)
+    L.mkv_release_all()
+    L.mkv_set_tuning(b"debug_first_stamp", (1 << 40) - (1 << 24) - 40)
+    try:
+        rng = np.random.default_rng(99)
+        exp = random_table(g, rng, 0.8, 1 << 20)
+        idx = HashIndex(g)
+        idx.load_table(exp)
+        for step in range(40):
+            e = random_requests(g, rng, int(rng.integers(200, 3000)), 1 << 20, hot=0.1)
+            if step % 5 == 4:
+                O.delete(og, exp, e)
+                idx.delete(dev(e))
+            else:
+                blocks = split_blocks(e, g, rng, "region")
+                O.insert(og, exp, blocks)
+                idx.insert([dev(b) for b in blocks])
+            got = idx.table_numpy()
+            assert np.array_equal(got, exp), (step, first_diff(got, exp))
+        from megakv_amd.index import _stream_ptr
+        assert L.mkv_debug_stamp_resets(_stream_ptr(None), 0) >= 1      # the guard really fired
+    finally:
+        L.mkv_set_tuning(b"debug_first_stamp", 0)
+        L.mkv_release_all()
