@@ -289,6 +289,65 @@ void orc_insert(const orc_geom_t *g, orc_bucket_t *table,
 	}
 }
 
+/* One host thread per insert block, for the CPU baseline only: valid when every block
+ * holds requests of one closed region and no two blocks share a region (the binning of
+ * libgpuhash/test/insert_test.c:117-124) -- regions never share a bucket, so the result
+ * equals orc_insert's.  Returns 0 and does nothing if the blocks are not binned like that. */
+struct insert_job {
+	const orc_geom_t *g;
+	orc_bucket_t *table;
+	const orc_ielem_t *in;
+	int n;
+};
+
+static void *insert_worker(void *p)
+{
+	struct insert_job *j = (struct insert_job *)p;
+	orc_stats_t st;
+	memset(&st, 0, sizeof(st));
+	for (int i = 0; i < j->n; i++) {
+		if (j->g->scheme == ORC_SCHEME_2CHOICE)
+			insert_2choice_one(j->g, j->table, &j->in[i], &st);
+		else
+			insert_cuckoo_one(j->g, j->table, &j->in[i], &st);
+	}
+	return NULL;
+}
+
+int orc_insert_mt(const orc_geom_t *g, orc_bucket_t *table, const orc_ielem_t *const *blk_input,
+		const int *blk_elem_num, int num_blks)
+{
+	const uint32_t shift = g->mem_p - 6u - g->iblock_p;
+	if (num_blks < 1 || num_blks > 64)
+		return 0;
+	int region_of[64];
+	for (int b = 0; b < num_blks; b++) {
+		region_of[b] = -1;
+		for (int i = 0; i < blk_elem_num[b]; i++) {
+			const int r = (int)(orc_primary(g, blk_input[b][i].hash) >> shift);
+			if (region_of[b] < 0)
+				region_of[b] = r;
+			else if (region_of[b] != r)
+				return 0;
+		}
+		for (int c = 0; c < b; c++)
+			if (region_of[b] >= 0 && region_of[c] == region_of[b])
+				return 0;
+	}
+	pthread_t tid[64];
+	struct insert_job jobs[64];
+	for (int b = 0; b < num_blks; b++) {
+		jobs[b].g = g;
+		jobs[b].table = table;
+		jobs[b].in = blk_input[b];
+		jobs[b].n = blk_elem_num[b];
+		pthread_create(&tid[b], NULL, insert_worker, &jobs[b]);
+	}
+	for (int b = 0; b < num_blks; b++)
+		pthread_join(tid[b], NULL);
+	return 1;
+}
+
 /* ---- delete: gpu_hash.cu:454-477 ---------------------------------------- */
 void orc_delete(const orc_geom_t *g, orc_bucket_t *table,
 		const orc_ielem_t *in, int64_t n, orc_stats_t *stats)

@@ -62,6 +62,11 @@ void orc_delete(const orc_geom_t *g, orc_bucket_t *table,
 void orc_search_mt(const orc_geom_t *g, const orc_bucket_t *table,
 		const orc_selem_t *in, uint32_t *out, int64_t n, int nthreads);
 
+/* orc_insert with one host thread per block, for blocks binned by closed region (each block
+ * one region, no region twice); returns 1, or 0 (nothing done) if they are not.  CPU baseline only. */
+int orc_insert_mt(const orc_geom_t *g, orc_bucket_t *table, const orc_ielem_t *const *blk_input,
+		const int *blk_elem_num, int num_blks);
+
 /* One UDP payload of the reference's request protocol (src/mega_recv.c:292-545,
  * README.md:70-81): appends its GETs ({sig, hash}) and SETs ({sig, hash, packet * 2048 + key
  * offset}); returns 0 or -1 like the reference's parser. */

@@ -127,6 +127,23 @@ def insert(g, table, blocks):
     return st.as_dict()
 
 
+def insert_mt(g, table, blocks):
+    """insert() with one host thread per block (blocks binned by closed region); falls back to
+    insert() when they are not.  For the CPU baseline."""
+    _check(table, 16)
+    blocks = [np.ascontiguousarray(b, dtype=np.uint32).reshape(-1, 3) for b in blocks]
+    nb = len(blocks)
+    ptrs = (ctypes.c_void_p * max(nb, 1))(*[b.ctypes.data for b in blocks])
+    cnts = (ctypes.c_int * max(nb, 1))(*[b.shape[0] for b in blocks])
+    L = lib()
+    L.orc_insert_mt.restype = ctypes.c_int
+    L.orc_insert_mt.argtypes = [ctypes.POINTER(Geom), ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_int]
+    if not L.orc_insert_mt(ctypes.byref(g), _ptr(table), ptrs, cnts, nb):
+        insert(g, table, blocks)
+        return False
+    return True
+
+
 def delete(g, table, delem):
     _check(table, 16)
     _check(delem, 3)

@@ -267,3 +267,24 @@ def test_search_mt_equals_single_thread():
     q = r.integers(0, 2**32, size=(5000, 2), dtype=np.uint64).astype(np.uint32)
     q[:, 0] %= 50
     assert np.array_equal(O.search(g, t, q), O.search(g, t, q, threads=4))
+
+
+def test_region_parallel_insert_equals_canonical_insert():
+    """orc_insert_mt (CPU baseline only: one host thread per region-binned block) gives the
+    table of the canonical single-thread insert; blocks that are not binned by region are
+    refused (and run single-threaded)."""
+    import numpy as np
+    from megakv_amd import workload as W
+    g = O.geom(mem_p=18, scheme=O.SCHEME_CUCKOO)
+    rng = np.random.default_rng(3)
+    a, b = O.new_table(g), O.new_table(g)
+    for _ in range(4):                                        # fill up until chains run
+        keys = rng.integers(1, 1 << 30, size=9000, dtype=np.uint64).astype(np.uint32)
+        blocks = W.bin_inserts(W.make_ielem(keys, None, W.KEYING_MIX), 18, 3, W.BIN_REGION)
+        O.insert(g, a, blocks)
+        assert O.insert_mt(g, b, blocks) is True
+        assert np.array_equal(a, b)
+    mixed = [np.concatenate(blocks[:2]), blocks[2]]            # first block spans two regions
+    O.insert(g, a, mixed)
+    assert O.insert_mt(g, b, mixed) is False
+    assert np.array_equal(a, b)
