@@ -107,7 +107,8 @@ class Stream:
         self.next_set = self.P + rank * span
 
     def batch(self):
-        gets = W.make_selem(self.zipf.keys(self.n_get), self.keying)
+        self.last_get_keys = self.zipf.keys(self.n_get)        # (kept for the result check after the warm-up)
+        gets = W.make_selem(self.last_get_keys, self.keying)
         if self.n_set == 0:
             return gets, np.zeros((0, 3), np.uint32)
         if self.args.sets == "new":
@@ -198,7 +199,11 @@ def main():
     # ---- distinct pre-generated batches, resident in HBM --------------------------
     nb = args.steps + args.warmup
     t0 = time.time()
-    batches = [engine.stage(*stream_gen.batch()) for _ in range(nb)]
+    batches, check_keys = [], None
+    for i in range(nb):
+        batches.append(engine.stage(*stream_gen.batch()))
+        if i == args.warmup - 1:
+            check_keys = stream_gen.last_get_keys.copy()
     torch.cuda.synchronize()
     t_gen = time.time() - t0
 
@@ -232,7 +237,9 @@ def main():
         if native and args.warmup and args.lf <= 0.5:
             # every GET key was pre-loaded or set earlier: anything but a full hit rate means the
             # exchange went wrong -> all ranks drop to the Python-driven step and warm up again
-            good = torch.tensor([1 if engine.hit_rate(batches[args.warmup - 1]) > 0.999 else 0],
+            o = batches[args.warmup - 1]["out"]
+            res0 = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
+            good = torch.tensor([1 if float((res0 == check_keys).mean()) > 0.999 else 0],
                                 dtype=torch.int32, device=device)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 0:
@@ -243,6 +250,14 @@ def main():
                 engine.run_pipelined(batches[:args.warmup])
                 run_stream.synchronize()
         hit_rate = engine.hit_rate(batches[args.warmup - 1]) if args.warmup else None
+        # stronger than a hit: the pre-load stored loc = key id, so every GET of a pre-loaded key
+        # must come back with exactly its own key id, in its own place of the result array
+        # (a result routed or un-permuted wrongly would still be "a hit")
+        loc_ok = None
+        if args.warmup and check_keys is not None and args.lf <= 0.5:
+            o = batches[args.warmup - 1]["out"]
+            res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
+            loc_ok = round(float((res == check_keys).mean()), 6)
         barrier()
         t_start = time.perf_counter()
         every = max(1, args.events_every)
@@ -310,7 +325,7 @@ def main():
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else
                        ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
-            "get_hit_rate": hit_rate, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
+            "get_hit_rate": hit_rate, "get_loc_correct": loc_ok, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
