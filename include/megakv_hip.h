@@ -156,8 +156,11 @@ int mkv_unroute_results(const loc_t *routed, const int32_t *perm, int64_t num_el
 /* ---- padded exchange format of the sharded index (no host sync in a step) ----
  * A rank packs its batch into nshards equal slots, one per peer:
  *   slot = [n_get, n_set, 0, 0 | cap_get x selem_t | cap_set x ielem_t]  (uint32 words)
- * stably, so the canonical insert order of a shard is (source rank, index).
- * perm_get[s*cap_get + r] = batch index of the r-th GET sent to shard s.
+ * SETs keep batch order, so the canonical insert order of a shard is (source rank, index);
+ * GETs of a slot are in no particular order.  perm_get[e] (n_get entries) = s * cap_get + r:
+ * GET e went to shard s at position r (-1: dropped, its slot was full) -- its result
+ * comes back at the same position (mkv_unpack_results).  `scratch` must be zero before the
+ * first call (the kernels leave it zero).
  * *overflow is set to 1 when a slot cannot hold its requests (they are dropped). */
 int64_t mkv_pack_slot_words(int64_t cap_get, int64_t cap_set);
 int64_t mkv_pack_scratch_bytes(int64_t n_get, int64_t n_set, int nshards);
@@ -178,9 +181,9 @@ int mkv_search_slots(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots
 int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
 		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
 		void *stream, void *timer, int slot);
-/* out[perm_get[pos]] = back[pos] for every position that carried a request. */
-int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf, int nshards,
-		int64_t cap_get, int64_t cap_set, loc_t *out, void *stream);
+/* out[e] = back[where[e]] for the n_get requests of the batch that was packed with
+ * perm_get = where (a request that was dropped by an overflowing slot gets 0). */
+int mkv_unpack_results(const loc_t *back, const int32_t *where, int64_t n_get, loc_t *out, void *stream);
 
 /* Request packets of the reference's protocol on the device (src/mega_recv.c:292-545,
  * README.md:70-81): payloads = npackets UDP payloads at `stride` bytes (a multiple of 4,

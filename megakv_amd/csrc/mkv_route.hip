@@ -341,14 +341,14 @@ __global__ __launch_bounds__(256) void k_pack_scatter(const uint32_t *__restrict
 			p[1] = w1;
 			if (is_set)
 				p[2] = w2;
-			else
-				perm_get[(int64_t)s * cap_get + dst] = (int32_t)e;
 		}
+		if (live && !is_set)
+			perm_get[e] = dst < cap ? (int32_t)((int64_t)s * cap_get + dst) : -1;   // where request e went
 	}
 }
 
 // ---- one-launch pack ----------------------------------------------------------
-// GET tiles place their requests with atomics (order inside a slot is free: `perm`
+// GET tiles place their requests with atomics (order inside a slot is free: `where`
 // brings every result home); SET tiles keep batch order -- per-tile counts, one meeting
 // of the SET tiles, prefix over the earlier tiles, ranked scatter.  The last work-group
 // to finish writes the slot headers and clears the control words for the next call.
@@ -495,10 +495,15 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 				if (lane == k)
 					cursor += (uint32_t)__popcll(m);
 			}
-			if (sh[it] != 0xffffffffu && dst < cap_get) {
-				uint2 *p = reinterpret_cast<uint2 *>(sendbuf + (int64_t)sh[it] * slot_words + kHdrWords) + dst;
-				*p = rq[it];
-				perm_get[(int64_t)sh[it] * cap_get + dst] = (int32_t)((int64_t)tile * kPackTile + it * 256 + t);
+			if (sh[it] != 0xffffffffu) {
+				if (dst < cap_get) {
+					uint2 *p = reinterpret_cast<uint2 *>(sendbuf + (int64_t)sh[it] * slot_words + kHdrWords) + dst;
+					*p = rq[it];
+				}
+				// where the request went (its result comes back to the same place): written in
+				// request order, i.e. coalesced -- the un-pack gathers through it
+				perm_get[(int64_t)tile * kPackTile + it * 256 + t] =
+						dst < cap_get ? (int32_t)((int64_t)sh[it] * cap_get + dst) : -1;
 			}
 		}
 	}
@@ -544,19 +549,16 @@ __global__ __launch_bounds__(256) void k_search_slots(const uint32_t *__restrict
 			chunks_per_slot);
 }
 
-// results come back in the layout they were sent in: result of slot s, position r
-// belongs to original request perm[s*cap_get + r]
+// results come back in the layout the requests were sent in; request e went to position
+// where[e] (slot * cap_get + rank), so its result is gathered from there: coalesced writes,
+// 8-byte gathers from a buffer the exchange has just written
 __global__ __launch_bounds__(256) void k_unpack_results(const uint2 *__restrict__ back,
-		const int32_t *__restrict__ perm_get, const uint32_t *__restrict__ sendbuf, int64_t slot_words,
-		uint32_t cap_get, int nshards, uint2 *__restrict__ out)
+		const int32_t *__restrict__ where, int64_t n_get, uint2 *__restrict__ out)
 {
-	const int64_t total = (int64_t)nshards * cap_get;
-	for (int64_t pos = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; pos < total;
-			pos += (int64_t)gridDim.x * blockDim.x) {
-		const uint32_t s = (uint32_t)(pos / cap_get);
-		const uint32_t r = (uint32_t)(pos - (int64_t)s * cap_get);
-		if (r < sendbuf[(int64_t)s * slot_words])
-			out[perm_get[pos]] = back[pos];
+	for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_get;
+			e += (int64_t)gridDim.x * blockDim.x) {
+		const int32_t w = where[e];
+		out[e] = w >= 0 ? back[w] : make_uint2(0u, 0u);
 	}
 }
 
@@ -642,20 +644,18 @@ extern "C" int mkv_search_slots(const mkv_geom_t *geom, const uint32_t *recvbuf,
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
-extern "C" int mkv_unpack_results(const loc_t *back, const int32_t *perm_get, const uint32_t *sendbuf,
-		int nshards, int64_t cap_get, int64_t cap_set, loc_t *out, void *stream)
+extern "C" int mkv_unpack_results(const loc_t *back, const int32_t *where, int64_t n_get, loc_t *out,
+		void *stream)
 {
-	if (nshards < 1 || cap_get < 0 || !back || !perm_get || !sendbuf || !out)
+	if (n_get < 0 || (n_get && (!back || !where || !out)))
 		return MKV_EINVAL;
-	const int64_t total = (int64_t)nshards * cap_get;
-	if (total == 0)
+	if (n_get == 0)
 		return MKV_OK;
-	int64_t blocks = (total + 255) / 256;
-	if (blocks > 2048)
-		blocks = 2048;
+	int64_t blocks = (n_get + 255) / 256;
+	if (blocks > 4096)
+		blocks = 4096;
 	hipLaunchKernelGGL(mkv::k_unpack_results, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
-			reinterpret_cast<const uint2 *>(back), perm_get, sendbuf, mkv_pack_slot_words(cap_get, cap_set),
-			(uint32_t)cap_get, nshards, reinterpret_cast<uint2 *>(out));
+			reinterpret_cast<const uint2 *>(back), where, n_get, reinterpret_cast<uint2 *>(out));
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

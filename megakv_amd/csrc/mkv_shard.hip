@@ -176,7 +176,7 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		SH_HIP(e, hipMalloc(&l.recvbuf, slot_bytes));
 		SH_HIP(e, hipMalloc(&l.out_slots, res_bytes));
 		SH_HIP(e, hipMalloc(&l.back_slots, res_bytes));
-		SH_HIP(e, hipMalloc(&l.perm, (size_t)world * (size_t)(cap_get ? cap_get : 1) * sizeof(int32_t)));
+		SH_HIP(e, hipMalloc(&l.perm, (size_t)(n_get ? n_get : 1) * sizeof(int32_t)));   // where each GET went
 		SH_HIP(e, hipMalloc(&l.scratch, (size_t)e->scratch_bytes + 64));
 		SH_HIP(e, hipMemset(l.sendbuf, 0, slot_bytes));
 		SH_HIP(e, hipMemset(l.recvbuf, 0, slot_bytes));
@@ -256,11 +256,10 @@ static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, co
 	return MKV_OK;
 }
 
-static int backward(mkv_shard *e, Lane &l, loc_t *out)
+static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get)
 {
 	SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
-	const int rc = mkv_unpack_results(l.back_slots, l.perm, l.sendbuf, e->world, e->cap_get, e->cap_set, out,
-			l.stream);
+	const int rc = mkv_unpack_results(l.back_slots, l.perm, n_get, out, l.stream);
 	if (rc != MKV_OK)
 		return fail(e, rc, "mkv_unpack_results", nullptr);
 	return MKV_OK;
@@ -311,7 +310,7 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 			return fail(e, rc, "mkv_slots_cycle", nullptr);
 		prev_local = l.ev_local[(i / L) & 1];
 		SH_HIP(e, hipEventRecord(prev_local, l.stream));
-		rc = backward(e, l, outs[i]);
+		rc = backward(e, l, outs[i], n_get[i]);
 		if (rc != MKV_OK)
 			return rc;
 	}

@@ -125,7 +125,7 @@ def load_library():
     L.mkv_resolve_results.restype = INT
     L.mkv_resolve_results.argtypes = [P, I64, P, P, P]
     L.mkv_unpack_results.restype = INT
-    L.mkv_unpack_results.argtypes = [P, P, P, INT, I64, I64, P, P]
+    L.mkv_unpack_results.argtypes = [P, P, I64, P, P]
     L.mkv_unroute_results.restype = INT
     L.mkv_unroute_results.argtypes = [P, P, I64, P, P]
     L.mkv_set_tuning.restype = INT

@@ -107,8 +107,8 @@ class HipOps:
                                         ctypes.c_void_p(timer) if timer else null, slot), "mkv_slots_cycle")
 
     def unpack(self, back, perm, sendbuf, g, cap_get, cap_set, out, stream=None):
-        _check(self.lib.mkv_unpack_results(_dev_ptr(back), _dev_ptr(perm), _dev_ptr(sendbuf), g, cap_get,
-                                           cap_set, _dev_ptr(out), self._sp(stream)), "mkv_unpack_results")
+        _check(self.lib.mkv_unpack_results(_dev_ptr(back), _dev_ptr(perm), out.shape[0], _dev_ptr(out),
+                                           self._sp(stream)), "mkv_unpack_results")
 
     def slot_set_pointers(self, recvbuf, g, slot_words, cap_get):
         base = recvbuf.data_ptr()

@@ -25,7 +25,8 @@ def test_sharded_pipelined_two_lanes(world):
 def test_pack_layout(g, n_get, n_set, three_pass):
     """mkv_pack_requests: every request lands in the slot of its shard; SET slots keep
     batch order (the canonical insert order of a shard is source rank, then index); GET
-    slots hold the right requests in any order with `perm` pointing home; headers count."""
+    slots hold the right requests in any order, `perm[e]` telling where request e went;
+    headers count."""
     import ctypes
     import numpy as np
     import torch
@@ -62,14 +63,18 @@ def test_pack_layout(g, n_get, n_set, three_pass):
             assert int(overflow.item()) == 0
             gsh = (gets[:, 1] & mask) >> shift
             ssh = (sets[:, 1] & mask) >> shift
+            where = pm[:n_get]
+            if n_get:
+                assert (where >= 0).all() and len(np.unique(where)) == n_get           # every GET has its own place
+                assert np.array_equal(where // cap_get, gsh)                            # ... in the slot of its shard
             for s in range(g):
                 want_g = np.flatnonzero(gsh == s)
                 want_s = np.flatnonzero(ssh == s)
                 assert sb[s, 0] == len(want_g) and sb[s, 1] == len(want_s) and sb[s, 2] == 0 and sb[s, 3] == 0
-                got_g = sb[s, 4:4 + 2 * len(want_g)].reshape(-1, 2)
-                home = pm[s * cap_get:s * cap_get + len(want_g)]
-                assert np.array_equal(np.sort(home), want_g)
-                assert np.array_equal(got_g, gets[home])
+                got_g = sb[s, 4:4 + 2 * cap_get].reshape(-1, 2)
+                pos = where[want_g] - s * cap_get
+                assert (pos < len(want_g)).all()                                        # packed densely
+                assert np.array_equal(got_g[pos], gets[want_g])
                 got_s = sb[s, 4 + 2 * cap_get:4 + 2 * cap_get + 3 * len(want_s)].reshape(-1, 3)
                 assert np.array_equal(got_s, sets[want_s])
     finally:
