@@ -62,6 +62,40 @@ struct mkv_shard {
 	char err[256] = {0};
 };
 
+// MKV_SHARD_TRACE=n (diagnostics): device timestamps around every operation of n batches
+// near the end of a run (events with timing; the run is synchronised at its end and the
+// table goes to stderr)
+namespace {
+struct TraceRec { const char *what; int lane, batch; hipEvent_t a, b; };
+struct Trace {
+	int on = -1, n = 0;
+	TraceRec rec[512];
+};
+Trace g_trace;
+
+struct Span {
+	TraceRec *r = nullptr;
+	hipStream_t s;
+	Span(const char *what, int lane, int batch, hipStream_t stream, bool active) : s(stream)
+	{
+		if (!active || g_trace.n >= 512)
+			return;
+		r = &g_trace.rec[g_trace.n++];
+		r->what = what;
+		r->lane = lane;
+		r->batch = batch;
+		(void)hipEventCreate(&r->a);
+		(void)hipEventCreate(&r->b);
+		(void)hipEventRecord(r->a, s);
+	}
+	~Span()
+	{
+		if (r)
+			(void)hipEventRecord(r->b, s);
+	}
+};
+}  // namespace
+
 static int fail(mkv_shard *e, int code, const char *what, const char *detail)
 {
 	snprintf(e->err, sizeof(e->err), "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
@@ -244,21 +278,31 @@ extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
 	return MKV_OK;
 }
 
-static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set)
+static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		int lane, int batch, bool tr)
 {
 	if (n_get > e->n_get || n_set > e->n_set)
 		return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
-	const int rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
-			e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
+	int rc;
+	{
+		Span sp("pack", lane, batch, l.stream, tr);
+		rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
+				e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
+	}
 	if (rc != MKV_OK)
 		return fail(e, rc, "mkv_pack_requests", nullptr);
+	Span sp("a2a-fwd", lane, batch, l.stream, tr);
 	SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
 	return MKV_OK;
 }
 
-static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get)
+static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get, int lane, int batch, bool tr)
 {
-	SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
+	{
+		Span sp("a2a-back", lane, batch, l.stream, tr);
+		SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
+	}
+	Span sp("unpack", lane, batch, l.stream, tr);
 	const int rc = mkv_unpack_results(l.back_slots, l.perm, n_get, out, l.stream);
 	if (rc != MKV_OK)
 		return fail(e, rc, "mkv_unpack_results", nullptr);
@@ -280,6 +324,12 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 		return MKV_OK;
 	hipStream_t main = (hipStream_t)stream;
 	const int L = e->nlanes;
+	if (g_trace.on < 0) {
+		const char *v = getenv("MKV_SHARD_TRACE");
+		g_trace.on = v ? atoi(v) : 0;
+	}
+	const int trace_from = g_trace.on > 0 && nbatches > g_trace.on + 16 ? nbatches - g_trace.on - 8 : nbatches + 1;
+	g_trace.n = 0;
 	SH_HIP(e, hipEventRecord(e->ev_start, main));
 	for (int li = 0; li < L; li++)
 		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
@@ -287,30 +337,34 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	// L batches in flight: the forward half of batch i+L-1 is queued before the local phase
 	// of batch i, so a lane has the time of L-1 local phases for its exchanges
 	for (int j = 0; j < L - 1 && j < nbatches; j++) {
-		rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j]);
+		rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j], j % L, j, false);
 		if (rc != MKV_OK)
 			return rc;
 	}
 	hipEvent_t prev_local = nullptr;
 	for (int i = 0; i < nbatches; i++) {
 		Lane &l = e->lane[i % L];
+		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
 		const int j = i + L - 1;
 		if (j < nbatches) {
-			rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j]);
+			rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j], j % L, j, tr);
 			if (rc != MKV_OK)
 				return rc;
 		}
 		if (prev_local)
 			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
 		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
-		rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
-				e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, l.stream, timed ? timer : nullptr,
-				timed ? i / timer_every : 0);
+		{
+			Span sp("local", i % L, i, l.stream, tr);
+			rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
+					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, l.stream, timed ? timer : nullptr,
+					timed ? i / timer_every : 0);
+		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_slots_cycle", nullptr);
 		prev_local = l.ev_local[(i / L) & 1];
 		SH_HIP(e, hipEventRecord(prev_local, l.stream));
-		rc = backward(e, l, outs[i], n_get[i]);
+		rc = backward(e, l, outs[i], n_get[i], i % L, i, tr);
 		if (rc != MKV_OK)
 			return rc;
 	}
@@ -318,6 +372,22 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 		Lane &l = e->lane[li];
 		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
 		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
+	}
+	if (g_trace.n) {
+		(void)hipDeviceSynchronize();
+		for (int k = 0; k < g_trace.n; k++) {
+			float t0 = 0, t1 = 0;
+			(void)hipEventElapsedTime(&t0, g_trace.rec[0].a, g_trace.rec[k].a);
+			(void)hipEventElapsedTime(&t1, g_trace.rec[0].a, g_trace.rec[k].b);
+			fprintf(stderr, "%8.1f -> %8.1f  lane %d %*s%-8s batch %d (%.1f us)\n", t0 * 1e3, t1 * 1e3,
+					g_trace.rec[k].lane, g_trace.rec[k].lane * 6, "", g_trace.rec[k].what, g_trace.rec[k].batch,
+					(t1 - t0) * 1e3);
+		}
+		for (int k = 0; k < g_trace.n; k++) {
+			(void)hipEventDestroy(g_trace.rec[k].a);
+			(void)hipEventDestroy(g_trace.rec[k].b);
+		}
+		g_trace.n = 0;
 	}
 	return MKV_OK;
 }
