@@ -32,6 +32,8 @@ struct Rccl {
 	ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
 	ncclResult_t (*AllToAll)(const void *, void *, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
+	ncclResult_t (*GroupStart)() = nullptr;
+	ncclResult_t (*GroupEnd)() = nullptr;
 };
 
 struct Lane {
@@ -43,6 +45,12 @@ struct Lane {
 	ielem_t **set_ptrs = nullptr;
 	hipEvent_t ev_local[2] = {nullptr, nullptr};   // alternated so a pending wait keeps its event
 	hipEvent_t ev_done = nullptr;
+	// fused-exchange schedule: packs run on a stream of their own, into alternating `where` arrays
+	hipStream_t aux = nullptr;
+	int32_t *perm2[2] = {nullptr, nullptr};
+	hipEvent_t ev_xchg[2] = {nullptr, nullptr};    // the exchange that carried the lane's requests is done
+	hipEvent_t ev_pack[2] = {nullptr, nullptr};    // the lane's next batch is packed
+	hipEvent_t ev_aux_done = nullptr;
 };
 
 }  // namespace
@@ -54,6 +62,8 @@ struct mkv_shard {
 	int64_t n_get = 0, n_set = 0, cap_get = 0, cap_set = 0, slot_words = 0, scratch_bytes = 0;
 	uint32_t agg_mask = 0, shift = 0;
 	int *overflow = nullptr;
+	int fused = 0;                  // MKV_SHARD_FUSED=1: one grouped collective per batch (run_fused; measured
+	                                // slower on this host: more API calls per step than the GPU time it saves)
 	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
 	Lane lane[4];
 	hipEvent_t ev_start = nullptr;
@@ -141,6 +151,13 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 		for (hipEvent_t ev : l.ev_local)
 			if (ev) (void)hipEventDestroy(ev);
 		if (l.ev_done) (void)hipEventDestroy(l.ev_done);
+		if (l.perm2[1]) (void)hipFree(l.perm2[1]);
+		for (hipEvent_t ev : l.ev_xchg)
+			if (ev) (void)hipEventDestroy(ev);
+		for (hipEvent_t ev : l.ev_pack)
+			if (ev) (void)hipEventDestroy(ev);
+		if (l.ev_aux_done) (void)hipEventDestroy(l.ev_aux_done);
+		if (l.aux) (void)hipStreamDestroy(l.aux);
 		if (l.stream) (void)hipStreamDestroy(l.stream);
 	}
 	if (e->overflow) (void)hipFree(e->overflow);
@@ -179,6 +196,8 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		if (n >= 2 && n <= 4)
 			e->nlanes = n;
 	}
+	if (const char *v = getenv("MKV_SHARD_FUSED"))
+		e->fused = atoi(v) != 0;
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
 	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
 
@@ -196,6 +215,8 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	SH_SYM(CommDestroy, "ncclCommDestroy");
 	SH_SYM(AllToAll, "ncclAllToAll");
 	SH_SYM(GetErrorString, "ncclGetErrorString");
+	SH_SYM(GroupStart, "ncclGroupStart");
+	SH_SYM(GroupEnd, "ncclGroupEnd");
 #undef SH_SYM
 
 	SH_HIP(e, hipMalloc(&e->overflow, sizeof(int)));
@@ -225,6 +246,14 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		for (hipEvent_t &ev : l.ev_local)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		SH_HIP(e, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
+		SH_HIP(e, hipStreamCreateWithFlags(&l.aux, hipStreamNonBlocking));
+		l.perm2[0] = l.perm;
+		SH_HIP(e, hipMalloc(&l.perm2[1], (size_t)(n_get ? n_get : 1) * sizeof(int32_t)));
+		for (hipEvent_t &ev : l.ev_xchg)
+			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		for (hipEvent_t &ev : l.ev_pack)
+			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		SH_HIP(e, hipEventCreateWithFlags(&l.ev_aux_done, hipEventDisableTiming));
 		if (cap_set) {
 			const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, l.stream);
 			if (rc != MKV_OK)
@@ -309,6 +338,114 @@ static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get, int lane, 
 	return MKV_OK;
 }
 
+static void print_trace()
+{
+	if (g_trace.n) {
+		(void)hipDeviceSynchronize();
+		for (int k = 0; k < g_trace.n; k++) {
+			float t0 = 0, t1 = 0;
+			(void)hipEventElapsedTime(&t0, g_trace.rec[0].a, g_trace.rec[k].a);
+			(void)hipEventElapsedTime(&t1, g_trace.rec[0].a, g_trace.rec[k].b);
+			fprintf(stderr, "%8.1f -> %8.1f  lane %d %*s%-8s batch %d (%.1f us)\n", t0 * 1e3, t1 * 1e3,
+					g_trace.rec[k].lane, g_trace.rec[k].lane * 6, "", g_trace.rec[k].what, g_trace.rec[k].batch,
+					(t1 - t0) * 1e3);
+		}
+		for (int k = 0; k < g_trace.n; k++) {
+			(void)hipEventDestroy(g_trace.rec[k].a);
+			(void)hipEventDestroy(g_trace.rec[k].b);
+		}
+		g_trace.n = 0;
+	}
+}
+
+// The schedule with ONE collective launch per batch: behind the local phase of batch i a
+// group of two all-to-alls carries the results of batch i back and the requests of batch
+// i+2 out (same lane).  The requests of batch i+1 went out a step earlier, so between two
+// local phases nothing but the event chain remains; exchange, un-pack and the pack of the
+// batch after next (on a stream of its own) all run beside the other lane's local phase.
+// Collective order on every rank: fwd(0), fwd(1), {back(0), fwd(2)}, {back(1), fwd(3)}, ...
+static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, hipStream_t main, void *timer,
+		int timer_every, int trace_from)
+{
+	SH_HIP(e, hipEventRecord(e->ev_start, main));
+	for (int li = 0; li < 2; li++) {
+		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
+		SH_HIP(e, hipStreamWaitEvent(e->lane[li].aux, e->ev_start, 0));
+	}
+	auto pack = [&](Lane &l, int j, hipStream_t s, int lane, bool tr) -> int {
+		if (n_get[j] > e->n_get || n_set[j] > e->n_set)
+			return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
+		Span sp("pack", lane, j, s, tr);
+		const int rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world,
+				l.sendbuf, e->cap_get, e->cap_set, l.perm2[(j / 2) & 1], l.scratch, e->scratch_bytes, e->overflow, s);
+		return rc == MKV_OK ? MKV_OK : fail(e, rc, "mkv_pack_requests", nullptr);
+	};
+	int rc = MKV_OK;
+	for (int j = 0; j < 2 && j < nbatches; j++) {
+		Lane &l = e->lane[j];
+		if ((rc = pack(l, j, l.stream, j, false)) != MKV_OK)
+			return rc;
+		SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
+		SH_HIP(e, hipEventRecord(l.ev_xchg[0], l.stream));
+	}
+	hipEvent_t prev_local = nullptr;
+	for (int i = 0; i < nbatches; i++) {
+		Lane &l = e->lane[i & 1];
+		const int lane = i & 1, k = (i / 2) & 1, k2 = k ^ 1;
+		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
+		const bool more = i + 2 < nbatches;
+		if (more) {
+			// the lane's send buffers are free once the exchange that carried batch i is done
+			SH_HIP(e, hipStreamWaitEvent(l.aux, l.ev_xchg[k], 0));
+			if ((rc = pack(l, i + 2, l.aux, lane, tr)) != MKV_OK)
+				return rc;
+			SH_HIP(e, hipEventRecord(l.ev_pack[k2], l.aux));
+		}
+		if (prev_local)
+			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
+		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
+		{
+			Span sp("local", lane, i, l.stream, tr);
+			rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
+					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, l.stream, timed ? timer : nullptr,
+					timed ? i / timer_every : 0);
+		}
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_slots_cycle", nullptr);
+		prev_local = l.ev_local[k];
+		SH_HIP(e, hipEventRecord(prev_local, l.stream));
+		if (more)
+			SH_HIP(e, hipStreamWaitEvent(l.stream, l.ev_pack[k2], 0));
+		{
+			Span sp("exchange", lane, i, l.stream, tr);
+			SH_NCCL(e, e->api.GroupStart());
+			ncclResult_t r1 = e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm,
+					l.stream);
+			ncclResult_t r2 = more ? e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32,
+					e->comm, l.stream) : ncclSuccess;
+			SH_NCCL(e, e->api.GroupEnd());
+			SH_NCCL(e, r1);
+			SH_NCCL(e, r2);
+		}
+		SH_HIP(e, hipEventRecord(l.ev_xchg[k2], l.stream));
+		{
+			Span sp("unpack", lane, i, l.stream, tr);
+			rc = mkv_unpack_results(l.back_slots, l.perm2[k], n_get[i], outs[i], l.stream);
+		}
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_unpack_results", nullptr);
+	}
+	for (int li = 0; li < 2; li++) {
+		Lane &l = e->lane[li];
+		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
+		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
+		SH_HIP(e, hipEventRecord(l.ev_aux_done, l.aux));
+		SH_HIP(e, hipStreamWaitEvent(main, l.ev_aux_done, 0));
+	}
+	return MKV_OK;
+}
+
 // nbatches batches of this rank: gets[i] (n_get[i] x selem_t), sets[i] (n_set[i] x ielem_t),
 // outs[i] (n_get[i] x 2 loc_t, request order) -- all device pointers, host arrays of them.
 // Everything is enqueued (no host synchronisation); the lanes start after what is queued
@@ -330,10 +467,16 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	}
 	const int trace_from = g_trace.on > 0 && nbatches > g_trace.on + 16 ? nbatches - g_trace.on - 8 : nbatches + 1;
 	g_trace.n = 0;
+	int rc = MKV_OK;
+	if (e->fused && L == 2) {
+		rc = run_fused(e, nbatches, gets, n_get, sets, n_set, outs, main, timer, timer_every, trace_from);
+		if (rc == MKV_OK)
+			print_trace();
+		return rc;
+	}
 	SH_HIP(e, hipEventRecord(e->ev_start, main));
 	for (int li = 0; li < L; li++)
 		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
-	int rc = MKV_OK;
 	// L batches in flight: the forward half of batch i+L-1 is queued before the local phase
 	// of batch i, so a lane has the time of L-1 local phases for its exchanges
 	for (int j = 0; j < L - 1 && j < nbatches; j++) {
@@ -373,22 +516,7 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
 		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
 	}
-	if (g_trace.n) {
-		(void)hipDeviceSynchronize();
-		for (int k = 0; k < g_trace.n; k++) {
-			float t0 = 0, t1 = 0;
-			(void)hipEventElapsedTime(&t0, g_trace.rec[0].a, g_trace.rec[k].a);
-			(void)hipEventElapsedTime(&t1, g_trace.rec[0].a, g_trace.rec[k].b);
-			fprintf(stderr, "%8.1f -> %8.1f  lane %d %*s%-8s batch %d (%.1f us)\n", t0 * 1e3, t1 * 1e3,
-					g_trace.rec[k].lane, g_trace.rec[k].lane * 6, "", g_trace.rec[k].what, g_trace.rec[k].batch,
-					(t1 - t0) * 1e3);
-		}
-		for (int k = 0; k < g_trace.n; k++) {
-			(void)hipEventDestroy(g_trace.rec[k].a);
-			(void)hipEventDestroy(g_trace.rec[k].b);
-		}
-		g_trace.n = 0;
-	}
+	print_trace();
 	return MKV_OK;
 }
 

@@ -81,8 +81,8 @@ def test_pack_layout(g, n_get, n_set, three_pass):
         L.mkv_set_tuning(b"pack_three_pass", 0)
 
 
-@pytest.mark.parametrize("scheme", [0, 1])
-def test_native_engine_one_rank_through_rccl(scheme):
+@pytest.mark.parametrize("scheme,fused", [(0, 0), (1, 0), (0, 1)])
+def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
     """The C engine (mkv_shard_*: pack, ncclAllToAll, local search+insert, result exchange,
     unpack; two batches in flight) with a one-rank communicator -- the only RCCL shape a
     one-GPU box can run -- against the oracle, results and final table."""
@@ -90,6 +90,7 @@ def test_native_engine_one_rank_through_rccl(scheme):
     import torch
     from megakv_amd.sharded import ShardedIndex
     from oracle import oracle as O
+    monkeypatch.setenv("MKV_SHARD_FUSED", str(fused))      # the engine reads it when it is created
     mem_p = 16
     rng = np.random.default_rng(77 + scheme)
     n_get, n_set = 6000, 900
