@@ -202,3 +202,66 @@ extern "C" int mkv_tuning_is_default_search(void)
 	const mkv::Tuning &t = mkv::tuning();
 	return t.search_u == 4 && t.search_nt == 0;
 }
+
+// ---- diagnostics: what the memory system gives for random reads ---------------------
+// Every 4-lane group reads `gran`-byte aligned pieces (64, 128 or 256 bytes: 16 bytes per
+// lane and step) at pseudo-random places of a buffer, `unroll` pieces in flight per group
+// like the search kernel -- no hashing, no compare, no result but a checksum.  The rate
+// this reaches is the ceiling for a kernel whose every request is two random buckets.
+namespace mkv {
+
+template <int GRAN, int U>
+__global__ __launch_bounds__(256) void k_random_read(const uint4 *__restrict__ buf, uint64_t pieces_mask,
+		int64_t pieces_per_group, uint32_t *__restrict__ sink, uint32_t seed)
+{
+	const uint32_t lane4 = threadIdx.x & 3u;
+	const uint64_t group = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2;
+	uint64_t x = (group + 1u) * 0x9e3779b97f4a7c15ull + seed;
+	uint32_t acc = 0;
+	for (int64_t it = 0; it < pieces_per_group; it += U) {
+		uint4 v[U][GRAN / 64];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			x ^= x >> 12;
+			x ^= x << 25;
+			x ^= x >> 27;
+			const uint64_t piece = (x * 0x2545f4914f6cdd1dull >> 20) & pieces_mask;
+			const uint4 *p = buf + piece * (GRAN / 16) + lane4;
+#pragma unroll
+			for (int k = 0; k < GRAN / 64; k++)
+				v[u][k] = p[k * 4];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+#pragma unroll
+			for (int k = 0; k < GRAN / 64; k++)
+				acc ^= v[u][k].x ^ v[u][k].y ^ v[u][k].z ^ v[u][k].w;
+	}
+	if (acc == 0x12345678u)
+		sink[0] = acc;          // (keeps the loads alive)
+}
+
+}  // namespace mkv
+
+// reads `groups` x pieces_per_group pieces of gran bytes from buf (buf_bytes: a power of two);
+// returns the bytes read, or a negative error
+extern "C" long long mkv_debug_random_read(const void *buf, long long buf_bytes, int gran, long long groups,
+		long long pieces_per_group, uint32_t *sink, void *stream)
+{
+	if (!buf || !sink || buf_bytes < 4096 || (buf_bytes & (buf_bytes - 1)) || groups < 64 || pieces_per_group < 4 ||
+			(pieces_per_group & 3) || (gran != 64 && gran != 128 && gran != 256))
+		return MKV_EINVAL;
+	const uint64_t mask = (uint64_t)buf_bytes / (uint64_t)gran - 1u;
+	const dim3 grid((unsigned)((groups * 4 + 255) / 256)), block(256);
+	const uint4 *b = reinterpret_cast<const uint4 *>(buf);
+	hipStream_t s = (hipStream_t)stream;
+	if (gran == 64)
+		hipLaunchKernelGGL((mkv::k_random_read<64, 4>), grid, block, 0, s, b, mask, pieces_per_group, sink, 1u);
+	else if (gran == 128)
+		hipLaunchKernelGGL((mkv::k_random_read<128, 4>), grid, block, 0, s, b, mask, pieces_per_group, sink, 1u);
+	else
+		hipLaunchKernelGGL((mkv::k_random_read<256, 4>), grid, block, 0, s, b, mask, pieces_per_group, sink, 1u);
+	if (hipGetLastError() != hipSuccess)
+		return MKV_EHIP;
+	return (long long)grid.x * 64 * pieces_per_group * gran;
+}

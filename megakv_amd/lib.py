@@ -31,7 +31,7 @@ ABI_SYMBOLS = [
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
     "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
-    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
@@ -86,6 +86,8 @@ def load_library():
     L.mkv_last_update_info.argtypes = [P, ctypes.POINTER(MkvUpdateInfo)]
     L.mkv_last_update_info_ex.restype = INT
     L.mkv_last_update_info_ex.argtypes = [P, INT, ctypes.POINTER(MkvUpdateInfo)]
+    L.mkv_debug_random_read.restype = ctypes.c_longlong
+    L.mkv_debug_random_read.argtypes = [P, ctypes.c_longlong, INT, ctypes.c_longlong, ctypes.c_longlong, P, P]
     L.mkv_debug_stamp_resets.restype = INT
     L.mkv_debug_stamp_resets.argtypes = [P, INT]
     L.mkv_debug_tail_phases.restype = INT
