@@ -31,7 +31,7 @@ def random_table(g: Geometry, rng, fill, sig_space):
     return t
 
 
-def random_requests(g: Geometry, rng, n, sig_space, hot=0.0, zero_low=0.0, zeros=0.0):
+def random_requests(g: Geometry, rng, n, sig_space, hot=0.0, zero_low=0.0, zeros=0.0, shape="random"):
     """[n,3] (sig, hash, loc).  hot: fraction drawn from 4 hot keys; zero_low:
     fraction whose signature has no region-local bits (alternate == primary);
     zeros: fraction of sig == 0 requests (half of them with loc == 0 too)."""
@@ -39,6 +39,17 @@ def random_requests(g: Geometry, rng, n, sig_space, hot=0.0, zero_low=0.0, zeros
     e[:, 0] = rng.integers(1, sig_space + 1, size=n)
     e[:, 1] = rng.integers(0, 2**32, size=n, dtype=np.uint64)
     e[:, 2] = rng.integers(1, 2**32, size=n, dtype=np.uint64)
+    if shape == "ref" and n:
+        # the reference's LOCAL_TEST keying on sequential ids: sig = k, hash = (k & 7) << 29 | k
+        # (every key of a region has the same alternate bucket, src/mega_recv.c:700-704)
+        k = (rng.integers(1, max(2, sig_space)) + np.arange(n, dtype=np.uint64)).astype(np.uint32)
+        rng.shuffle(k)
+        e[:, 0] = k
+        e[:, 1] = ((k & np.uint32(7)) << np.uint32(29)) | k
+    elif shape == "cluster" and n:
+        # many different signatures on few primary buckets: long runs of registrants per bucket
+        centres = rng.integers(0, 2**32, size=max(1, n // 40), dtype=np.uint64).astype(np.uint32)
+        e[:, 1] = centres[rng.integers(0, len(centres), size=n)]
     if hot > 0 and n:
         hk = np.stack([rng.integers(1, sig_space + 1, size=4),
                        rng.integers(0, 2**32, size=4, dtype=np.uint64)], axis=1).astype(np.uint32)

@@ -75,11 +75,15 @@ def _run(seed, forced):
     idx = HashIndex(g)
     idx.load_table(exp)
     nslots = g.nbuckets * 8
+    # request shapes beside uniformly random ones, drawn apart from the main stream of random
+    # numbers so that the sequences of earlier rounds stay what they were
+    shape = str(np.random.default_rng(7000 + seed).choice(["random", "random", "random", "ref", "cluster"]))
     for step in range(3):
         op = rng.choice(["insert", "insert", "delete", "search"])
         n = int(rng.integers(1, max(2, min(40000, nslots))))
         e = random_requests(g, rng, n, sig_space, hot=float(rng.choice([0.0, 0.1, 0.6])),
-                            zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])))
+                            zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])),
+                            shape=shape)
         ctx = dict(seed=seed, mem_p=mem_p, iblock_p=iblock_p, scheme=scheme, max_cuckoo=max_cuckoo, fill=fill,
                    step=step, op=str(op), n=n)
         if op == "insert":
