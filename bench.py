@@ -157,14 +157,37 @@ def main():
     scheme = M.SCHEME_CUCKOO if args.scheme == "cuckoo" else M.SCHEME_2CHOICE
 
     stream_gen = Stream(args, rank, world, mem_p_agg)
+    # ---- distinct pre-generated batches (host side first: the sharded engine sizes its slots by them)
+    nb = args.steps + args.warmup
+    t0 = time.time()
+    host_batches, check_keys = [], None
+    for i in range(nb):
+        host_batches.append(stream_gen.batch())
+        if i == args.warmup - 1:
+            check_keys = stream_gen.last_get_keys.copy()
+    t_gen = time.time() - t0
+    slot_factor = None
     if not sharded:
         from megakv_amd.index import HashIndex
         geom = M.Geometry(mem_p=args.mem_p, scheme=scheme)
         engine = SingleGpu(HashIndex(geom, device=device), args)
     else:
         from megakv_amd.sharded import ShardedIndex, NcclComm, StagedComm
+        # Slot capacity: the largest share one shard gets of any batch of any rank (a hot key sends
+        # all its GETs to one shard), plus 3 %.  Padding is exchanged like payload, so no more than
+        # needed; and a slot can then not overflow in this run.
+        mask, shift, share = (1 << (mem_p_agg - 6)) - 1, args.mem_p - 6, 1.0
+        for gets, sets in host_batches:
+            for a in (gets, sets):
+                if a.shape[0] >= world:
+                    c = np.bincount((a[:, 1] & np.uint32(mask)) >> np.uint32(shift), minlength=world)
+                    share = max(share, float(c.max()) * world / a.shape[0])
+        t = torch.tensor([share], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        slot_factor = round(float(t.item()) * 1.03, 4)
         engine = ShardedIndex(args.mem_p, world, rank, scheme, device, stream_gen.n_get, stream_gen.n_set,
-                              StagedComm(dist) if args.comm == "staged" else NcclComm(dist))
+                              StagedComm(dist) if args.comm == "staged" else NcclComm(dist),
+                              cap_factor=slot_factor)
     native = False
     if sharded and args.comm == "nccl" and not args.no_native and not args.no_pipeline:
         # the step as ONE library call per run (own RCCL communicator); all ranks agree, or all
@@ -196,16 +219,12 @@ def main():
     torch.cuda.synchronize()
     t_preload = time.time() - t0
 
-    # ---- distinct pre-generated batches, resident in HBM --------------------------
-    nb = args.steps + args.warmup
+    # ---- the batches, resident in HBM --------------------------------------------------
     t0 = time.time()
-    batches, check_keys = [], None
-    for i in range(nb):
-        batches.append(engine.stage(*stream_gen.batch()))
-        if i == args.warmup - 1:
-            check_keys = stream_gen.last_get_keys.copy()
+    batches = [engine.stage(g, s) for g, s in host_batches]
+    del host_batches
     torch.cuda.synchronize()
-    t_gen = time.time() - t0
+    t_gen += time.time() - t0
 
     run_stream = torch.cuda.Stream(device=device)
     use_events = not args.no_events
@@ -320,6 +339,7 @@ def main():
                        "batch": 1 << args.batch_log2, "gets": stream_gen.n_get, "sets": stream_gen.n_set,
                        "keying": "K-" + args.keying, "set_keys": "S-" + args.sets, "load_factor": args.lf,
                        "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "memset" if args.memset else "by the search kernel", "mark_pass": args.overlap,
+                       "slot_capacity_factor": slot_factor,
                        "sharding": "single table" if not sharded else
                        f"{world} shards by top bucket bits, RCCL all-to-all, "
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
