@@ -26,18 +26,31 @@
 //               exclusive use of those buckets -- and logs what it overwrote;
 //               losers re-register for round 2 and bump a registrant count on
 //               the buckets they lost.
-//   K3 round 2  the same over the losers.  It also classifies them: a loser
-//               might turn hard before its turn unless it holds a duplicate or
-//               the empty slots of P and A outnumber the other registrants.
+//   K3 round 2  the same over the losers (without eviction chains: see below).  It also
+//               classifies them: a loser might turn hard before its turn unless it
+//               holds a duplicate or the empty slots of P and A outnumber the other
+//               registrants.
 //   barrier     hard requests, and losers that might turn hard, publish their
 //               index into a per-region minimum B: an eviction chain may reach
 //               any bucket of the region, so nothing at or beyond B may run
 //               before it.  Commits are optimistic: K4 first rolls back (from
 //               the log) every commit at or beyond the final B.
-//   K4 tail     one 1024-lane work-group runs further rounds over what is left
-//               (same rule, decide-then-commit with work-group barriers), then
-//               sorts the remainder by canonical index in LDS and replays it in
-//               order, eviction chains included.
+//   K4 tail     one launch of 32 work-groups of 1024 lanes.  With something to roll
+//               back or much left, all of them share the scans over the request
+//               tags (roll-back, gather; grid-wide meetings on counters the kernel
+//               before resets); otherwise the helpers leave at once.  Work-group 0
+//               then runs further rounds over what is left (same rule, decide-then-
+//               commit with work-group barriers) -- all 32 groups when a final pass
+//               is left with a long list -- until a round would resolve less than
+//               the in-order replay does in its time; the remainder is sorted by
+//               canonical index and replayed in order per closed region, eviction
+//               chains included.
+//
+// "Holds a duplicate" only counts while nothing can evict that duplicate before the
+// request's turn: never for signature 0 (which matches empty slots anybody may fill);
+// in K3 because no chain runs beside the classification; in the tail's rounds only if
+// the request owns the bucket or no registrant has it as its alternate bucket (a chain
+// starts at the alternate bucket and goes on through unregistered ones).
 //
 // Why this equals the canonical order: DESIGN.md, "insert: why the result is
 // the canonical one".  No host synchronisation anywhere: request counts are
