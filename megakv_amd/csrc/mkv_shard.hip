@@ -106,6 +106,26 @@ struct Span {
 };
 }  // namespace
 
+// MKV_SHARD_FAKE_XFER_US=n (diagnostics): every exchange is followed by a one-wave kernel that
+// waits n microseconds on the lane's stream -- a stand-in for the time the exchange takes over
+// xGMI when only one GPU is there to measure schedules on
+__global__ void k_wait_us(unsigned us)
+{
+	const unsigned long long t0 = wall_clock64();
+	while (wall_clock64() - t0 < (unsigned long long)us * 100ull)
+		__builtin_amdgcn_s_sleep(8);
+}
+static int g_fake_xfer_us = -1;
+static void fake_xfer(hipStream_t s)
+{
+	if (g_fake_xfer_us < 0) {
+		const char *v = getenv("MKV_SHARD_FAKE_XFER_US");
+		g_fake_xfer_us = v ? atoi(v) : 0;
+	}
+	if (g_fake_xfer_us > 0)
+		hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, s, (unsigned)g_fake_xfer_us);
+}
+
 static int fail(mkv_shard *e, int code, const char *what, const char *detail)
 {
 	snprintf(e->err, sizeof(e->err), "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
@@ -322,6 +342,7 @@ static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, co
 		return fail(e, rc, "mkv_pack_requests", nullptr);
 	Span sp("a2a-fwd", lane, batch, l.stream, tr);
 	SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
+	fake_xfer(l.stream);
 	return MKV_OK;
 }
 
@@ -330,6 +351,7 @@ static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get, int lane, 
 	{
 		Span sp("a2a-back", lane, batch, l.stream, tr);
 		SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
+		fake_xfer(l.stream);
 	}
 	Span sp("unpack", lane, batch, l.stream, tr);
 	const int rc = mkv_unpack_results(l.back_slots, l.perm, n_get, out, l.stream);
@@ -427,6 +449,7 @@ static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 			SH_NCCL(e, e->api.GroupEnd());
 			SH_NCCL(e, r1);
 			SH_NCCL(e, r2);
+			fake_xfer(l.stream);
 		}
 		SH_HIP(e, hipEventRecord(l.ev_xchg[k2], l.stream));
 		{
