@@ -62,8 +62,8 @@ struct mkv_shard {
 	int64_t n_get = 0, n_set = 0, cap_get = 0, cap_set = 0, slot_words = 0, scratch_bytes = 0;
 	uint32_t agg_mask = 0, shift = 0;
 	int *overflow = nullptr;
-	int fused = 0;                  // MKV_SHARD_FUSED=1: one grouped collective per batch (run_fused; measured
-	                                // slower on this host: more API calls per step than the GPU time it saves)
+	int fused = 0;                  // one grouped collective per batch (run_fused): default with several ranks,
+	                                // MKV_SHARD_FUSED=0/1 overrides
 	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
 	Lane lane[4];
 	hipEvent_t ev_start = nullptr;
@@ -216,6 +216,10 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		if (n >= 2 && n <= 4)
 			e->nlanes = n;
 	}
+	// one rank: the exchanges are local copies, the plain schedule is faster (99 vs 106 us per
+	// step); several ranks: exchanges take time and RCCL runs them one after the other, so the
+	// grouped exchange wins (120 vs 131 us with 40 us of stand-in transfer time)
+	e->fused = world > 1;
 	if (const char *v = getenv("MKV_SHARD_FUSED"))
 		e->fused = atoi(v) != 0;
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
