@@ -1011,6 +1011,12 @@ __device__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint
 		const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
 		const bool take = !below_bar || (s_bar[region] != kNone && idx <= s_bar[region]);
 		lreg[i] = take ? (uint8_t)region : (uint8_t)0xffu;
+		if (take) {
+			// touch both buckets: the replaying lane then finds them in L2
+			const uint32_t P = rc.y & g.hash_mask, A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+			const uint32_t a = ld_agent32(table + sig_word(P, 0u)), b = ld_agent32(table + sig_word(A, 0u));
+			asm volatile("" ::"v"(a), "v"(b));
+		}
 	}
 	__syncthreads();
 	const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
