@@ -39,62 +39,51 @@
 extern "C" {
 #endif
 
-void gpu_hash_search(
-		selem_t 	*in,
-		loc_t		*out,
-		bucket_t	*hash_table,
-		int			num_elem,
-		int			num_thread,
-		int			threads_per_blk,
+/* Parameter names below describe what is passed; the reference's names are given in brackets
+ * where they differ (ref libgpuhash.h:29-62).  Types and order are the reference's. */
+
+/* Probe `count` [num_elem] requests: results[2i], results[2i+1] <- location found in the
+ * primary / alternate bucket of request i [in, out, hash_table]. */
+void gpu_hash_search(selem_t *requests, loc_t *results, bucket_t *table, int count, int num_thread,
+		int threads_per_blk, cudaStream_t stream);
+
+/* Insert `blocks` [num_blks] blocks: block_requests[b] holds block_counts[b] requests
+ * [blk_input, blk_elem_num] -- both arrays live in device memory. */
+void gpu_hash_insert(bucket_t *table, ielem_t **block_requests, int *block_counts, int blocks,
 		cudaStream_t stream);
 
-void gpu_hash_insert(
-		bucket_t	*hash_table,
-		ielem_t		**blk_input,
-		int			*blk_elem_num,
-		int			num_blks,
+/* Empty the slots that hold exactly (sig, loc) of each of the `count` requests. */
+void gpu_hash_delete(delem_t *requests, bucket_t *table, int count, int num_thread, int threads_per_blk,
 		cudaStream_t stream);
 
-void gpu_hash_delete(
-		delem_t 	*in,
-		bucket_t	*hash_table,
-		int			num_elem,
-		int 		num_thread,
-		int			threads_per_blk,
+/* Declared by the reference (libgpuhash.h:53-62) but defined nowhere and never called.
+ * Provided here as delete-then-insert on the same stream so that a host referencing it links. */
+void gpu_delete_insert(bucket_t *table, delem_t *deletes, uint32_t delete_count, ielem_t **block_requests,
+		int *block_counts, int blocks, uint32_t num_delete_thread, uint32_t threads_per_blk,
 		cudaStream_t stream);
-
-/* Declared by the reference (libgpuhash.h:53-62) but defined nowhere and never
- * called.  Provided here as delete-then-insert on the same stream so that a
- * host referencing it links. */
-void gpu_delete_insert(
-		bucket_t		*hash_table,
-		delem_t			*delete_in,
-		uint32_t		num_delete_job,
-		ielem_t			**insert_blk_input,
-		int				*insert_blk_elem_num,
-		int				num_insert_blks,
-		uint32_t		num_delete_thread,
-		uint32_t		threads_per_blk,
-		cudaStream_t	stream);
 
 #ifdef __cplusplus
 }
 #endif
 
-#define CUDA_SAFE_CALL(call) do {                                            \
-	cudaError_t err = call;                                                    \
-	if(cudaSuccess != err) {                                                \
-		fprintf(stderr, "Cuda error in file '%s' in line %i : %s.\n",        \
-				 __FILE__, __LINE__, cudaGetErrorString( err) );             \
-		exit(EXIT_FAILURE);                                                  \
-	} } while (0)
+/* The reference's hosts wrap their runtime calls in CUDA_SAFE_CALL (ref libgpuhash.h:64-70):
+ * on failure, the same message on stderr and exit(EXIT_FAILURE). */
+static inline void libgpuhash_check_(cudaError_t status, const char *file, int line)
+{
+	if (status == cudaSuccess)
+		return;
+	fprintf(stderr, "Cuda error in file '%s' in line %i : %s.\n", file, line, cudaGetErrorString(status));
+	exit(EXIT_FAILURE);
+}
+#define CUDA_SAFE_CALL(call) libgpuhash_check_((call), __FILE__, __LINE__)
 
-#define CUDA_SAFE_CALL_SYNC(call) do {                                       \
-	cudaError_t err_s = call;                                                  \
-	if (cudaSuccess == err_s) err_s = cudaDeviceSynchronize();                \
-	if(cudaSuccess != err_s) {                                              \
-		fprintf(stderr, "Cuda error in file '%s' in line %i : %s.\n",        \
-				__FILE__, __LINE__, cudaGetErrorString( err_s) );            \
-		exit(EXIT_FAILURE);                                                  \
-	} } while (0)
+/* the call, then a device synchronisation, both checked (the reference's macro of this name,
+ * ref :72-79, does not compile and is used nowhere) */
+static inline void libgpuhash_check_sync_(cudaError_t status, const char *file, int line)
+{
+	libgpuhash_check_(status, file, line);
+	libgpuhash_check_(cudaDeviceSynchronize(), file, line);
+}
+#define CUDA_SAFE_CALL_SYNC(call) libgpuhash_check_sync_((call), __FILE__, __LINE__)
+
 #endif
