@@ -144,7 +144,10 @@ class NativeEngine:
     def _check(self, rc, what):
         if rc != 0:
             msg = self.lib.mkv_shard_error(self.h) if self.h else b""
-            raise RuntimeError(f"{what} failed ({rc}): {(msg or b'').decode(errors='replace')}")
+            text = (msg or b"").decode(errors="replace")
+            if what in ("mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect"):
+                self.close()                      # a half-built engine is of no use: free what it holds
+            raise RuntimeError(f"{what} failed ({rc}): {text}")
 
     def run(self, batches, stream=None, timer=None, timer_every=0):
         n = len(batches)
