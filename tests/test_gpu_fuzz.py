@@ -51,7 +51,9 @@ def test_signature_zero_request_turns_hard_behind_others():
 def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
     L = load_library()
-    mem_p = int(rng.integers(10, 19))
+    env = __import__("os").environ
+    big = int(env.get("MKV_FUZZ_BIG", "0"))          # 1: tables up to 2 MiB, batches up to 300 K requests
+    mem_p = int(rng.integers(10, 19)) + (int(rng.integers(0, 4)) if big else 0)
     iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
     scheme = int(rng.integers(0, 2))
     max_cuckoo = int(rng.choice([0, 1, 2, 5, 6]))
@@ -80,7 +82,7 @@ def _run(seed, forced):
     shape = str(np.random.default_rng(7000 + seed).choice(["random", "random", "random", "ref", "cluster"]))
     for step in range(3):
         op = rng.choice(["insert", "insert", "delete", "search"])
-        n = int(rng.integers(1, max(2, min(40000, nslots))))
+        n = int(rng.integers(1, max(2, min(300000 if big else 40000, nslots))))
         e = random_requests(g, rng, n, sig_space, hot=float(rng.choice([0.0, 0.1, 0.6])),
                             zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])),
                             shape=shape)
