@@ -91,7 +91,9 @@ enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 // work lists, no same-address atomics on the hot path.
 constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_LOSER = 4, ST_TAIL = 5,
 		ST_CHAIN1 = 6, ST_CHAIN2 = 7,   // committed with an eviction chain (log in the chain log)
-		ST_CHAIN_OK = 8;                // tail rounds: chain walked and all its buckets claimed
+		ST_CHAIN_OK = 8,                // tail rounds: chain walked and all its buckets claimed
+		ST_DUPW = 9,                    // tail rounds: holds a duplicate nothing can evict -- a pure loc write
+		ST_DUPW_OK = 10;                // ... and takes part in this round's last-writer election of its bucket
 constexpr int kShards = 64;         // statistics counters are spread over this many words
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
@@ -581,7 +583,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			// earlier pass are closed here, so that a later roll-back never takes them for
 			// commits of its own pass (it starts at the carry index, like this loop)
 			const uint8_t st = state[idx];
-			live = st == ST_PENDING || st == ST_LOSER || st == ST_TAIL || st == ST_CHAIN_OK;
+			live = st == ST_PENDING || st == ST_LOSER || st == ST_TAIL || st >= ST_CHAIN_OK;
 			if (live ? st != ST_PENDING : st != ST_DONE)
 				state[idx] = live ? ST_PENDING : ST_DONE;
 			if (live) {
@@ -1070,7 +1072,7 @@ __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const
 			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 			const uint32_t idx = base + (uint32_t)k;
 			c += (idx >= lo_idx && idx < last &&
-					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK)) ? 1u : 0u;
+					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK)) ? 1u : 0u;
 		}
 	}
 	scratch1024[t] = c;
@@ -1091,7 +1093,7 @@ __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const
 			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 			const uint32_t idx = base + (uint32_t)k;
 			if (idx >= lo_idx && idx < last &&
-					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
+					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK))
 				glist[at++] = idx;
 		}
 	}
@@ -1173,6 +1175,48 @@ __device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Re
 	}
 }
 
+// Tail rounds, duplicate writers.  A request tagged DUPW holds a duplicate in its primary
+// bucket that nothing can evict before its turn: all it will do is overwrite that slot's
+// location, which commutes with every structural request -- only the order among the
+// writers of one slot matters (the last one wins).  So the writers of a bucket below the
+// round's barrier elect the highest index among them (atomicMax on a word per bucket);
+// the winner writes, the others with the winner's signature are dead writes and done,
+// writers of another slot of that bucket try again next round.  Nobody else may write the
+// bucket in that round: the election only counts when the bucket's owner (its lowest
+// registrant) is a duplicate writer too -- any other request needs to own what it writes.
+// Thousands of SETs of one hot key thus take a round or two instead of one round each.
+__device__ __forceinline__ void elect_last_writer(const DevGeom &g, const unsigned long long *owner,
+		unsigned long long *emax, const uint4 *reqc, uint8_t *state, uint32_t idx, uint32_t bar,
+		unsigned long long stamp)
+{
+	if (state[idx] != ST_DUPW || idx >= bar)
+		return;
+	const uint32_t P = reqc[idx].y & g.hash_mask;
+	const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
+	const uint8_t so = state[o];
+	if (so != ST_DUPW && so != ST_DUPW_OK)
+		return;
+	atomicMax(&emax[P], (stamp << kIdxBits) | idx);
+	state[idx] = ST_DUPW_OK;
+}
+
+// commit of a request tagged DUPW_OK: 1 = done (wrote, or a dead write), 0 = try again
+__device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom &g, const unsigned long long *emax,
+		const uint4 *reqc, const Req &r, uint32_t P, uint32_t idx)
+{
+	const uint32_t w = (uint32_t)(ld_agent(&emax[P]) & ((1ull << kIdxBits) - 1ull));
+	if (w == idx) {
+		uint4 lo, hi;
+		load_sig_row<true>(table, P, lo, hi);
+		const uint32_t m = eq_mask(lo, hi, r.sig);
+		if (!m)
+			return 0;                                   // (cannot happen: the duplicate was stable)
+		table[loc_word(P, (uint32_t)__ffs((int)m) - 1u)] = r.loc;
+		return 1;
+	}
+	return reqc[w].x == r.sig ? 1 : 0;
+}
+
 // Reservation rounds inside the tail work-group over keys[0..m) (kNone = done).
 // Same rule as the grid-wide rounds, with decide-then-commit separated by
 // work-group barriers.  A region whose lowest pending request is itself the
@@ -1188,6 +1232,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 {
 	const uint32_t t = threadIdx.x;
 	const unsigned long long stamp0 = ctl->stamp_base + 2;
+	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
 	uint32_t left = m, recent = 0;
 	for (int round = 0; round < max_rounds && left != 0; round++) {
 		*rounds_used = (uint32_t)round + 1u;
@@ -1231,6 +1276,8 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				const uint32_t P = rc.y & g.hash_mask;
 				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 				const uint32_t region = P >> g.region_shift;
+				if (state[idx] >= ST_DUPW)
+					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
 					continue;
 				uint4 lo, hi;
@@ -1243,8 +1290,10 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				// (and never for signature 0, which "matches" empty slots anybody may fill):
 				// the request owns the bucket (every other registrant comes later), or no
 				// registrant has the bucket as its alternate.
-				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
+				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp))) {
+					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
 					continue;
+				}
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 				const bool clean = ownP && ownA;
 				if (clean && room)
@@ -1269,6 +1318,14 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					atomicMin(&s_rbar[region], idx);
 			}
 			wg_sync();
+			// the duplicate writers below the round's barrier elect the last one per bucket
+			for (uint32_t i = t; i < m; i += blockDim.x) {
+				const uint32_t idx = keys[i];
+				if (idx != kNone && state[idx] == ST_DUPW)
+					elect_last_writer(g, owner, emax, reqc, state, idx,
+							s_rbar[(reqc[idx].y & g.hash_mask) >> g.region_shift], stamp);
+			}
+			wg_sync();
 		}
 		// commit
 		for (uint32_t i = t; i < m; i += blockDim.x) {
@@ -1283,16 +1340,24 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			if (OP == OP_CUCKOO) {
 				const uint32_t region = P >> g.region_shift;
 				const uint32_t bar = s_rbar[region];
+				const uint8_t st = state[idx];
 				if (idx == bar && idx == s_rmin[region]) {
 					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
 					done = true;
-				} else if (idx >= bar) {
-					if (state[idx] == ST_CHAIN_OK)
+				} else if (idx >= bar || st == ST_DUPW) {
+					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
 					atomicAdd(s_left, 1u);
 					continue;
-				} else if (state[idx] == ST_CHAIN_OK) {
+				} else if (st == ST_CHAIN_OK) {
 					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
+					done = true;
+				} else if (st == ST_DUPW_OK) {
+					if (!commit_last_writer(table, g, emax, reqc, r, P, idx)) {
+						state[idx] = ST_TAIL;
+						atomicAdd(s_left, 1u);
+						continue;
+					}
 					done = true;
 				}
 			}
@@ -1324,7 +1389,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 // The same rounds run by every work-group of the tail launch over the global list
 // keys[0..m): for a final pass that is left with more than one work-group can chew.
 // Round state lives in the control block; same-address atomics are folded per
-// work-group in LDS first.  Three grid-wide meetings per round.  All groups read the
+// work-group in LDS first.  Four grid-wide meetings per round.  All groups read the
 // same totals after the third and so leave the loop together.
 template <Op OP>
 __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
@@ -1335,6 +1400,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
 	const unsigned long long stamp0 = ctl->stamp_base + 2;
+	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
 	uint32_t left = m, nth = 0, used = 0, par = 0, recent = 0;
 	for (int round = 0; round < max_rounds && left != 0; round++) {
 		const unsigned long long stamp = stamp0 + (unsigned)round;
@@ -1382,6 +1448,8 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				const uint32_t P = rc.y & g.hash_mask;
 				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 				const uint32_t region = P >> g.region_shift;
+				if (state[idx] >= ST_DUPW)
+					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
 					continue;
 				uint4 lo, hi;
@@ -1394,8 +1462,10 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				// (and never for signature 0, which "matches" empty slots anybody may fill):
 				// the request owns the bucket (every other registrant comes later), or no
 				// registrant has the bucket as its alternate.
-				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp)))
+				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp))) {
+					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
 					continue;
+				}
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 				const bool clean = ownP && ownA;
 				if (clean && room)
@@ -1427,6 +1497,14 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				s_rmin[t] = t < g.nregions ? ld_agent32(&ctl->g_rmin[set][t]) : kNone;
 			}
 			__syncthreads();
+			// the duplicate writers below the round's barrier elect the last one per bucket
+			for (uint32_t i = first; i < m; i += span) {
+				const uint32_t idx = keys[i];
+				if (idx != kNone && state[idx] == ST_DUPW)
+					elect_last_writer(g, owner, emax, reqc, state, idx,
+							s_rbar[(reqc[idx].y & g.hash_mask) >> g.region_shift], stamp);
+			}
+			grid_sync_nth(&ctl->g_sync, nwg, &nth);
 		}
 		// the idle set is made ready for the next round
 		if (wg == 0 && t < kMaxRegions) {
@@ -1449,16 +1527,24 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			if (OP == OP_CUCKOO) {
 				const uint32_t region = P >> g.region_shift;
 				const uint32_t bar = s_rbar[region];
+				const uint8_t st = state[idx];
 				if (idx == bar && idx == s_rmin[region]) {
 					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
 					done = true;
-				} else if (idx >= bar) {
-					if (state[idx] == ST_CHAIN_OK)
+				} else if (idx >= bar || st == ST_DUPW) {
+					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
 					my_left++;
 					continue;
-				} else if (state[idx] == ST_CHAIN_OK) {
+				} else if (st == ST_CHAIN_OK) {
 					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
+					done = true;
+				} else if (st == ST_DUPW_OK) {
+					if (!commit_last_writer(table, g, emax, reqc, r, P, idx)) {
+						state[idx] = ST_TAIL;
+						my_left++;
+						continue;
+					}
 					done = true;
 				}
 			}
@@ -1658,7 +1744,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 				const uint32_t idx = base + (uint32_t)k;
 				if (idx >= lo_idx && idx < total &&
-						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
+						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK))
 					take |= 1u << k;
 			}
 			if (!take)
@@ -1738,7 +1824,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 				const uint32_t idx = base + (uint32_t)k;
 				if (idx >= lo_idx && idx < total &&
-						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st == ST_CHAIN_OK))
+						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK))
 					glist[atomicAdd(&s_n, 1u)] = idx;
 			}
 		}
@@ -1983,7 +2069,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 			// reserve covers that): start over with cleared reservation tables, in stream order
 			bool ok = hipMemsetAsync(w->owner[0], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->owner[1], 0xff, w->nbuckets * 8, stream) == hipSuccess;
-			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 8, stream) == hipSuccess;
+			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 16, stream) == hipSuccess;
 			if (!ok)
 				return MKV_EHIP;
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull);
@@ -2005,7 +2091,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	bool ok = true;
 	for (int i = 0; i < 2 && ok; i++)
 		ok = ok && hipMalloc(&w->owner[i], nb * 8) == hipSuccess;
-	ok = ok && hipMalloc(&w->cnt, nb * 8) == hipSuccess;
+	ok = ok && hipMalloc(&w->cnt, nb * 16) == hipSuccess;     // registrant counts, then the election words
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
@@ -2027,7 +2113,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		// owner entries start at "no owner" (all ones); counters at zero
 		ok = ok && hipMemsetAsync(w->owner[0], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->owner[1], 0xff, nb * 8, stream) == hipSuccess;
-		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 8, stream) == hipSuccess;
+		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 16, stream) == hipSuccess;
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
 					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1));
