@@ -509,6 +509,62 @@ __device__ __forceinline__ void reserve_wave(unsigned long long *owner, uint32_t
 	atomic_min_dedup(owner, A, key, active && A != P);
 }
 
+// wave-convergent registrant count: lanes of a wave that count on the same bucket as the
+// wave's first pending lane are served by one add of their number (two peeling steps, then
+// one per lane) -- duplicates of a hot key would otherwise queue on one word
+__device__ __forceinline__ void bump_wave(unsigned long long *cnt, uint32_t b, unsigned long long stamp,
+		bool alt, bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		const unsigned long long group = __ballot(same), alts = __ballot(same && alt);
+		if ((int)(threadIdx.x & 63u) == first) {
+			atomicMax(&cnt[fb], stamp << kIdxBits);
+			atomicAdd(&cnt[fb], (unsigned long long)__popcll(group));
+			if (alts)
+				atomicOr(&cnt[fb], kAltFlag);
+		}
+		active = active && !same;
+	}
+	if (active) {
+		if (alt)
+			bump_alt(cnt, b, stamp);
+		else
+			bump(cnt, b, stamp);
+	}
+}
+
+// wave-convergent atomicMax with the same folding
+__device__ __forceinline__ void atomic_max_dedup(unsigned long long *words, uint32_t b, unsigned long long key,
+		bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		unsigned long long k = same ? key : 0ull;
+		for (int off = 32; off > 0; off >>= 1) {
+			const unsigned long long o = __shfl_xor(k, off);
+			k = o > k ? o : k;
+		}
+		if ((int)(threadIdx.x & 63u) == first)
+			atomicMax(&words[fb], k);
+		active = active && !same;
+	}
+	if (active)
+		atomicMax(&words[b], key);
+}
+
 // statistics: one atomic per wave, spread over kShards words
 __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 {
@@ -764,12 +820,15 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
 	const uint32_t carry = ctl->carry_lo;
 	const uint32_t start = carry < lo_idx ? carry : lo_idx;
-	for (uint32_t idx = start + blockIdx.x * blockDim.x + threadIdx.x; idx < count && idx >= start;
-			idx += span) {
+	// whole waves go round together (the losers' re-registration folds the atomics of lanes on
+	// one bucket): the loop variable is the work-group's first index
+	for (uint32_t base = start + blockIdx.x * blockDim.x; base < count && base >= start; base += span) {
+		const uint32_t idx = base + threadIdx.x;
+		const bool in_range = idx < count;
 		// first round trip: request and its state -- independent loads
-		const uint8_t st = state[idx];
+		const uint8_t st = in_range ? state[idx] : ST_DONE;
 		const bool pending = st == (ROUND == 1 ? ST_PENDING : ST_LOSER);
-		const uint4 rc = (ROUND == 1 || pending) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
+		const uint4 rc = (in_range && (ROUND == 1 || pending)) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
 		const Req r = req_of(rc);
 		const uint32_t P = r.hash & g.hash_mask;
 		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
@@ -801,7 +860,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			if (!(dbg & 8))
 				kP = load_bucket(table, P);
 		}
-		bool done = false, lose = false, to_tail = false;
+		bool done = false, lose = false, to_tail = false, bump_p = false, bump_a = false;
 		if (pending) {
 			// a barrier already published at or below this request: leave it to the tail
 			const bool blocked = OP == OP_CUCKOO && idx >= bar;
@@ -889,14 +948,11 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				}
 				if (ROUND == 1 && !blocked) {
 					lose = true;
-					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
 					if (OP == OP_CUCKOO) {
 						// registrant counts of round 1: every registrant that is not the
 						// owner adds itself (owners are counted as the +1 in the test above)
-						if (!ownP)
-							bump(cnt, P, stamp1);
-						if (A != P && (ownP ? !ownA : owner[A] != key))
-							bump(cnt, A, stamp1);
+						bump_p = !ownP;
+						bump_a = A != P && (ownP ? !ownA : owner[A] != key);
 					}
 				} else {
 					to_tail = true;
@@ -904,6 +960,14 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			}
 		}
 next_request:
+		if (ROUND == 1) {
+			// the losers register for round 2 and count themselves (every lane comes by here)
+			reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
+			if (OP == OP_CUCKOO) {
+				bump_wave(cnt, P, stamp1, false, lose && bump_p);
+				bump_wave(cnt, A, stamp1, false, lose && bump_a);
+			}
+		}
 		if (lose) {
 			state[idx] = ST_LOSER;
 			ctl->any_loser = 1u;
@@ -1186,18 +1250,19 @@ __device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Re
 // registrant) is a duplicate writer too -- any other request needs to own what it writes.
 // Thousands of SETs of one hot key thus take a round or two instead of one round each.
 __device__ __forceinline__ void elect_last_writer(const DevGeom &g, const unsigned long long *owner,
-		unsigned long long *emax, const uint4 *reqc, uint8_t *state, uint32_t idx, uint32_t bar,
-		unsigned long long stamp)
+		unsigned long long *emax, const uint4 *reqc, uint8_t *state, uint32_t idx, uint32_t P, uint32_t bar,
+		unsigned long long stamp, bool active)
 {
-	if (state[idx] != ST_DUPW || idx >= bar)
-		return;
-	const uint32_t P = reqc[idx].y & g.hash_mask;
-	const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
-	const uint8_t so = state[o];
-	if (so != ST_DUPW && so != ST_DUPW_OK)
-		return;
-	atomicMax(&emax[P], (stamp << kIdxBits) | idx);
-	state[idx] = ST_DUPW_OK;
+	// every lane of the wave calls this; `active` = the lane holds a pending request
+	bool take = active && state[idx] == ST_DUPW && idx < bar;
+	if (take) {
+		const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
+		const uint8_t so = state[o];
+		take = so == ST_DUPW || so == ST_DUPW_OK;
+	}
+	atomic_max_dedup(emax, P, (stamp << kIdxBits) | idx, take);
+	if (take)
+		state[idx] = ST_DUPW_OK;
 }
 
 // commit of a request tagged DUPW_OK: 1 = done (wrote, or a dead write), 0 = try again
@@ -1246,23 +1311,21 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			*s_left = 0;
 		}
 		__syncthreads();
-		// register; the count decides who might turn hard
-		for (uint32_t i = t; i < m; i += blockDim.x) {
-			const uint32_t idx = keys[i];
-			if (idx == kNone)
-				continue;
-			const uint4 rc = reqc[idx];
+		// register; the count decides who might turn hard (whole waves go round together: the
+		// atomics of lanes on one bucket are folded)
+		for (uint32_t base = 0; base < m; base += blockDim.x) {
+			const uint32_t i = base + t;
+			const uint32_t idx = i < m ? keys[i] : kNone;
+			const bool live = idx != kNone;
+			const uint4 rc = live ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
-			reserve(owner, P, A, owner_key(stamp, idx));
+			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), live);
 			if (OP == OP_CUCKOO) {
-				if (A != P) {
-					bump(cnt, P, stamp);
-					bump_alt(cnt, A, stamp);
-				} else {
-					bump_alt(cnt, P, stamp);
-				}
-				atomicMin(&s_rmin[P >> g.region_shift], idx);
+				bump_wave(cnt, P, stamp, A == P, live);
+				bump_wave(cnt, A, stamp, true, live && A != P);
+				if (live)
+					atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
 		}
 		wg_sync();
@@ -1319,11 +1382,13 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			}
 			wg_sync();
 			// the duplicate writers below the round's barrier elect the last one per bucket
-			for (uint32_t i = t; i < m; i += blockDim.x) {
-				const uint32_t idx = keys[i];
-				if (idx != kNone && state[idx] == ST_DUPW)
-					elect_last_writer(g, owner, emax, reqc, state, idx,
-							s_rbar[(reqc[idx].y & g.hash_mask) >> g.region_shift], stamp);
+			for (uint32_t base = 0; base < m; base += blockDim.x) {
+				const uint32_t i = base + t;
+				const uint32_t idx = i < m ? keys[i] : kNone;
+				const bool live = idx != kNone;
+				const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
+				elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift], stamp,
+						live);
 			}
 			wg_sync();
 		}
@@ -1415,23 +1480,20 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			*s_left = 0;
 		}
 		__syncthreads();
-		// register
-		for (uint32_t i = first; i < m; i += span) {
-			const uint32_t idx = keys[i];
-			if (idx == kNone)
-				continue;
-			const uint4 rc = reqc[idx];
+		// register (whole waves go round together: atomics of lanes on one bucket are folded)
+		for (uint32_t base = wg * blockDim.x; base < m; base += span) {
+			const uint32_t i = base + t;
+			const uint32_t idx = i < m ? keys[i] : kNone;
+			const bool live = idx != kNone;
+			const uint4 rc = live ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
-			reserve(owner, P, A, owner_key(stamp, idx));
+			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), live);
 			if (OP == OP_CUCKOO) {
-				if (A != P) {
-					bump(cnt, P, stamp);
-					bump_alt(cnt, A, stamp);
-				} else {
-					bump_alt(cnt, P, stamp);
-				}
-				atomicMin(&s_rmin[P >> g.region_shift], idx);
+				bump_wave(cnt, P, stamp, A == P, live);
+				bump_wave(cnt, A, stamp, true, live && A != P);
+				if (live)
+					atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
 		}
 		__syncthreads();
@@ -1498,11 +1560,13 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			}
 			__syncthreads();
 			// the duplicate writers below the round's barrier elect the last one per bucket
-			for (uint32_t i = first; i < m; i += span) {
-				const uint32_t idx = keys[i];
-				if (idx != kNone && state[idx] == ST_DUPW)
-					elect_last_writer(g, owner, emax, reqc, state, idx,
-							s_rbar[(reqc[idx].y & g.hash_mask) >> g.region_shift], stamp);
+			for (uint32_t base = wg * blockDim.x; base < m; base += span) {
+				const uint32_t i = base + t;
+				const uint32_t idx = i < m ? keys[i] : kNone;
+				const bool live = idx != kNone;
+				const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
+				elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift], stamp,
+						live);
 			}
 			grid_sync_nth(&ctl->g_sync, nwg, &nth);
 		}
