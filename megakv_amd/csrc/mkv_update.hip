@@ -961,11 +961,24 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 		}
 next_request:
 		if (ROUND == 1) {
-			// the losers register for round 2 and count themselves (every lane comes by here)
-			reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
-			if (OP == OP_CUCKOO) {
-				bump_wave(cnt, P, stamp1, false, lose && bump_p);
-				bump_wave(cnt, A, stamp1, false, lose && bump_a);
+			// The losers register for round 2 and count themselves (every lane comes by here).
+			// Many losers in one wave mean duplicates of a hot key: their atomics on one bucket
+			// are folded; the usual two or three losers go one atomic each (folding costs more
+			// instructions than it saves them).
+			if (__popcll(__ballot(lose)) >= 8) {
+				reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
+				if (OP == OP_CUCKOO) {
+					bump_wave(cnt, P, stamp1, false, lose && bump_p);
+					bump_wave(cnt, A, stamp1, false, lose && bump_a);
+				}
+			} else if (lose) {
+				reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+				if (OP == OP_CUCKOO) {
+					if (bump_p)
+						bump(cnt, P, stamp1);
+					if (bump_a)
+						bump(cnt, A, stamp1);
+				}
 			}
 		}
 		if (lose) {
