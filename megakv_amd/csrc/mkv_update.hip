@@ -1334,7 +1334,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), live);
-			if (OP == OP_CUCKOO) {
+			if (OP != OP_DELETE) {
 				bump_wave(cnt, P, stamp, A == P, live);
 				bump_wave(cnt, A, stamp, true, live && A != P);
 				if (live)
@@ -1343,7 +1343,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		}
 		wg_sync();
 		// decide: the lowest index per region that is hard or might turn hard
-		if (OP == OP_CUCKOO) {
+		if (OP != OP_DELETE) {
 			for (uint32_t i = t; i < m; i += blockDim.x) {
 				const uint32_t idx = keys[i];
 				if (idx == kNone)
@@ -1370,6 +1370,8 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
 					continue;
 				}
+				if (OP != OP_CUCKOO)
+					continue;                               // two-choice: nothing turns hard
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 				const bool clean = ownP && ownA;
 				if (clean && room)
@@ -1415,7 +1417,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
 			bool done = false;
-			if (OP == OP_CUCKOO) {
+			if (OP != OP_DELETE) {
 				const uint32_t region = P >> g.region_shift;
 				const uint32_t bar = s_rbar[region];
 				const uint8_t st = state[idx];
@@ -1502,7 +1504,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), live);
-			if (OP == OP_CUCKOO) {
+			if (OP != OP_DELETE) {
 				bump_wave(cnt, P, stamp, A == P, live);
 				bump_wave(cnt, A, stamp, true, live && A != P);
 				if (live)
@@ -1514,7 +1516,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			atomicMin(&ctl->g_rmin[set][t], s_rmin[t]);
 		grid_sync_nth(&ctl->g_sync, nwg, &nth);
 		// decide: the lowest index per region that is hard or might turn hard
-		if (OP == OP_CUCKOO) {
+		if (OP != OP_DELETE) {
 			for (uint32_t i = first; i < m; i += span) {
 				const uint32_t idx = keys[i];
 				if (idx == kNone)
@@ -1541,6 +1543,8 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
 					continue;
 				}
+				if (OP != OP_CUCKOO)
+					continue;                               // two-choice: nothing turns hard
 				uint32_t room = (uint32_t)__popc(eq_mask(lo, hi, 0u));
 				const bool clean = ownP && ownA;
 				if (clean && room)
@@ -1601,7 +1605,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
 			bool done = false;
-			if (OP == OP_CUCKOO) {
+			if (OP != OP_DELETE) {
 				const uint32_t region = P >> g.region_shift;
 				const uint32_t bar = s_rbar[region];
 				const uint8_t st = state[idx];
