@@ -108,6 +108,7 @@ typedef struct mkv_update_info_s {
 	uint32_t chains;		/* eviction chains committed in the grid-wide rounds (conflict-free) */
 	uint32_t bar_chain;		/* region barriers raised by chains that met another request's bucket */
 	uint32_t bar_class;		/* region barriers raised for requests that might turn hard */
+	uint32_t tail_rounds;	/* reservation rounds the tail launches ran */
 } mkv_update_info_t;
 
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);

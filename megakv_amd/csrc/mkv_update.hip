@@ -106,6 +106,7 @@ constexpr int64_t kMaxReqCap = (1ll << kIdxBits) - 16;
 struct Info {
 	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow, chains,
 			bar_chain, bar_class;   // barriers published by failed chains / by classification
+	uint32_t tail_rounds;       // rounds the tail launches ran, summed over the call's passes
 };
 
 // Log of an optimistic eviction chain: every word it overwrote, in order.
@@ -2024,6 +2025,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
 		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + s_serial;
 		ctl->last.undone = (first_chunk ? 0u : ctl->last.undone) + s_undone;
+		ctl->last.tail_rounds = (first_chunk ? 0u : ctl->last.tail_rounds) + rounds_used;
 		const uint32_t fh = ctl->first_hard;
 		ctl->last.first_hard = first_chunk ? fh : (fh < ctl->last.first_hard ? fh : ctl->last.first_hard);
 		ctl->last.overflow = ctl->overflow;
@@ -2065,7 +2067,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k] = ctl->committed[1][k] = 0;
 		ctl->first_hard = kNone;
-		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0};
+		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0, 0};
 		ctl->bar_chain = ctl->bar_class = 0;
 		ctl->carry_lo = kNone;
 		ctl->chain_n = 0;
@@ -2670,6 +2672,7 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->chains = h.last.chains;
 	info->bar_chain = h.last.bar_chain;
 	info->bar_class = h.last.bar_class;
+	info->tail_rounds = h.last.tail_rounds;
 	return MKV_OK;
 }
 
