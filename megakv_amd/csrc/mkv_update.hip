@@ -142,6 +142,7 @@ struct Ctl {
 	uint32_t g_rbar[2][kMaxRegions]; // grid-wide rounds: round barrier / lowest pending index per region,
 	uint32_t g_rmin[2][kMaxRegions]; //   two sets used alternately (the idle one is reset meanwhile)
 	uint32_t g_progress[2], g_left[2];
+	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t tail_phase[8];          // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 };
@@ -480,11 +481,14 @@ __device__ __forceinline__ void atomic_min_dedup(unsigned long long *owner, uint
 		const int first = __ffsll((long long)pend) - 1;
 		const uint32_t fb = __shfl(b, first);
 		const bool same = active && b == fb;
-		// smallest key of the group (wave reduction over the group's lanes)
+		// smallest key of the group (wave reduction over the group's lanes; a group of one
+		// needs none)
 		unsigned long long k = same ? key : ~0ull;
-		for (int off = 32; off > 0; off >>= 1) {
-			const unsigned long long o = __shfl_xor(k, off);
-			k = o < k ? o : k;
+		if (__popcll(__ballot(same)) > 1) {
+			for (int off = 32; off > 0; off >>= 1) {
+				const unsigned long long o = __shfl_xor(k, off);
+				k = o < k ? o : k;
+			}
 		}
 		if ((int)(threadIdx.x & 63u) == first)
 			atomicMin(&owner[fb], k);
@@ -554,9 +558,11 @@ __device__ __forceinline__ void atomic_max_dedup(unsigned long long *words, uint
 		const uint32_t fb = __shfl(b, first);
 		const bool same = active && b == fb;
 		unsigned long long k = same ? key : 0ull;
-		for (int off = 32; off > 0; off >>= 1) {
-			const unsigned long long o = __shfl_xor(k, off);
-			k = o > k ? o : k;
+		if (__popcll(__ballot(same)) > 1) {
+			for (int off = 32; off > 0; off >>= 1) {
+				const unsigned long long o = __shfl_xor(k, off);
+				k = o > k ? o : k;
+			}
 		}
 		if ((int)(threadIdx.x & 63u) == first)
 			atomicMax(&words[fb], k);
@@ -1032,6 +1038,7 @@ __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 	ctl->undone_acc = 0;
 	ctl->g_progress[0] = ctl->g_progress[1] = 0;
 	ctl->g_left[0] = ctl->g_left[1] = 0;
+	ctl->g_dupw[0] = ctl->g_dupw[1] = 0;
 	ctl->tail_rounds_used = 0;
 	for (int k = 0; k < kMaxRegions; k++) {
 		ctl->g_rbar[0][k] = ctl->g_rbar[1][k] = kNone;
@@ -1307,7 +1314,7 @@ template <Op OP>
 __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
-		int max_rounds, uint32_t *rounds_used)
+		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used)
 {
 	const uint32_t t = threadIdx.x;
 	const unsigned long long stamp0 = ctl->stamp_base + 2;
@@ -1323,6 +1330,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		if (t == 0) {
 			*s_progress = 0;
 			*s_left = 0;
+			*s_dupw = 0;
 		}
 		__syncthreads();
 		// register; the count decides who might turn hard (whole waves go round together: the
@@ -1369,6 +1377,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				// registrant has the bucket as its alternate.
 				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp))) {
 					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
+					*s_dupw = 1u;
 					continue;
 				}
 				if (OP != OP_CUCKOO)
@@ -1398,15 +1407,17 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			}
 			wg_sync();
 			// the duplicate writers below the round's barrier elect the last one per bucket
-			for (uint32_t base = 0; base < m; base += blockDim.x) {
-				const uint32_t i = base + t;
-				const uint32_t idx = i < m ? keys[i] : kNone;
-				const bool live = idx != kNone;
-				const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
-				elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift], stamp,
-						live);
+			if (*s_dupw) {
+				for (uint32_t base = 0; base < m; base += blockDim.x) {
+					const uint32_t i = base + t;
+					const uint32_t idx = i < m ? keys[i] : kNone;
+					const bool live = idx != kNone;
+					const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
+					elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift],
+							stamp, live);
+				}
+				wg_sync();
 			}
-			wg_sync();
 		}
 		// commit
 		for (uint32_t i = t; i < m; i += blockDim.x) {
@@ -1475,8 +1486,8 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 template <Op OP>
 __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
-		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, int max_rounds,
-		uint32_t *rounds_used, uint32_t *par_total)
+		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
+		int max_rounds, uint32_t *rounds_used, uint32_t *par_total)
 {
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
@@ -1494,6 +1505,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		if (t == 0) {
 			*s_progress = 0;
 			*s_left = 0;
+			*s_dupw = 0;
 		}
 		__syncthreads();
 		// register (whole waves go round together: atomics of lanes on one bucket are folded)
@@ -1542,6 +1554,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				// registrant has the bucket as its alternate.
 				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp))) {
 					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
+					*s_dupw = 1u;
 					continue;
 				}
 				if (OP != OP_CUCKOO)
@@ -1571,6 +1584,8 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			__syncthreads();
 			if (t < g.nregions && s_rbar[t] != kNone)
 				atomicMin(&ctl->g_rbar[set][t], s_rbar[t]);
+			if (t == 0 && *s_dupw)
+				atomicOr(&ctl->g_dupw[set], 1u);
 			grid_sync_nth(&ctl->g_sync, nwg, &nth);
 			if (t < kMaxRegions) {
 				s_rbar[t] = t < g.nregions ? ld_agent32(&ctl->g_rbar[set][t]) : kNone;
@@ -1578,22 +1593,25 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			}
 			__syncthreads();
 			// the duplicate writers below the round's barrier elect the last one per bucket
-			for (uint32_t base = wg * blockDim.x; base < m; base += span) {
-				const uint32_t i = base + t;
-				const uint32_t idx = i < m ? keys[i] : kNone;
-				const bool live = idx != kNone;
-				const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
-				elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift], stamp,
-						live);
+			// (all work-groups read the same flag: they take or skip the meeting together)
+			if (ld_agent32(&ctl->g_dupw[set])) {
+				for (uint32_t base = wg * blockDim.x; base < m; base += span) {
+					const uint32_t i = base + t;
+					const uint32_t idx = i < m ? keys[i] : kNone;
+					const bool live = idx != kNone;
+					const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
+					elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift],
+							stamp, live);
+				}
+				grid_sync_nth(&ctl->g_sync, nwg, &nth);
 			}
-			grid_sync_nth(&ctl->g_sync, nwg, &nth);
 		}
 		// the idle set is made ready for the next round
 		if (wg == 0 && t < kMaxRegions) {
 			ctl->g_rbar[set ^ 1u][t] = kNone;
 			ctl->g_rmin[set ^ 1u][t] = kNone;
 			if (t == 0)
-				ctl->g_progress[set ^ 1u] = ctl->g_left[set ^ 1u] = 0;
+				ctl->g_progress[set ^ 1u] = ctl->g_left[set ^ 1u] = ctl->g_dupw[set ^ 1u] = 0;
 		}
 		// commit
 		uint32_t my_done = 0, my_left = 0;
@@ -1677,7 +1695,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
-	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left;
+	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw;
 	__shared__ uint32_t s_carry;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	unsigned long long tick = wall_clock64();
@@ -1942,7 +1960,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	if (m != 0 && grid_mode) {
 		uint32_t par = 0;
 		const uint32_t left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin,
-				&s_progress, &s_left, kGridRoundsMax, &rounds_used, &par);
+				&s_progress, &s_left, &s_dupw, kGridRoundsMax, &rounds_used, &par);
 		if (wg != 0)
 			return;
 		if (t == 0)
@@ -1992,7 +2010,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		wg_sync();
 		// a handful of requests: the in-order replay is done before a round would be
 		const uint32_t left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin,
-				&s_progress, &s_par, &s_left, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &rounds_used);
+				&s_progress, &s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &rounds_used);
 		MKV_PHASE(4);
 		if (left != 0 && in_lds) {
 			// what is left: canonical order, one request at a time
