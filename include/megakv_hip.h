@@ -119,7 +119,7 @@ int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *i
  * over the call's passes.  Synchronises the stream. */
 int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[8]);
 /* diagnostics: the random-read rate of the memory system -- groups of 4 lanes read
- * pieces_per_group (a multiple of 4) pseudo-random gran-byte pieces (64 / 128 / 256) of buf
+ * pieces_per_group (a multiple of 8) pseudo-random gran-byte pieces (32 / 64 / 128 / 256) of buf
  * (buf_bytes a power of two), 4 pieces in flight per group as in the search kernel; returns
  * the bytes read (negative: error).  tools/random_read_probe.py times it. */
 long long mkv_debug_random_read(const void *buf, long long buf_bytes, int gran, long long groups,

@@ -243,19 +243,50 @@ __global__ __launch_bounds__(256) void k_random_read(const uint4 *__restrict__ b
 
 }  // namespace mkv
 
+namespace mkv {
+// 32-byte pieces: two lanes per piece, two pieces per 4-lane group and step
+template <int U>
+__global__ __launch_bounds__(256) void k_random_read32(const uint4 *__restrict__ buf, uint64_t pieces_mask,
+		int64_t pieces_per_group, uint32_t *__restrict__ sink, uint32_t seed)
+{
+	const uint32_t lane4 = threadIdx.x & 3u;
+	const uint64_t pair = ((uint64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 1;     // two lanes share a piece
+	uint64_t x = (pair + 1u) * 0x9e3779b97f4a7c15ull + seed;
+	uint32_t acc = 0;
+	for (int64_t it = 0; it < pieces_per_group; it += 2 * U) {
+		uint4 v[U];
+#pragma unroll
+		for (int u = 0; u < U; u++) {
+			x ^= x >> 12;
+			x ^= x << 25;
+			x ^= x >> 27;
+			const uint64_t piece = (x * 0x2545f4914f6cdd1dull >> 20) & pieces_mask;
+			v[u] = buf[piece * 2 + (lane4 & 1u)];
+		}
+#pragma unroll
+		for (int u = 0; u < U; u++)
+			acc ^= v[u].x ^ v[u].y ^ v[u].z ^ v[u].w;
+	}
+	if (acc == 0x12345678u)
+		sink[0] = acc;
+}
+}  // namespace mkv
+
 // reads `groups` x pieces_per_group pieces of gran bytes from buf (buf_bytes: a power of two);
 // returns the bytes read, or a negative error
 extern "C" long long mkv_debug_random_read(const void *buf, long long buf_bytes, int gran, long long groups,
 		long long pieces_per_group, uint32_t *sink, void *stream)
 {
 	if (!buf || !sink || buf_bytes < 4096 || (buf_bytes & (buf_bytes - 1)) || groups < 64 || pieces_per_group < 4 ||
-			(pieces_per_group & 3) || (gran != 64 && gran != 128 && gran != 256))
+			(pieces_per_group & 7) || (gran != 32 && gran != 64 && gran != 128 && gran != 256))
 		return MKV_EINVAL;
 	const uint64_t mask = (uint64_t)buf_bytes / (uint64_t)gran - 1u;
 	const dim3 grid((unsigned)((groups * 4 + 255) / 256)), block(256);
 	const uint4 *b = reinterpret_cast<const uint4 *>(buf);
 	hipStream_t s = (hipStream_t)stream;
-	if (gran == 64)
+	if (gran == 32)
+		hipLaunchKernelGGL((mkv::k_random_read32<4>), grid, block, 0, s, b, mask, pieces_per_group, sink, 1u);
+	else if (gran == 64)
 		hipLaunchKernelGGL((mkv::k_random_read<64, 4>), grid, block, 0, s, b, mask, pieces_per_group, sink, 1u);
 	else if (gran == 128)
 		hipLaunchKernelGGL((mkv::k_random_read<128, 4>), grid, block, 0, s, b, mask, pieces_per_group, sink, 1u);

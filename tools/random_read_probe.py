@@ -17,10 +17,10 @@ L = load_library()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 for mib in (1024, 16):
     buf = torch.empty(mib << 18, dtype=torch.int32, device="cuda").random_()
-    for gran in (64, 128, 256):
+    for gran in (32, 64, 128, 256):
         for groups in (1 << 18, 1 << 20):
             pieces = (1 << 23) // groups * 4 if gran == 64 else (1 << 23) // groups * 2
-            pieces = max(4, pieces & ~3)
+            pieces = max(8, pieces & ~7)
             best = None
             for _ in range(5):
                 a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
