@@ -67,7 +67,9 @@ def _stream_ptr(stream):
 
 
 def _dev_ptr(t):
-    assert t.is_cuda and t.is_contiguous(), "contiguous CUDA tensor expected"
+    # (pinned host memory is mapped into the device's address space at the same address: the
+    # kernels can read requests from it and write results to it over PCIe, see tools/zero_copy_probe.py)
+    assert (t.is_cuda or t.is_pinned()) and t.is_contiguous(), "contiguous CUDA (or pinned host) tensor expected"
     return ctypes.c_void_p(t.data_ptr())
 
 

@@ -313,6 +313,48 @@ def test_cycle_equals_search_delete_insert(memset, overlap, scheme):
             assert np.array_equal(got, exp), (step, first_diff(got, exp))
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_cycle_on_pinned_host_buffers(scheme):
+    """Requests, insert blocks and results in pinned HOST memory (mapped into the device's
+    address space): the cycle's kernels read and write them over PCIe, no copies.  Same
+    results as the oracle, several cycles in a row."""
+    g = Geometry(mem_p=16, scheme=scheme)
+    og = ogeom(g)
+    rng = np.random.default_rng(4100 + scheme)
+    img = random_table(g, rng, 0.5, 1 << 20)
+    idx = HashIndex(g)
+    idx.load_table(img)
+    exp = img.copy()
+    stream = torch.cuda.Stream()
+
+    def pin(a):
+        return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).pin_memory()
+
+    with torch.cuda.stream(stream):
+        for step in range(3):
+            q = random_requests(g, rng, 6000, 1 << 20)[:, :2].copy()
+            d = random_requests(g, rng, 500, 1 << 20)
+            e = random_requests(g, rng, 4000, 1 << 20, hot=0.1)
+            occ = np.argwhere(exp[:, :8] != 0)[:2000]
+            for k, (b, s) in enumerate(occ):
+                q[k] = (exp[b, s], b)
+                if k < 200:
+                    d[k] = (exp[b, s], b, exp[b, 8 + s])
+            blocks = split_blocks(e, g, rng, "region")
+            hq, hd = pin(q), pin(d)
+            hblocks = [pin(b.reshape(-1, 3)) for b in blocks]
+            ptrs, cnts, keep = idx.stage_blocks(hblocks)          # device array of HOST block pointers
+            out = pin(np.full((q.shape[0], 2), 0x5555AAAA, np.uint32))
+            idx.cycle(hq, out, ptrs, cnts, len(keep), delem=hd, stream=stream, insert_hint=e.shape[0])
+            exp_out = O.search(og, exp, q)
+            O.delete(og, exp, d)
+            O.insert(og, exp, blocks)
+            stream.synchronize()
+            assert np.array_equal(out.numpy().view(np.uint32), exp_out), f"search of cycle {step}"
+            got = idx.table_numpy()
+            assert np.array_equal(got, exp), (step, first_diff(got, exp))
+
+
 def test_large_preload_with_chunks_and_carries_matches_oracle():
     """24 M keys into a MEM_P=29 table (load factor 0.36) in 1 M-request calls: every
     call runs as 64 K chunks with a size hint, barriers appear as the table fills and
