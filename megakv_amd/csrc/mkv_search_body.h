@@ -89,6 +89,78 @@ __device__ __forceinline__ void search_body(uint32_t block, const uint2 *__restr
 	}
 }
 
+// row_shl:4 -- lane i takes the value of lane i+4 (inside its row of 16)
+__device__ __forceinline__ uint32_t dpp_from_plus4(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);
+}
+
+// The same search with 8 lanes per request: a quad owns one bucket, each lane one 16-byte
+// quarter of it (sig[0..3], sig[4..7], loc[0..3], loc[4..7]), so a bucket is ONE 64-byte
+// access of one load instruction instead of two 32-byte halves of two instructions -- half
+// the cache-line look-ups per bucket in the L1.  Lanes 0/1 of the quad compare, the
+// locations come over from lanes 2/3 with a quad permute.  8 * U requests per wave.
+template <int U, bool ZERO_MISS, bool NT>
+__device__ __forceinline__ void search_body_wide(uint32_t block, const uint2 *__restrict__ in,
+		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n,
+		uint32_t hash_mask, uint32_t blk_mask)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t q = lane & 3u;            // quarter of the bucket
+	const uint32_t side = (lane >> 2) & 1u;  // 0: primary bucket, 1: alternate
+	const uint32_t grp = lane >> 3;          // request slot inside the wave, 0..7
+	const int64_t wave = (int64_t)block * (blockDim.x >> 6) + (threadIdx.x >> 6);
+	const int64_t base = wave * (8 * U);
+
+	u32x4 v[U];
+	uint32_t sig[U];
+	bool live[U];
+
+#pragma unroll
+	for (int u = 0; u < U; u++) {
+		const int64_t e = base + u * 8 + grp;
+		live[u] = e < n;
+		uint2 req = live[u] ? in[e] : make_uint2(0u, 0u);    // {sig, hash}
+		sig[u] = req.x;
+		const uint32_t pri = req.y & hash_mask;
+		const uint32_t alt = alt_bucket(req.y, req.x, hash_mask, blk_mask);
+		const uint32_t b = side ? alt : pri;
+		const u32x4 *p = reinterpret_cast<const u32x4 *>(table) + ((uint64_t)b << 2) + q;
+		if (live[u])
+			v[u] = NT ? __builtin_nontemporal_load(p) : p[0];
+		else
+			v[u] = (u32x4)(0u);
+	}
+
+#pragma unroll
+	for (int u = 0; u < U; u++) {
+		const int64_t e = base + u * 8 + grp;
+		// the locations of this lane's four signatures: same quarter index, two lanes up
+		const uint32_t lx = dpp_swap2(v[u].x), ly = dpp_swap2(v[u].y), lz = dpp_swap2(v[u].z),
+				lw = dpp_swap2(v[u].w);
+		// highest matching slot of this lane's four (lanes 2/3 compare locations: never read)
+		uint32_t hit = 0u, val = 0u;
+		if (v[u].x == sig[u]) { hit = 1u; val = lx; }
+		if (v[u].y == sig[u]) { hit = 1u; val = ly; }
+		if (v[u].z == sig[u]) { hit = 1u; val = lz; }
+		if (v[u].w == sig[u]) { hit = 1u; val = lw; }
+		// merge the pair: lane 1 holds slots 4..7 and takes precedence
+		const uint32_t phit = dpp_swap1(hit), pval = dpp_swap1(val);
+		if (q == 0u && phit) { hit = 1u; val = pval; }
+		if (ZERO_MISS) {
+			// lane 0 of the group gathers the alternate quad's result and stores both words
+			const uint32_t ahit = dpp_from_plus4(hit), aval = dpp_from_plus4(val);
+			if ((lane & 7u) == 0u && live[u]) {
+				uint2 r = make_uint2(hit ? val : 0u, ahit ? aval : 0u);
+				*reinterpret_cast<uint2 *>(out + 2 * e) = r;
+			}
+		} else {
+			if (q == 0u && hit && live[u])
+				out[2 * e + side] = val;
+		}
+	}
+}
+
 // Search of the slots a shard received (padded exchange format, mkv_route.hip):
 // linear block index -> (slot, 256-request chunk); the slot's request count is read
 // from its header on the device.

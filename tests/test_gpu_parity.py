@@ -26,6 +26,7 @@ def _defaults():
     set_tuning("insert_chunk", 65536)
     set_tuning("search_u", 4)
     set_tuning("search_nt", 0)
+    set_tuning("search_wide", 0)
 
 
 # ---------------------------------------------------------------- search ----
@@ -61,6 +62,28 @@ def test_search_tuning_variants_agree(u, nt):
     idx.load_table(img)
     out = idx.search(dev(q))
     assert np.array_equal(host(out), O.search(ogeom(g), img, q))
+
+
+@pytest.mark.parametrize("u", [1, 4])
+@pytest.mark.parametrize("zero_miss", [True, False])
+@pytest.mark.parametrize("n", [1, 9, 64, 30011])
+def test_search_wide_layout_agrees(u, zero_miss, n):
+    """The 8-lanes-per-request layout (one 64-byte access per bucket; slower, kept as a
+    measured alternative: DESIGN 5.1) gives the same results, ragged tails included."""
+    set_tuning("search_u", u)
+    set_tuning("search_wide", 1)
+    g = Geometry(mem_p=18)
+    rng = np.random.default_rng(78 + n)
+    img = random_table(g, rng, 0.6, sig_space=60)          # few signatures: in-bucket duplicates
+    q = random_requests(g, rng, n, 60)[:, :2].copy()
+    idx = HashIndex(g)
+    idx.load_table(img)
+    exp = np.zeros((n, 2), np.uint32) if zero_miss else np.full((n, 2), 0xABCD1234, np.uint32)
+    O.search(ogeom(g), img, q, out=exp)
+    out = dev(np.full((n, 2), 0xABCD1234, np.uint32))
+    idx.search(dev(q), out=out, zero_miss=zero_miss)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out), exp)
 
 
 def test_search_kat_image_reference_test():

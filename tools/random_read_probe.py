@@ -33,3 +33,19 @@ for mib in (1024, 16):
                 best = t if best is None or t < best else best
             print(f"buffer {mib:5d} MiB  piece {gran:3d} B  groups {groups:8d} x {pieces:3d} pieces: "
                   f"{n / 1e6:8.1f} MB in {best * 1e6:7.1f} us = {n / best / 1e12:5.2f} TB/s ({n / best / 8e12:4.2f} of 8 TB/s)")
+
+# at the size of ONE search launch: 2^21 bucket reads (2^20 GETs) and multiples
+buf = torch.empty(1024 << 18, dtype=torch.int32, device="cuda").random_()
+for groups, pieces in ((1 << 18, 8), (1 << 19, 8), (1 << 17, 16), (1 << 18, 16), (1 << 18, 32)):
+    best = None
+    for _ in range(7):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record()
+        n = L.mkv_debug_random_read(_dev_ptr(buf), 1024 << 20, 64, groups, pieces, _dev_ptr(sink), _stream_ptr(None))
+        b.record()
+        torch.cuda.synchronize()
+        assert n > 0, n
+        t = a.elapsed_time(b) * 1e-3
+        best = t if best is None or t < best else best
+    print(f"groups {groups} x {pieces} pieces of 64 B = {groups * pieces / 2 ** 20:.1f} M pieces: {best * 1e6:.1f} us = "
+          f"{groups * pieces / best / 1e9:.1f} G pieces/s")
