@@ -378,6 +378,49 @@ def test_cycle_on_pinned_host_buffers(scheme):
             assert np.array_equal(got, exp), (step, first_diff(got, exp))
 
 
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_largest_geometry_mem_p_33(scheme):
+    """MEM_P=33, the largest table the library takes (8 GiB, 2^27 buckets; word offsets reach
+    2^31): insert with duplicates, search, delete, search -- against the oracle on a lazily
+    committed host image.  The tables are compared on every bucket a request can have touched
+    (both candidates of every request; eviction chains do not occur at this fill)."""
+    if torch.cuda.mem_get_info()[0] < (10 << 30):
+        pytest.skip("needs 10 GiB of free device memory")
+    g = Geometry(mem_p=33, scheme=scheme)
+    og = ogeom(g)
+    rng = np.random.default_rng(3300 + scheme)
+    exp = O.new_table(og)
+    idx = HashIndex(g)
+    n = 300000
+    e = random_requests(g, rng, n, 1 << 31, hot=0.05)
+    e[: n // 8, 1] |= np.uint32(0xFFFF0000)                    # a good share in the topmost buckets
+    blocks = split_blocks(e, g, rng, "region")
+    st = O.insert(og, exp, blocks)
+    idx.insert([dev(b.reshape(-1, 3)) for b in blocks])
+    P = e[:, 1] & np.uint32(g.hash_mask)
+    A = (((e[:, 1] ^ e[:, 0]) & np.uint32(g.block_hash_mask)) | (e[:, 1] & ~np.uint32(g.block_hash_mask))) & np.uint32(g.hash_mask)
+    rows = np.unique(np.concatenate([P, A, [0, g.nbuckets - 1]])).astype(np.int64)
+    assert rows.max() == g.nbuckets - 1 and (rows >> 24).max() == 7
+
+    def touched():
+        return idx.table.view(-1, 16)[torch.from_numpy(rows).cuda()].cpu().numpy().view(np.uint32)
+
+    got = touched()
+    assert np.array_equal(got, exp[rows]), first_diff(got, exp[rows])
+    q = np.ascontiguousarray(e[:, :2])
+    assert np.array_equal(host(idx.search(dev(q))), O.search(og, exp, q))
+    d = np.ascontiguousarray(e[::2])
+    O.delete(og, exp, d)
+    idx.delete(dev(d))
+    got = touched()
+    assert np.array_equal(got, exp[rows]), first_diff(got, exp[rows])
+    assert np.array_equal(host(idx.search(dev(q))), O.search(og, exp, q))
+    # nothing outside the touched buckets was written: the table holds exactly the oracle's entries
+    assert int((idx.table.view(-1, 16)[:, :8] != 0).sum().item()) == int((exp[rows][:, :8] != 0).sum())
+    del idx
+    torch.cuda.empty_cache()
+
+
 def test_large_preload_with_chunks_and_carries_matches_oracle():
     """24 M keys into a MEM_P=29 table (load factor 0.36) in 1 M-request calls: every
     call runs as 64 K chunks with a size hint, barriers appear as the table fills and
