@@ -341,7 +341,8 @@ def main():
                        "preloaded_keys": stream_gen.P - 1, "miss_zeroing": "memset" if args.memset else "by the search kernel", "mark_pass": args.overlap,
                        "slot_capacity_factor": slot_factor,
                        "sharding": "single table" if not sharded else
-                       f"{world} shards by top bucket bits, RCCL all-to-all, "
+                       f"{world} shards by top bucket bits, "
+                       + ("all-to-all staged through host memory (gloo), " if args.comm == "staged" else "RCCL all-to-all, ")
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else
                        ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
