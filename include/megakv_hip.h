@@ -115,9 +115,10 @@ int mkv_last_update_info(void *stream, mkv_update_info_t *info);
 /* cycle_insert != 0: the insert half of the last mkv_cycle on `stream` */
 int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
 /* diagnostics: microseconds the last call's tail kernels spent per phase (roll-back, gather,
- * exact replay below a barrier, retag, in-group rounds, serial replay; two spare), summed
- * over the call's passes.  Synchronises the stream. */
-int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[8]);
+ * exact replay below a barrier, retag, in-group rounds, serial replay, two gather details; then
+ * inside the grid-wide rounds: register, meeting, decide, meeting, election + meeting, commit,
+ * meeting, one spare), summed over the call's passes.  Synchronises the stream. */
+int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[16]);
 /* diagnostics: the random-read rate of the memory system -- groups of 4 lanes read
  * pieces_per_group (a multiple of 8) pseudo-random gran-byte pieces (32 / 64 / 128 / 256) of buf
  * (buf_bytes a power of two), 4 pieces in flight per group as in the search kernel; returns

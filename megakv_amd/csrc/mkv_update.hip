@@ -144,7 +144,8 @@ struct Ctl {
 	uint32_t g_progress[2], g_left[2];
 	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
-	uint32_t tail_phase[8];          // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
+	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
+	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
 };
 
 struct Req {
@@ -1487,10 +1488,13 @@ template <Op OP>
 __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
-		int max_rounds, uint32_t *rounds_used, uint32_t *par_total)
+		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks)
 {
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
+	unsigned long long tick = wall_clock64();
+	// ticks[0..7]: register, its meeting, decide, its meeting, election + meeting, commit, its meeting
+#define MKV_GTICK(k) do { const unsigned long long now_ = wall_clock64(); ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
 	const unsigned long long stamp0 = ctl->stamp_base + 2;
 	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
 	uint32_t left = m, nth = 0, used = 0, par = 0, recent = 0;
@@ -1527,7 +1531,9 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		__syncthreads();
 		if (OP == OP_CUCKOO && t < g.nregions && s_rmin[t] != kNone)
 			atomicMin(&ctl->g_rmin[set][t], s_rmin[t]);
+		MKV_GTICK(0);
 		grid_sync_nth(&ctl->g_sync, nwg, &nth);
+		MKV_GTICK(1);
 		// decide: the lowest index per region that is hard or might turn hard
 		if (OP != OP_DELETE) {
 			for (uint32_t i = first; i < m; i += span) {
@@ -1586,7 +1592,9 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				atomicMin(&ctl->g_rbar[set][t], s_rbar[t]);
 			if (t == 0 && *s_dupw)
 				atomicOr(&ctl->g_dupw[set], 1u);
+			MKV_GTICK(2);
 			grid_sync_nth(&ctl->g_sync, nwg, &nth);
+			MKV_GTICK(3);
 			if (t < kMaxRegions) {
 				s_rbar[t] = t < g.nregions ? ld_agent32(&ctl->g_rbar[set][t]) : kNone;
 				s_rmin[t] = t < g.nregions ? ld_agent32(&ctl->g_rmin[set][t]) : kNone;
@@ -1604,6 +1612,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 							stamp, live);
 				}
 				grid_sync_nth(&ctl->g_sync, nwg, &nth);
+				MKV_GTICK(4);
 			}
 		}
 		// the idle set is made ready for the next round
@@ -1669,7 +1678,9 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 			if (*s_left)
 				atomicAdd(&ctl->g_left[set], *s_left);
 		}
+		MKV_GTICK(5);
 		grid_sync_nth(&ctl->g_sync, nwg, &nth);
+		MKV_GTICK(6);
 		const uint32_t progress = ld_agent32(&ctl->g_progress[set]);
 		left = ld_agent32(&ctl->g_left[set]);
 		par += progress;
@@ -1699,7 +1710,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	__shared__ uint32_t s_carry;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	unsigned long long tick = wall_clock64();
-	uint32_t phase_ticks[8] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
+	uint32_t phase_ticks[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #define MKV_PHASE(k) do { const unsigned long long now_ = wall_clock64(); phase_ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
 	const uint32_t total_all = ctl->total;
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
@@ -1960,7 +1971,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	if (m != 0 && grid_mode) {
 		uint32_t par = 0;
 		const uint32_t left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin,
-				&s_progress, &s_left, &s_dupw, kGridRoundsMax, &rounds_used, &par);
+				&s_progress, &s_left, &s_dupw, kGridRoundsMax, &rounds_used, &par, phase_ticks + 8);
 		if (wg != 0)
 			return;
 		if (t == 0)
@@ -2037,7 +2048,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	}
 	if (t == 0) {
 		// diagnostics of this call (summed over its chunks), then the control block of the next pass
-		for (int k = 0; k < 8; k++)
+		for (int k = 0; k < 16; k++)
 			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + phase_ticks[k];
 		ctl->last.total = total_all;
 		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
@@ -2709,7 +2720,7 @@ extern "C" int mkv_debug_stamp_resets(void *stream, int cycle_insert)
 
 // diagnostics: microseconds the last call's tail kernels spent per phase
 // (roll-back, gather, exact replay, retag, in-group rounds, serial), summed over its passes
-extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[8])
+extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_us[16])
 {
 	int dev = 0;
 	if (!out_us || hipGetDevice(&dev) != hipSuccess)
@@ -2727,7 +2738,7 @@ extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_u
 	if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess ||
 			hipMemcpy(&h, w->ctl, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
 		return MKV_EHIP;
-	for (int k = 0; k < 8; k++)
+	for (int k = 0; k < 16; k++)
 		out_us[k] = (float)h.tail_phase[k] * 0.01f;
 	return MKV_OK;
 }

@@ -222,7 +222,7 @@ class HashIndex:
     def tail_phases_us(self, stream=None, cycle_insert=False):
         """diagnostics: time of the last call's tail kernels per phase (roll-back, gather,
         exact replay, retag, in-group rounds, serial), microseconds"""
-        out = (ctypes.c_float * 8)()
+        out = (ctypes.c_float * 16)()
         _check(self.lib.mkv_debug_tail_phases(_stream_ptr(stream), 1 if cycle_insert else 0, out),
                "mkv_debug_tail_phases")
         return [round(float(x), 1) for x in out]
