@@ -233,10 +233,18 @@ int mkv_shard_overflowed(mkv_shard_t *e, int *flag);   /* synchronises the devic
 const char *mkv_shard_error(const mkv_shard_t *e);
 void mkv_shard_destroy(mkv_shard_t *e);
 
-/* Tuning knobs: "search_u" (1/2/4/8 requests in flight per lane group),
- * "search_nt" (non-temporal table loads), "tail_rounds" (0..48 reservation
- * rounds inside the tail work-group), "insert_chunk" (requests per chunk of a hinted insert), "req_cap" (default requests per update
- * call).  Results never depend on them; they exist for measurement and tests. */
+/* Tuning knobs (all but the debug ones also environment variables MKV_<NAME>, read once at start-up):
+ *   search:  "search_u" (1/2/4/8 requests in flight per lane group), "search_nt" (non-temporal
+ *            table loads), "search_wide" (8 lanes per request, one 64-byte access per bucket);
+ *   update:  "tail_rounds" (0..48 reservation rounds of the tail), "tail_groups" (work-groups of
+ *            the tail launch, 1..64), "grid_min" (a final tail list longer than this runs its
+ *            rounds on all of them), "insert_chunk" (requests per pass of a hinted insert),
+ *            "calm_factor" (passes that many times larger while no barrier was met lately),
+ *            "barrier_sticky", "barrier_split", "mark_blocks", "req_cap" (default request
+ *            capacity of an update workspace);
+ *   sharded: "pack_three_pass";
+ *   tests:   "debug_first_stamp", "debug_skip" (breaks results: timing experiments only).
+ * Results never depend on them (debug_skip aside); they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);
 
 const char *mkv_version(void);
