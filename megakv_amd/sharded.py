@@ -253,7 +253,8 @@ class ShardedIndex:
 
     # -- shard of a request ---------------------------------------------------------
     def shard_of(self, hash_np):
-        return (hash_np.astype(np.uint64) & np.uint64(self.agg_mask)) >> np.uint64(self.shift)
+        h = np.ascontiguousarray(hash_np, dtype=np.uint32)       # (a strided column is several times slower)
+        return (h & np.uint32(self.agg_mask)) >> np.uint32(self.shift)
 
     # -- one step -----------------------------------------------------------------------
     def _forward(self, ln, gets, sets, sp=None):
@@ -344,7 +345,7 @@ class ShardedIndex:
         for lo in range(1, P, step):
             k = np.arange(lo, min(lo + step, P), dtype=np.uint64).astype(np.uint32)
             e = W.make_ielem(k, None, keying)
-            mine = e[self.shard_of(e[:, 1]) == self.rank]
+            mine = np.take(e, np.flatnonzero(self.shard_of(e[:, 1]) == self.rank), axis=0)
             blocks = W.bin_inserts(mine, g.mem_p, g.iblock_p, W.BIN_REGION)
             self.idx.insert([torch.from_numpy(np.ascontiguousarray(b).view(np.int32)).to(self.device)
                              for b in blocks])
