@@ -11,7 +11,9 @@
  * It is the build's own counterpart of the caller (the reference's .c files
  * are not copied) and doubles as the link test of lib/libgpuhash.a:
  *   gcc -Iinclude examples/scheduler_cycle.c -Llib -lgpuhash -lamdhip64 -lstdc++
- * usage: scheduler_cycle [cycles] [worker streams, default 4]
+ * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0]
+ *   mapped = 1: no staging copies; the library gets the pinned host buffers themselves
+ *   (mapped into the device's address space), same calls, same checks.
  * Self-checking: every key inserted in cycle c is found in cycle c+1 with its
  * loc (property P1 of libgpuhash/test/insert_test.c:178-195), deleted keys are
  * gone (P2, :237-244).  Exit code 0 = all checks passed.
@@ -54,6 +56,7 @@ typedef struct worker_s {
 	ielem_t *insert_in_d;				/* device, INSERT_BLOCK slices */
 	ielem_t **insert_ptrarray_d;		/* device array of device pointers */
 	int *insert_job_num_d;
+	int *insert_job_num_p;				/* mapped mode: the counts in pinned host memory */
 	int insert_job_num[INSERT_BLOCK];
 	int num_search, num_delete, num_gone;
 	uint32_t *search_keys;
@@ -66,6 +69,10 @@ int main(int argc, char **argv)
 	 * against each other (SURVEY B-1): with several workers a lost update between two
 	 * concurrent inserts into one bucket is possible by design.  1 worker = fully defined. */
 	int WORKERS = argc > 2 ? atoi(argv[2]) : 4;
+	/* 1: no staging copies -- the pinned host buffers are mapped into the device's address space
+	 * (same addresses), so the library is handed the host buffers themselves and its kernels read
+	 * the requests and write the results over PCIe.  0: the reference's copies. */
+	int MAPPED = argc > 3 ? atoi(argv[3]) : 0;
 	uint8_t *table;
 	worker_t w[MAX_WORKERS];
 	if (WORKERS < 1 || WORKERS > MAX_WORKERS)
@@ -90,8 +97,9 @@ int main(int argc, char **argv)
 		CUDA_SAFE_CALL(cudaMalloc((void **)&k->insert_job_num_d, INSERT_BLOCK * sizeof(int)));
 		for (b = 0; b < INSERT_BLOCK; b++) {
 			CUDA_SAFE_CALL(cudaHostAlloc((void **)&k->insert_in[b], MAX_INSERT * sizeof(ielem_t), cudaHostAllocDefault));
-			ptrs[b] = k->insert_in_d + (size_t)b * MAX_INSERT;
+			ptrs[b] = MAPPED ? k->insert_in[b] : k->insert_in_d + (size_t)b * MAX_INSERT;
 		}
+		CUDA_SAFE_CALL(cudaHostAlloc((void **)&k->insert_job_num_p, INSERT_BLOCK * sizeof(int), cudaHostAllocDefault));
 		/* written once at init, like src/mega_recv.c:186-191 */
 		CUDA_SAFE_CALL(cudaMemcpy(k->insert_ptrarray_d, ptrs, sizeof(ptrs), cudaMemcpyHostToDevice));
 		k->search_keys = (uint32_t *)malloc(MAX_SEARCH * sizeof(uint32_t));
@@ -128,6 +136,12 @@ int main(int argc, char **argv)
 			worker_t *k = &w[id];
 			if (k->num_search == 0)
 				continue;
+			if (MAPPED) {
+				memset(k->search_out, 0, 2 * k->num_search * sizeof(loc_t));
+				gpu_hash_search(k->search_in, k->search_out, (bucket_t *)table, k->num_search, 24576, 256, k->stream);
+				total_search += k->num_search;
+				continue;
+			}
 			CUDA_SAFE_CALL(cudaMemcpyAsync(k->search_in_d, k->search_in, k->num_search * sizeof(selem_t),
 						cudaMemcpyHostToDevice, k->stream));
 			CUDA_SAFE_CALL(cudaMemsetAsync(k->search_out_d, 0, 2 * k->num_search * sizeof(loc_t), k->stream));
@@ -141,6 +155,11 @@ int main(int argc, char **argv)
 			worker_t *k = &w[id];
 			if (k->num_delete == 0)
 				continue;
+			if (MAPPED) {
+				gpu_hash_delete(k->delete_in, (bucket_t *)table, k->num_delete, 16384, 256, k->stream);
+				total_delete += k->num_delete;
+				continue;
+			}
 			CUDA_SAFE_CALL(cudaMemcpyAsync(k->delete_in_d, k->delete_in, k->num_delete * sizeof(delem_t),
 						cudaMemcpyHostToDevice, k->stream));
 			gpu_hash_delete(k->delete_in_d, (bucket_t *)table, k->num_delete, 16384, 256, k->stream);
@@ -148,6 +167,14 @@ int main(int argc, char **argv)
 		}
 		for (id = 0; id < WORKERS; id++) {				/* 3. insert */
 			worker_t *k = &w[id];
+			if (MAPPED) {
+				for (b = 0; b < INSERT_BLOCK; b++) {
+					k->insert_job_num_p[b] = k->insert_job_num[b];
+					total_insert += k->insert_job_num[b];
+				}
+				gpu_hash_insert((bucket_t *)table, k->insert_ptrarray_d, k->insert_job_num_p, INSERT_BLOCK, k->stream);
+				continue;
+			}
 			for (b = 0; b < INSERT_BLOCK; b++) {
 				if (k->insert_job_num[b] == 0)
 					continue;
@@ -211,8 +238,8 @@ int main(int argc, char **argv)
 	}
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	double us = 1e6 * (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) / 1e3;
-	printf("cycles %d workers %d: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d\n",
-			cycles, WORKERS, (unsigned long long)total_search, (unsigned long long)total_insert,
+	printf("cycles %d workers %d%s: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d\n",
+			cycles, WORKERS, MAPPED ? " (host buffers mapped, no copies)" : "", (unsigned long long)total_search, (unsigned long long)total_insert,
 			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors);
 	return errors ? 1 : 0;
 }

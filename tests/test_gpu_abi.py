@@ -87,6 +87,11 @@ def test_plain_c_scheduler_driver_runs_clean():
     import re
     errs = int(re.search(r"errors (\d+)", r.stdout).group(1))
     assert errs <= 20, r.stdout + r.stderr
+    # the same through the reference's three entry points on the pinned host buffers themselves
+    # (no staging copies: the kernels read requests and write results over PCIe)
+    r = subprocess.run([exe, "12", "1", "1"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout + r.stderr
+    assert "errors 0" in r.stdout and "no copies" in r.stdout
 
 
 def test_plain_c_driver_with_other_baked_in_macros():
