@@ -315,13 +315,20 @@ def main():
                     "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(len(ms)), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
                     "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2)}
 
+    # side measurements: whatever happens in them, the line with `value` is still printed
     pcie = None
     if rank == 0 and not sharded and not args.no_pcie:
-        pcie = pcie_inclusive(engine, batches[args.warmup:args.warmup + 24], run_stream, args)
+        try:
+            pcie = pcie_inclusive(engine, batches[args.warmup:args.warmup + 24], run_stream, args)
+        except Exception as ex:                                   # noqa: BLE001
+            pcie = {"error": f"{type(ex).__name__}: {ex}"}
 
     cpu = None
     if rank == 0 and not sharded and not args.no_cpu:
-        cpu = cpu_baseline(engine, stream_gen, args)
+        try:
+            cpu = cpu_baseline(engine, stream_gen, args)
+        except Exception as ex:                                   # noqa: BLE001
+            cpu = {"error": f"{type(ex).__name__}: {ex}"}
 
     if sharded and engine.overflowed():
         raise SystemExit("a shard slot overflowed: raise cap_factor (results of this run are invalid)")
@@ -432,7 +439,7 @@ def pcie_inclusive(engine, batches, stream, args):
     D2H of the results on the worker's stream, src/mega_scheduler.c:404-419,484-494).
     The batches are re-run (their SET keys are then updates), which does not change
     the bytes moved."""
-    if not batches:
+    if len(batches) < 6:                  # four warm-up steps of the copy paths, then at least two timed
         return None
     idx = engine.idx
     host = []
