@@ -277,11 +277,11 @@ def main():
             o = batches[args.warmup - 1]["out"]
             res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
             loc_ok = round(float((res == check_keys).mean()), 6)
-        barrier()
-        t_start = time.perf_counter()
         every = max(1, args.events_every)
         timer = engine.make_timer((args.steps + every - 1) // every) if (use_events and not args.graph) else None
         timed = batches[args.warmup:]
+        barrier()
+        t_start = time.perf_counter()
         if sharded and not args.no_pipeline:
             # two batches in flight: exchanges of one overlap the local kernels of the other
             engine.run_pipelined(timed, (lambda i: [timer.h, i // every] if (timer and i % every == 0) else None))
