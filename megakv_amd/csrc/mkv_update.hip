@@ -2068,7 +2068,6 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->bar_class;
 		ctl->bar_chain = 0;
 		ctl->bar_class = 0;
-		ctl->carry_lo = s_carry;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
@@ -2082,6 +2081,13 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	}
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
+	// The next pass's carry is published LAST.  A helper work-group that only gets to run
+	// now reads the control block while it is being reset: everything above changes towards
+	// "nothing to do" (it leaves), only the carry could widen the range it would scan -- once
+	// it sees the new carry it also sees the rest reset.  (Only work-group 0 comes here.)
+	__syncthreads();
+	if (t == 0)
+		ctl->carry_lo = s_carry;
 }
 
 __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
