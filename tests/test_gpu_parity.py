@@ -421,6 +421,32 @@ def test_largest_geometry_mem_p_33(scheme):
     torch.cuda.empty_cache()
 
 
+def test_index_fixture_through_the_library():
+    """tests/golden/index_kat.json replayed through the C ABI: the behaviours SURVEY 8(c) recorded
+    from the reference's code and the committed regression vectors, compared with the committed
+    rows / table digests / search results (no oracle involved)."""
+    from tests.golden_util import load_index_kat, initial_rows, blocks_of, check_step
+    for sc in load_index_kat():
+        g = Geometry(mem_p=sc["mem_p"], scheme=sc["scheme"], iblock_p=sc["iblock_p"], max_cuckoo=sc["max_cuckoo"])
+        idx = HashIndex(g)
+        bi, rows = initial_rows(sc)
+        tv = idx.table.view(-1, 16)
+        if len(bi):
+            tv[torch.from_numpy(bi).cuda()] = dev(rows)
+        for k, (op, exp) in enumerate(zip(sc["ops"], sc["expected"])):
+            out = None
+            if op["op"] == "insert":
+                idx.insert([dev(b) for b in blocks_of(op)])
+            elif op["op"] == "delete":
+                idx.delete(dev(np.array(op["requests"], dtype=np.uint32).reshape(-1, 3)))
+            else:
+                out = host(idx.search(dev(np.array(op["requests"], dtype=np.uint32).reshape(-1, 2))))
+            torch.cuda.synchronize()
+            check_step(sc["name"], k, exp, lambda i: host(tv[torch.from_numpy(i).cuda()]),
+                       lambda: idx.table_numpy(), out)
+        del idx
+
+
 def test_large_preload_with_chunks_and_carries_matches_oracle():
     """24 M keys into a MEM_P=29 table (load factor 0.36) in 1 M-request calls: every
     call runs as 64 K chunks with a size hint, barriers appear as the table fills and

@@ -288,3 +288,25 @@ def test_region_parallel_insert_equals_canonical_insert():
     O.insert(g, a, mixed)
     assert O.insert_mt(g, b, mixed) is False
     assert np.array_equal(a, b)
+
+
+# ---- the committed index fixture (tests/golden/index_kat.json) ---------------------------
+def test_oracle_reproduces_index_fixture():
+    """Every scenario of the fixture -- the SURVEY 8(c) answers and the regression vectors --
+    replayed with the oracle: rows / table digests / search results as committed."""
+    from tests.golden_util import load_index_kat, initial_rows, blocks_of, check_step
+    for sc in load_index_kat():
+        g = O.geom(mem_p=sc["mem_p"], scheme=sc["scheme"], iblock_p=sc["iblock_p"], max_cuckoo=sc["max_cuckoo"])
+        t = O.new_table(g)
+        idx, rows = initial_rows(sc)
+        if len(idx):
+            t[idx] = rows
+        for k, (op, exp) in enumerate(zip(sc["ops"], sc["expected"])):
+            out = None
+            if op["op"] == "insert":
+                O.insert(g, t, blocks_of(op))
+            elif op["op"] == "delete":
+                O.delete(g, t, np.array(op["requests"], dtype=np.uint32).reshape(-1, 3))
+            else:
+                out = O.search(g, t, np.array(op["requests"], dtype=np.uint32).reshape(-1, 2))
+            check_step(sc["name"], k, exp, lambda i: t[i], lambda: t, out)
