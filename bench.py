@@ -71,8 +71,7 @@ def parse():
                     help="sharded path: drive the step from Python/torch.distributed instead of the C engine")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1: run the steps strictly one after the other (no exchange/compute overlap)")
-    ap.add_argument("--events-every", type=int, default=0,
-                    help="time the search launch of every n-th step (0: every 4th, every steps/12-th in longer runs)")
+    ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
@@ -278,8 +277,7 @@ def main():
             o = batches[args.warmup - 1]["out"]
             res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
             loc_ok = round(float((res == check_keys).mean()), 6)
-        # (an event pair around a launch costs ~7 us of gaps on that step: a dozen samples are enough)
-        every = args.events_every if args.events_every > 0 else max(4, args.steps // 12)
+        every = max(1, args.events_every)
         timer = engine.make_timer((args.steps + every - 1) // every) if (use_events and not args.graph) else None
         timed = batches[args.warmup:]
         barrier()
