@@ -300,6 +300,19 @@ def main():
     n_ops = (1 << args.batch_log2) * args.steps * world
     value = n_ops / elapsed / 1e6
 
+    # the results of the LAST timed batch, checked like those of the warm-up: every GET of a
+    # pre-loaded key must have come back with its own key id in its own place (all ranks)
+    loc_ok_last = None
+    if args.steps and args.lf <= 0.5:
+        o = batches[-1]["out"]
+        res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
+        loc_ok_last = float((res == stream_gen.last_get_keys).mean())
+        if dist is not None:
+            t = torch.tensor([loc_ok_last], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
+            dist.all_reduce(t, op=dist.ReduceOp.MIN)
+            loc_ok_last = float(t.item())
+        loc_ok_last = round(loc_ok_last, 6)
+
     roofline = None
     if use_events and timer:
         ms = np.array(timer.elapsed_ms())
@@ -353,7 +366,8 @@ def main():
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else
                        ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
-            "get_hit_rate": hit_rate, "get_loc_correct": loc_ok, "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
+            "get_hit_rate": hit_rate, "get_loc_correct": loc_ok, "get_loc_correct_last_timed": loc_ok_last,
+            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
