@@ -421,6 +421,36 @@ def test_largest_geometry_mem_p_33(scheme):
     torch.cuda.empty_cache()
 
 
+def test_baseline_config1_shape_through_the_library():
+    """BASELINE configs[0] (the reference's LOCAL_TEST shape: MEM_P=25, two-choice, reference keying,
+    pre-load of P-1 = 838 859 SETs in batches of <= 8 x 4096 binned the receiver's way, then uniform
+    GET batches of 32 767 = batch_max_search_job - 1) through the library: table image equal to the
+    oracle's, every GET hits in its primary bucket with loc == key (tests/test_workload.py runs the
+    same on the oracle alone)."""
+    from megakv_amd import workload as W
+    mem_p = 25
+    g = Geometry(mem_p=mem_p, scheme=1)
+    og = ogeom(g)
+    exp = O.new_table(og)
+    idx = HashIndex(g)
+    P = W.preload_count(mem_p)
+    keys = np.arange(1, P, dtype=np.uint32)
+    for lo in range(0, keys.shape[0], 8 * 4095):
+        e = W.make_ielem(keys[lo:lo + 8 * 4095], None, W.KEYING_REF)
+        blocks = W.bin_inserts(e, mem_p, 3, W.BIN_APP)
+        O.insert(og, exp, blocks)
+        idx.insert([dev(b.reshape(-1, 3)) for b in blocks], hint=0)          # the plain ABI: no size hint
+    got = idx.table_numpy()
+    assert np.array_equal(got, exp), first_diff(got, exp)
+    z = W.ZipfKeys(P - 2, 0.0, 21)
+    blk_mask = (1 << (mem_p - 9)) - 1
+    for _ in range(3):
+        k = z.keys(32767)
+        out = host(idx.search(dev(W.make_selem(k, W.KEYING_REF))))
+        assert np.array_equal(out[:, 0], k)                                   # 100 % hits, loc = key
+        assert np.array_equal(out[:, 1], np.where((k & blk_mask) == 0, k, 0))
+
+
 def test_index_fixture_through_the_library():
     """tests/golden/index_kat.json replayed through the C ABI: the behaviours SURVEY 8(c) recorded
     from the reference's code and the committed regression vectors, compared with the committed
