@@ -592,8 +592,8 @@ def cpu_baseline(engine, sg, args):
                       f"table in {'transparent huge pages (madvise)' if huge else '4 KiB pages'}",
             "all_threads": {"value": round(ops / dt_mt / 1e6, 1), "threads": ncpu,
                             "insert_threads": 1 << g.iblock_p,
-                            "note": "searches over all threads, inserts one thread per closed region; threads are "
-                                    "created per batch (more than 64 of them cost more than they bring)"},
+                            "note": "searches over a persistent pool of host threads, inserts one thread per closed "
+                                    "region (64 threads: 128 or 256 of this box's 256 hardware threads run slower)"},
             "search_only_all_threads": {"value": round(mt_search, 1), "threads": ncpu}}
 
 

@@ -124,6 +124,74 @@ void orc_search(const orc_geom_t *g, const orc_bucket_t *table,
 	}
 }
 
+/* A persistent pool of host threads for the all-threads legs of the CPU baseline (threads made
+ * once, jobs handed out in parts): making and joining 64 and more threads per 2^20-request batch
+ * costs as much as the batch. */
+typedef void (*pool_fn)(void *arg, int part);
+static struct {
+	pthread_mutex_t mu;
+	pthread_cond_t start, done;
+	int nthreads;
+	unsigned long gen;
+	int nparts, next_part, remaining;
+	pool_fn fn;
+	void *arg;
+} P = { PTHREAD_MUTEX_INITIALIZER, PTHREAD_COND_INITIALIZER, PTHREAD_COND_INITIALIZER, 0, 0, 0, 0, 0, NULL, NULL };
+
+static void *pool_worker(void *unused)
+{
+	(void)unused;
+	unsigned long seen = 0;
+	pthread_mutex_lock(&P.mu);
+	for (;;) {
+		while (P.gen == seen)
+			pthread_cond_wait(&P.start, &P.mu);
+		seen = P.gen;
+		while (P.next_part < P.nparts) {
+			const int part = P.next_part++;
+			const pool_fn fn = P.fn;
+			void *arg = P.arg;
+			pthread_mutex_unlock(&P.mu);
+			fn(arg, part);
+			pthread_mutex_lock(&P.mu);
+			if (--P.remaining == 0)
+				pthread_cond_signal(&P.done);
+		}
+	}
+	return NULL;
+}
+
+/* runs fn(arg, 0..nparts-1) on up to nthreads pool threads and waits; one caller at a time */
+static void pool_run(int nthreads, pool_fn fn, void *arg, int nparts)
+{
+	if (nparts <= 0)
+		return;
+	pthread_mutex_lock(&P.mu);
+	while (P.nthreads < nthreads) {
+		pthread_t t;
+		if (pthread_create(&t, NULL, pool_worker, NULL) != 0)
+			break;
+		pthread_detach(t);
+		P.nthreads++;
+	}
+	if (P.nthreads == 0) {				/* no thread could be made: run here */
+		pthread_mutex_unlock(&P.mu);
+		for (int p = 0; p < nparts; p++)
+			fn(arg, p);
+		return;
+	}
+	P.fn = fn;
+	P.arg = arg;
+	P.nparts = nparts;
+	P.next_part = 0;
+	P.remaining = nparts;
+	P.gen++;
+	pthread_cond_broadcast(&P.start);
+	while (P.remaining)
+		pthread_cond_wait(&P.done, &P.mu);
+	pthread_mutex_unlock(&P.mu);
+}
+
 struct search_job {
 	const orc_geom_t *g;
 	const orc_bucket_t *table;
@@ -132,11 +200,18 @@ struct search_job {
 	int64_t n;
 };
 
-static void *search_worker(void *p)
+struct search_parts {
+	struct search_job whole;
+	int64_t chunk;
+};
+
+static void search_part(void *p, int part)
 {
-	struct search_job *j = (struct search_job *)p;
-	orc_search(j->g, j->table, j->in, j->out, j->n);
-	return NULL;
+	const struct search_parts *j = (const struct search_parts *)p;
+	int64_t lo = j->chunk * part, hi = lo + j->chunk;
+	if (lo > j->whole.n) lo = j->whole.n;
+	if (hi > j->whole.n) hi = j->whole.n;
+	orc_search(j->whole.g, j->whole.table, j->whole.in + lo, j->whole.out + 2 * lo, hi - lo);
 }
 
 void orc_search_mt(const orc_geom_t *g, const orc_bucket_t *table,
@@ -146,25 +221,16 @@ void orc_search_mt(const orc_geom_t *g, const orc_bucket_t *table,
 		orc_search(g, table, in, out, n);
 		return;
 	}
-	pthread_t *tid = (pthread_t *)malloc(sizeof(pthread_t) * (size_t)nthreads);
-	struct search_job *jobs =
-		(struct search_job *)malloc(sizeof(struct search_job) * (size_t)nthreads);
-	int64_t chunk = (n + nthreads - 1) / nthreads;
-	for (int t = 0; t < nthreads; t++) {
-		int64_t lo = chunk * t, hi = lo + chunk;
-		if (lo > n) lo = n;
-		if (hi > n) hi = n;
-		jobs[t].g = g;
-		jobs[t].table = table;
-		jobs[t].in = in + lo;
-		jobs[t].out = out + 2 * lo;
-		jobs[t].n = hi - lo;
-		pthread_create(&tid[t], NULL, search_worker, &jobs[t]);
-	}
-	for (int t = 0; t < nthreads; t++)
-		pthread_join(tid[t], NULL);
-	free(jobs);
-	free(tid);
+	struct search_parts j;
+	j.whole.g = g;
+	j.whole.table = table;
+	j.whole.in = in;
+	j.whole.out = out;
+	j.whole.n = n;
+	/* four parts per thread: a thread that starts late or is descheduled does not hold the others up */
+	const int nparts = nthreads * 4;
+	j.chunk = (n + nparts - 1) / nparts;
+	pool_run(nthreads, search_part, &j, nparts);
 }
 
 /* ---- insert ------------------------------------------------------------- */
@@ -316,9 +382,9 @@ struct insert_job {
 	int n;
 };
 
-static void *insert_worker(void *p)
+static void insert_part(void *p, int part)
 {
-	struct insert_job *j = (struct insert_job *)p;
+	struct insert_job *j = (struct insert_job *)p + part;
 	orc_stats_t st;
 	memset(&st, 0, sizeof(st));
 	for (int i = 0; i < j->n; i++) {
@@ -329,7 +395,6 @@ static void *insert_worker(void *p)
 		else
 			insert_cuckoo_one(j->g, j->table, &j->in[i], &st);
 	}
-	return NULL;
 }
 
 int orc_insert_mt(const orc_geom_t *g, orc_bucket_t *table, const orc_ielem_t *const *blk_input,
@@ -352,17 +417,14 @@ int orc_insert_mt(const orc_geom_t *g, orc_bucket_t *table, const orc_ielem_t *c
 			if (region_of[b] >= 0 && region_of[c] == region_of[b])
 				return 0;
 	}
-	pthread_t tid[64];
 	struct insert_job jobs[64];
 	for (int b = 0; b < num_blks; b++) {
 		jobs[b].g = g;
 		jobs[b].table = table;
 		jobs[b].in = blk_input[b];
 		jobs[b].n = blk_elem_num[b];
-		pthread_create(&tid[b], NULL, insert_worker, &jobs[b]);
 	}
-	for (int b = 0; b < num_blks; b++)
-		pthread_join(tid[b], NULL);
+	pool_run(num_blks, insert_part, jobs, num_blks);
 	return 1;
 }
 
