@@ -29,21 +29,26 @@ import os
 import sys
 import time
 
+import subprocess
+
 import numpy as np
-import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
-import megakv_amd as M  # noqa: E402
-from megakv_amd import workload as W  # noqa: E402
+# torch and the HIP library are imported in main(), AFTER the decision whether this process is
+# a launcher (--gpus N > 1 without a torch.distributed environment): a launcher never loads
+# anything that could initialise the GPU.
+torch = None
+M = None
+W = None
 
 HBM_PEAK_GBPS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
 GET_BYTES = 144                 # 8 (request) + 2 x 64 (buckets) + 8 (result)
 
 
-def parse():
+def parse(argv=None):
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=100)
@@ -71,7 +76,15 @@ def parse():
                     help="sharded path: drive the step from Python/torch.distributed instead of the C engine")
     ap.add_argument("--no-pipeline", action="store_true",
                     help="N > 1: run the steps strictly one after the other (no exchange/compute overlap)")
-    ap.add_argument("--events-every", type=int, default=4, help="time the search launch of every n-th step")
+    ap.add_argument("--events-every", type=int, default=0,
+                    help="also time the search launch of every n-th step INSIDE the timed region (0 = never: events "
+                         "cost a few microseconds of gaps per step; the roofline comes from the pass after it)")
+    ap.add_argument("--kernel-launches", type=int, default=96,
+                    help="launches of the dominant kernel timed by HIP events, one per step, in a separate pass "
+                         "AFTER the timed region over the same batches (`value` stays unperturbed)")
+    ap.add_argument("--prewarm-ms", type=float, default=250.0,
+                    help="untimed read-only searches before the warm-up steps, so that a short run (the driver's "
+                         "--steps 20 --warmup 5 is 1.5 ms of GPU work) does not measure the clocks ramping up")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
@@ -79,7 +92,7 @@ def parse():
                     help="batches of the same workload replayed on the CPU oracle (~10 s single-threaded)")
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
     ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: mkv_set_tuning('debug_skip')")
-    return ap.parse_args()
+    return ap.parse_args(argv)
 
 
 def dev(a, device):
@@ -119,20 +132,49 @@ class Stream:
         return gets, W.make_ielem(k, None, self.keying)
 
 
+def late_imports():
+    """torch, the HIP library's host mirror and the workload generator (tests that drive
+    Stream / SingleGpu directly call this first)."""
+    global torch, M, W
+    import torch as _torch
+    import megakv_amd as _M
+    import workload as _W
+    torch, M, W = _torch, _M, _W
+
+
+def launch_ranks(n):
+    """`python bench.py --gpus N` (N > 1) outside torch.distributed.run: start the N ranks as a
+    CHILD process (one rank per GPU, rendezvous on 127.0.0.1), relay its output -- rank 0's one
+    JSON line on stdout -- and return its exit code.  This process has not touched the GPU and
+    never does; nothing is exec'ed."""
+    import socket
+    port = os.environ.get("MASTER_PORT")
+    if not port:
+        with socket.socket() as s:
+            s.bind(("127.0.0.1", 0))
+            port = str(s.getsockname()[1])
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}",
+           "--master-addr", "127.0.0.1", "--master-port", port, os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     # Libraries (RCCL prints a version banner) must not share the channel of the one JSON
     # line: everything written to fd 1 from here on goes to stderr, the line is written
     # to the saved descriptor at the end.
+    args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(launch_ranks(args.gpus))
+    late_imports()
     sys.stdout.flush()
     json_fd = os.dup(1)
     os.dup2(2, 1)
-    args = parse()
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run (one rank per GPU)")
         args.gpus = world
     if args.comm == "staged":
         local_rank = 0
@@ -172,7 +214,7 @@ def main():
         geom = M.Geometry(mem_p=args.mem_p, scheme=scheme)
         engine = SingleGpu(HashIndex(geom, device=device), args)
     else:
-        from megakv_amd.sharded import ShardedIndex, NcclComm, StagedComm
+        from megakv_amd.sharded import NcclComm, StagedComm
         # Slot capacity: the largest share one shard gets of any batch of any rank (a hot key sends
         # all its GETs to one shard), plus 3 %.  Padding is exchanged like payload, so no more than
         # needed; and a slot can then not overflow in this run.
@@ -185,7 +227,7 @@ def main():
         t = torch.tensor([share], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         slot_factor = round(float(t.item()) * 1.03, 4)
-        engine = ShardedIndex(args.mem_p, world, rank, scheme, device, stream_gen.n_get, stream_gen.n_set,
+        engine = sharded_engine(args.mem_p, world, rank, scheme, device, stream_gen.n_get, stream_gen.n_set,
                               StagedComm(dist) if args.comm == "staged" else NcclComm(dist),
                               cap_factor=slot_factor)
     native = False
@@ -222,6 +264,7 @@ def main():
     # ---- the batches, resident in HBM --------------------------------------------------
     t0 = time.time()
     batches = [engine.stage(g, s) for g, s in host_batches]
+    last_sets = [s_ for _, s_ in host_batches[-4:]] if args.steps >= 1 else []
     del host_batches
     torch.cuda.synchronize()
     t_gen += time.time() - t0
@@ -246,6 +289,7 @@ def main():
                                                          file=sys.stderr, flush=True), os._exit(19)))
         watchdog.daemon = True
         watchdog.start()
+        t_prewarm = engine.prewarm(batches, args.prewarm_ms, run_stream) if args.prewarm_ms > 0 else 0.0
         if sharded and not args.no_pipeline:
             engine.run_pipelined(batches[:args.warmup])       # warms both lanes and their workspaces
         else:
@@ -278,8 +322,12 @@ def main():
             res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
             loc_ok = round(float((res == check_keys).mean()), 6)
         every = max(1, args.events_every)
-        timer = engine.make_timer((args.steps + every - 1) // every) if (use_events and not args.graph) else None
+        timer = engine.make_timer((args.steps + every - 1) // every) \
+            if (use_events and not args.graph and args.events_every > 0) else None
         timed = batches[args.warmup:]
+        if args.prewarm_ms > 0:
+            # (the result checks above left the GPU idle for some milliseconds)
+            t_prewarm += engine.prewarm(batches, min(args.prewarm_ms, 40.0), run_stream)
         barrier()
         t_start = time.perf_counter()
         if sharded and not args.no_pipeline:
@@ -313,20 +361,62 @@ def main():
             loc_ok_last = float(t.item())
         loc_ok_last = round(loc_ok_last, 6)
 
+    # ---- what the timed region did, proven after it ---------------------------------------
+    # (a) every SET key of the last timed batches is searched: the inserts of the timed region
+    #     are in the table, under their own key id (loc = key id);
+    # (b) the occupied slots of the table are counted: pre-loaded + inserted keys.
+    set_ok, entries = None, None
+    try:
+        if last_sets and stream_gen.n_set:
+            set_ok = engine.verify_sets(last_sets, run_stream)
+        n_ins = stream_gen.n_set * (args.steps + args.warmup) * world if args.sets == "new" else 0
+        entries = {"counted": engine.count_entries(dist), "expected": (stream_gen.P - 1) + n_ins}
+        entries["ok"] = entries["counted"] == entries["expected"] if args.lf <= 0.5 else None
+    except Exception as ex:                                       # noqa: BLE001
+        entries = {"error": f"{type(ex).__name__}: {ex}"}
+    if dist is not None and set_ok is not None:
+        t = torch.tensor([set_ok], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN)
+        set_ok = float(t.item())
+
+    # ---- the dominant kernel, timed launch by launch in a pass of its own -------------------
+    # The same cycles over the timed region's batches once more (their SETs are then updates
+    # with the same value: the table does not change), HIP events on the run stream around the
+    # search launch of EVERY step.  Not part of `value`.
     roofline = None
-    if use_events and timer:
-        ms = np.array(timer.elapsed_ms())
-        avg_s = float(ms.mean()) * 1e-3
+    inside = np.array(timer.elapsed_ms()) if timer else None
+    if use_events and not args.graph and args.steps:
+        L = max(8, args.kernel_launches)
+        post = [batches[args.warmup + (i % args.steps)] for i in range(L)]
+        ptimer = engine.make_timer(L)
+        with torch.cuda.stream(run_stream):
+            if sharded and not args.no_pipeline:
+                engine.run_pipelined(post, (lambda i: [ptimer.h, i]))
+            else:
+                for i, b in enumerate(post):
+                    engine.step(b, run_stream, [ptimer.h, i])
+            run_stream.synchronize()
+        barrier()
+        ms = np.array(ptimer.elapsed_ms())[4:]          # (the first launches after the checks above start cold)
+        med_s = float(np.median(ms)) * 1e-3
         algo_bytes = GET_BYTES * engine.search_requests_per_launch(stream_gen)
-        achieved = algo_bytes / avg_s / 1e9
+        achieved = algo_bytes / med_s / 1e9
         fused = not sharded and args.overlap == "fused" and not args.memset and stream_gen.n_set > 0
+        traffic, traffic_src = load_traffic(args, fused, sharded)
         roofline = {"bound": "hbm",
                     "kernel": "mkv::k_search_mark (search work-groups + the insert's mark work-groups)" if fused
-                    else ("mkv::k_search_slots" if sharded else "mkv::k_search"), "achieved": round(achieved, 1),
-                    "peak": HBM_PEAK_GBPS, "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4),
-                    "traffic": load_traffic(args), "algorithmic_bytes_per_launch": algo_bytes,
-                    "avg_launch_us": round(avg_s * 1e6, 2), "launches_timed": int(len(ms)), "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
-                    "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2)}
+                    else ("mkv::k_search_slots_mark" if sharded else "mkv::k_search"),
+                    "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    "algorithmic_bytes_per_launch": algo_bytes,
+                    "launch_us": round(med_s * 1e6, 2), "launch_us_is": "median of launches_timed HIP-event pairs",
+                    "launches_timed": int(len(ms)), "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
+                    "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
+                    "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2),
+                    "timed_in": "a pass after the timed region, same batches, every step"}
+        if inside is not None and len(inside):
+            roofline["inside_timed_region"] = {"launches_timed": int(len(inside)),
+                                               "median_us": round(float(np.median(inside)) * 1e3, 2)}
 
     # side measurements: whatever happens in them, the line with `value` is still printed
     pcie = None
@@ -367,13 +457,100 @@ def main():
                        "launch": "hipGraph" if args.graph else
                        ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
             "get_hit_rate": hit_rate, "get_loc_correct": loc_ok, "get_loc_correct_last_timed": loc_ok_last,
-            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie,
+            "set_loc_correct_last_timed": set_ok, "table_entries": entries,
+            "table_entries_ok": entries.get("ok") if isinstance(entries, dict) else None,
+            "step_algorithmic": step_algorithmic(stream_gen, cpu, elapsed / args.steps),
+            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "prewarm_s": round(t_prewarm, 3),
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if dist is not None:
         dist.destroy_process_group()
+
+
+def sharded_engine(*a, **kw):
+    """ShardedIndex (megakv_amd/sharded.py) plus what this benchmark drives around it: pre-load,
+    staging of a batch, clock pre-warm and the checks of the timed region's work."""
+    from megakv_amd.sharded import ShardedIndex
+
+    class ShardedBench(ShardedIndex):
+        def preload(self, P, keying):
+            g = self.geom
+            step = 1 << 22
+            self.idx.reserve(2 * step // self.world + 4096)
+            for lo in range(1, P, step):
+                k = np.arange(lo, min(lo + step, P), dtype=np.uint64).astype(np.uint32)
+                e = W.make_ielem(k, None, keying)
+                mine = np.take(e, np.flatnonzero(self.shard_of(e[:, 1]) == self.rank), axis=0)
+                blocks = W.bin_inserts(mine, g.mem_p, g.iblock_p, W.BIN_REGION)
+                self.idx.insert([torch.from_numpy(np.ascontiguousarray(b).view(np.int32)).to(self.device)
+                                 for b in blocks])
+            torch.cuda.synchronize()
+
+        def stage(self, gets, sets):
+            dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(self.device)
+            return {"q": dev(gets), "s": dev(sets.reshape(-1, 3)),
+                    "out": torch.zeros((gets.shape[0], 2), dtype=torch.int32, device=self.device)}
+
+        def reserve(self, stream):
+            self.idx.reserve(self.world * self.cap_set + 1024, stream)
+            for ln in self.lanes:
+                if ln.stream is not None:
+                    self.idx.reserve(self.world * self.cap_set + 1024, ln.stream)
+
+        def make_timer(self, slots):
+            from megakv_amd.index import SearchTimer
+            return SearchTimer(slots)
+
+        def step(self, b, stream, pair):
+            self._timing = pair            # [timer, slot] or None
+            self.step_tensors(b["q"], b["s"], b["out"])
+            self._timing = None
+
+        def hit_rate(self, b):
+            o = b["out"]
+            return round(float(((o[:, 0] != 0) | (o[:, 1] != 0)).float().mean().item()), 6)
+
+        def search_requests_per_launch(self, sg):
+            return sg.n_get
+
+        def prewarm(self, batches, ms, stream):
+            """untimed read-only searches of the local table (clocks up before a short run)"""
+            scratch = torch.empty_like(batches[0]["out"])
+            t0 = time.perf_counter()
+            while (time.perf_counter() - t0) * 1e3 < ms:
+                for b in batches[:16]:
+                    if b["q"].shape[0] == scratch.shape[0]:
+                        self.idx.search(b["q"], out=scratch, stream=stream)
+                stream.synchronize()
+            return time.perf_counter() - t0
+
+        def verify_sets(self, sets_list, stream):
+            """fraction of this rank's SET requests (host arrays [n,3]) found under their own
+            location through the sharded path -- minimum over the batches.  Collective."""
+            staged = [self.stage(np.ascontiguousarray(s[:, :2]), np.zeros((0, 3), np.uint32)) for s in sets_list]
+            self.run_pipelined(staged)
+            torch.cuda.synchronize()
+            worst = 1.0
+            for s, b in zip(sets_list, staged):
+                if not s.shape[0]:
+                    continue
+                o = b["out"]
+                res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
+                worst = min(worst, float((res == s[:, 2]).mean()))
+            return round(worst, 6)
+
+        def count_entries(self, dist=None):
+            """occupied slots of all shards (sum over the ranks)"""
+            n = (self.idx.table.view(-1, 16)[:, :8] != 0).sum().to(torch.int64)
+            if dist is not None and self.world > 1:
+                t = n.reshape(1).cpu() if dist.get_backend() == "gloo" else n.reshape(1)
+                dist.all_reduce(t)
+                return int(t.item())
+            return int(n.item())
+
+    return ShardedBench(*a, **kw)
 
 
 class SingleGpu:
@@ -445,6 +622,34 @@ class SingleGpu:
 
     def table_host(self):
         return self.idx.table_numpy()
+
+    def prewarm(self, batches, ms, stream):
+        """untimed read-only searches of the staged batches into a scratch buffer"""
+        scratch = torch.empty_like(batches[0]["out"])
+        t0 = time.perf_counter()
+        while (time.perf_counter() - t0) * 1e3 < ms:
+            for b in batches[:16]:
+                if b["q"].shape[0] == scratch.shape[0]:
+                    self.idx.search(b["q"], out=scratch, stream=stream)
+            stream.synchronize()
+        return time.perf_counter() - t0
+
+    def verify_sets(self, sets_list, stream):
+        """fraction of the given SET requests (host arrays [n,3]) now found under their own
+        location -- minimum over the batches"""
+        worst = 1.0
+        for sets in sets_list:
+            if not sets.shape[0]:
+                continue
+            o = self.idx.search(dev(np.ascontiguousarray(sets[:, :2]), self.device), stream=stream)
+            stream.synchronize()
+            res = torch.where(o[:, 0] != 0, o[:, 0], o[:, 1]).cpu().numpy().view(np.uint32)
+            worst = min(worst, float((res == sets[:, 2]).mean()))
+        return round(worst, 6)
+
+    def count_entries(self, dist=None):
+        """occupied slots (signature != 0) of the table"""
+        return int((self.idx.table.view(-1, 16)[:, :8] != 0).sum().item())
 
 
 def pcie_inclusive(engine, batches, stream, args):
@@ -526,22 +731,41 @@ def pcie_inclusive(engine, batches, stream, args):
             "note": "pinned host buffers, H2D requests + D2H results per step on one stream, no copy/compute overlap; best of three passes"}
 
 
-def load_traffic(args):
-    """HBM bytes per search launch from the rocprofv3 PMC passes of this same
-    command (profiles/make_traffic.py writes the file); null when absent."""
+def load_traffic(args, fused, sharded):
+    """HBM bytes per launch of the dominant kernel: NOT measured by this run -- read from the
+    committed rocprofv3 PMC passes of this command (tools/make_profiles.py writes the file,
+    separate --pmc passes, FETCH_SIZE + WRITE_SIZE as MI355X_MICROARCH.md prescribes) and
+    labelled with where it came from; null when there is no entry for this kernel/workload."""
     p = os.path.join(ROOT, "profiles", "search_traffic.json")
     try:
         d = json.load(open(p))
-        key = f"{args.workload}-{args.keying}"
-        return d.get(key, {}).get("hbm_bytes_per_launch")
+        kern = "k_search_slots_mark" if sharded else ("k_search_mark" if fused else "k_search")
+        e = d.get(f"{args.workload}-{args.keying}-{kern}")
+        if not e:
+            return None, None
+        return e.get("hbm_bytes_per_launch"), f"profiles/{e.get('source', 'search_traffic.json')}@{e.get('head', '?')}"
     except Exception:
-        return None
+        return None, None
+
+
+def step_algorithmic(sg, cpu, s_per_step):
+    """Whole-step figure: (GETs x 144 B + SETs x oracle-counted bytes) / step time.  SET bytes =
+    12 + 64 V + 4 W, V buckets visited and W dword stores counted by the CPU
+    oracle on the cpu_baseline sample of the same workload; 84 B (V=1, W=2) without it."""
+    set_b, src = 84.0, "assumed 84 B per SET (no oracle sample in this run)"
+    if isinstance(cpu, dict) and cpu.get("set_bytes_per_request"):
+        set_b, src = float(cpu["set_bytes_per_request"]), "oracle-counted on the cpu_baseline sample"
+    total = GET_BYTES * sg.n_get + set_b * sg.n_set
+    gbps = total / s_per_step / 1e9
+    return {"bytes_per_step": int(total), "GBps": round(gbps, 1), "frac_of_peak": round(gbps / HBM_PEAK_GBPS, 4),
+            "set_bytes_per_request": round(set_b, 2), "set_bytes_source": src, "per_rank": True}
 
 
 def cpu_baseline(engine, sg, args):
     """The CPU oracle (a port: the reference has no CPU index path) on the
     host's cores, same table image, a bounded sample of the same workload."""
     from oracle import oracle as O
+    native = O.use_native()           # -O3 -march=native, built on this box (SURVEY 8(d))
     scheme = O.SCHEME_CUCKOO if args.scheme == "cuckoo" else O.SCHEME_2CHOICE
     og = O.geom(mem_p=args.mem_p, scheme=scheme)
     # the table image in transparent huge pages where the host allows it (madvise): with 4 KiB
@@ -565,11 +789,15 @@ def cpu_baseline(engine, sg, args):
     g = engine.idx.geom
     t0 = time.perf_counter()
     ops = 0
+    nset = vis = stores = 0
     for gets, sets in work:
         out = np.zeros((gets.shape[0], 2), np.uint32)           # the memset
         O.search(og, table, gets, out=out)
         if sets.shape[0]:
-            O.insert(og, table, W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION))
+            st = O.insert(og, table, W.bin_inserts(sets, g.mem_p, g.iblock_p, W.BIN_REGION))
+            nset += st["elems"]
+            vis += st["buckets_visited"]
+            stores += st["dword_stores"]
         ops += gets.shape[0] + sets.shape[0]
     dt = time.perf_counter() - t0
     one = ops / dt / 1e6
@@ -587,9 +815,11 @@ def cpu_baseline(engine, sg, args):
     dt_mt = time.perf_counter() - t0
     mt_search = sum(w[0].shape[0] for w in work) / max(t_search, 1e-9) / 1e6
     return {"value": round(one, 2), "unit": "Mops", "cores": 1, "kind": "port",
+            "set_bytes_per_request": round(12 + (64 * vis + 4 * stores) / nset, 2) if nset else None,
             "sample": f"{nb} batches of 2^{args.batch_log2} requests of the same workload, same table image, "
                       f"single thread in canonical order ({dt:.1f} s); software prefetch 12 requests ahead, "
-                      f"table in {'transparent huge pages (madvise)' if huge else '4 KiB pages'}",
+                      f"table in {'transparent huge pages (madvise)' if huge else '4 KiB pages'}; "
+                      f"built {'-O3 -march=native on this box' if native else '-O3 (portable)'}",
             "all_threads": {"value": round(ops / dt_mt / 1e6, 1), "threads": ncpu,
                             "insert_threads": 1 << g.iblock_p,
                             "note": "searches over a persistent pool of host threads, inserts one thread per closed "

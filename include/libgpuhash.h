@@ -23,6 +23,17 @@
  *     (ref :492-493), delete unless num_thread >= threads_per_blk (ref :567-568);
  *   - MEM_P and HASH_CUCKOO / HASH_2CHOICE are baked in at library build time.
  *
+ * Where this build differs from "the library is stateless and allocates nothing":
+ *   - gpu_hash_insert / gpu_hash_delete keep a device workspace (reservation tables, request
+ *     state), created on the first call that needs it -- call mkv_reserve() (megakv_hip.h) at
+ *     start-up to keep the allocation out of the request path;
+ *   - one insert/delete call may carry at most MKV_REQ_CAP requests (environment variable,
+ *     default 4 194 304; the reference's hosts stay below 32 768 per call,
+ *     src/mega.c:143-144,163-165).  The counts are device memory, so an oversize batch is only
+ *     detected on the device: it is NOT applied, and the next insert/delete call on that
+ *     workspace prints what happened and abort()s -- loud, never silent.
+ *     mkv_insert_hinted (megakv_hip.h) takes the batch size and grows the workspace instead.
+ *
  * Result definition: search output and final table state are bit-identical to
  * the reference kernels executed one request at a time in (block, index) order
  * -- the only order for which the reference itself is deterministic.

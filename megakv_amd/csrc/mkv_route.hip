@@ -601,7 +601,23 @@ extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem
 	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sets);
 	const int64_t set_tiles = (n_set + mkv::kPackTile - 1) / mkv::kPackTile;
 	const int64_t get_tiles = (n_get + mkv::kPackTile - 1) / mkv::kPackTile;
-	if (nshards <= mkv::kPackBins && set_tiles <= 1024 && !mkv::tuning().pack_three_pass &&
+	// The SET tiles of the one-launch pack meet once (they spin on an arrival counter): every one
+	// of them must be resident at the same time.  They are the first work-groups of the grid, so
+	// it is enough that the device can hold that many -- asked once per device (a CU-masked or
+	// partitioned device holds fewer); beyond that the three-pass pack is used.
+	static int resident_cap[64] = {0};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev >= 0 && dev < 64 && resident_cap[dev] == 0) {
+		int per_cu = 0, cus = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_fused, 256, 0) != hipSuccess ||
+				hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+			per_cu = cus = 0;
+		resident_cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+	}
+	const int64_t set_tiles_max = (dev >= 0 && dev < 64 && resident_cap[dev] > 0) ?
+			(resident_cap[dev] < 1024 ? resident_cap[dev] : 1024) : 128;
+	if (nshards <= mkv::kPackBins && set_tiles <= set_tiles_max && !mkv::tuning().pack_three_pass &&
 			scratch_bytes >= (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4) {
 		// one launch; its control words (the head of `scratch`) are zero between calls: zeroed
 		// by the caller once, cleared again by the kernel's last work-group

@@ -60,7 +60,7 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 			hipLaunchKernelGGL((k_search_wide<U, true, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
 		else
 			hipLaunchKernelGGL((k_search_wide<U, false, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
-		return MKV_OK;
+		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
 	if (zero) {
 		if (nt)
@@ -73,7 +73,7 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 		else
 			hipLaunchKernelGGL((k_search<U, false, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
 	}
-	return MKV_OK;
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
 Tuning &tuning()

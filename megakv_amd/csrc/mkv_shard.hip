@@ -62,6 +62,7 @@ struct mkv_shard {
 	int64_t n_get = 0, n_set = 0, cap_get = 0, cap_set = 0, slot_words = 0, scratch_bytes = 0;
 	uint32_t agg_mask = 0, shift = 0;
 	int *overflow = nullptr;
+	int loopback = 0;               // rccl_path "loopback": the exchanges are local copies (tests)
 	int fused = 0;                  // one grouped collective per batch (run_fused): default with several ranks,
 	                                // MKV_SHARD_FUSED=0/1 overrides
 	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
@@ -125,6 +126,39 @@ static void fake_xfer(hipStream_t s)
 	if (g_fake_xfer_us > 0)
 		hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, s, (unsigned)g_fake_xfer_us);
 }
+
+// rccl_path "loopback": the schedule of a W-rank run on ONE process and one GPU, for tests
+// (RCCL wants a GPU per rank, so a one-GPU box can only form a one-rank communicator, where
+// every request goes to slot 0 and the same place every time).  Every peer is this process: the
+// slot packed for shard s comes back as the slot received from source rank s, so the local
+// table is served W slots with W different `where` arrays per batch -- pack, slot search,
+// one insert block per source rank, result exchange and unpack run exactly as with W ranks,
+// only the wire is a device copy.  Canonical order of the local table = (slot, batch index).
+namespace {
+int g_loop_world = 1;
+ncclResult_t loop_id(ncclUniqueId *id) { memset(id, 0, sizeof(*id)); return ncclSuccess; }
+ncclResult_t loop_init(ncclComm_t *c, int, ncclUniqueId, int) { *c = reinterpret_cast<ncclComm_t>(&g_loop_world); return ncclSuccess; }
+ncclResult_t loop_destroy(ncclComm_t) { return ncclSuccess; }
+ncclResult_t loop_a2a(const void *send, void *recv, size_t count, ncclDataType_t, ncclComm_t, hipStream_t s)
+{
+	return hipMemcpyAsync(recv, send, (size_t)g_loop_world * count * 4u, hipMemcpyDeviceToDevice, s) == hipSuccess
+			? ncclSuccess : ncclUnhandledCudaError;
+}
+const char *loop_err(ncclResult_t) { return "loopback exchange failed"; }
+ncclResult_t loop_group() { return ncclSuccess; }
+Rccl loopback_api()
+{
+	Rccl a;
+	a.GetUniqueId = loop_id;
+	a.CommInitRank = loop_init;
+	a.CommDestroy = loop_destroy;
+	a.AllToAll = loop_a2a;
+	a.GetErrorString = loop_err;
+	a.GroupStart = loop_group;
+	a.GroupEnd = loop_group;
+	return a;
+}
+}  // namespace
 
 static int fail(mkv_shard *e, int code, const char *what, const char *detail)
 {
@@ -225,6 +259,12 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
 	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
 
+	if (rccl_path && !strcmp(rccl_path, "loopback")) {
+		// test shape (tests/test_gpu_sharded.py): every peer is this process -- see loopback_api()
+		e->api = loopback_api();
+		g_loop_world = world;
+		e->loopback = 1;
+	} else {
 	e->api.lib = dlopen(rccl_path && *rccl_path ? rccl_path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
 	if (!e->api.lib)
 		return fail(e, MKV_EHIP, "dlopen(rccl)", dlerror());
@@ -242,6 +282,7 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	SH_SYM(GroupStart, "ncclGroupStart");
 	SH_SYM(GroupEnd, "ncclGroupEnd");
 #undef SH_SYM
+	}
 
 	SH_HIP(e, hipMalloc(&e->overflow, sizeof(int)));
 	SH_HIP(e, hipMemset(e->overflow, 0, sizeof(int)));
@@ -307,6 +348,8 @@ extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
 	ncclUniqueId id;
 	memcpy(&id, id128, sizeof(id));
 	SH_NCCL(e, e->api.CommInitRank(&e->comm, e->world, id, e->rank));
+	if (e->loopback)
+		return MKV_OK;                 // (block j comes back as block j: nothing to check)
 	// Self-check of the exchange before anything relies on it: block j of rank i must arrive
 	// as block i of rank j.  (With one rank every layout looks right, so this is the only
 	// place a wrong assumption about the collective would show before the results do.)
@@ -455,13 +498,16 @@ static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 			SH_NCCL(e, r2);
 			fake_xfer(l.stream);
 		}
-		SH_HIP(e, hipEventRecord(l.ev_xchg[k2], l.stream));
 		{
 			Span sp("unpack", lane, i, l.stream, tr);
 			rc = mkv_unpack_results(l.back_slots, l.perm2[k], n_get[i], outs[i], l.stream);
 		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_unpack_results", nullptr);
+		// Recorded AFTER the un-pack: the pack of batch i+4 (two iterations on, on the aux stream)
+		// waits for this event and then writes perm2[k], which the un-pack above is reading --
+		// and the send buffer, which the exchange above has read.
+		SH_HIP(e, hipEventRecord(l.ev_xchg[k2], l.stream));
 	}
 	for (int li = 0; li < 2; li++) {
 		Lane &l = e->lane[li];

@@ -60,6 +60,9 @@
 //
 // The per-lane atomicCAS the north star suggests for slot claims is not needed:
 // exclusivity comes from the reservation, so a commit is two plain stores.
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <mutex>
 #include <unordered_map>
 
@@ -2064,7 +2067,8 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		// up -- the host clears the reservation tables before a later call (ensure_ws)
 		if (last_chunk && host_flag)
 			*host_flag = ((ctl->last.bar_chain + ctl->bar_chain + ctl->last.bar_class + ctl->bar_class) != 0u ? 1u : 0u) |
-					(ctl->stamp_base > kStampMax - kStampReserve ? 2u : 0u);
+					(ctl->stamp_base > kStampMax - kStampReserve ? 2u : 0u) |
+					(ctl->overflow ? 4u : (*host_flag & 4u));     // bit 2 is sticky: the host reports it
 		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->bar_class;
 		ctl->bar_chain = 0;
 		ctl->bar_class = 0;
@@ -2181,6 +2185,17 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	Workspace *&w = g_ws[key];
 	if (!w)
 		w = new Workspace();
+	if (w->host_flag && (*w->host_flag & 4u)) {
+		// An earlier insert/delete on this workspace carried more requests than it holds: the counts
+		// are device memory, so the library only learns this after the fact, and that batch was NOT
+		// applied.  Nothing can be returned through the void ABI (and the call has long returned):
+		// stop loudly rather than go on with a table that silently misses a batch.
+		fprintf(stderr, "libgpuhash (MI355X): an insert/delete call carried more requests than the update "
+				"workspace holds (%lld); that batch was dropped.  Size the workspace with "
+				"mkv_reserve(geom, max_requests, stream), pass the batch size to mkv_insert_hinted, or set "
+				"MKV_REQ_CAP (limit %lld requests per call).\n", (long long)w->req_cap, (long long)kMaxReqCap);
+		abort();
+	}
 	if (w->device == dev && w->nbuckets >= nbuckets && w->req_cap >= req_cap) {
 		if (w->host_flag && (*w->host_flag & 2u)) {
 			// round stamps nearly used up (tail kernel's flag, read a call or two late: the
@@ -2249,11 +2264,13 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	return MKV_OK;
 }
 
-static int64_t ws_need(const ReqSrc &src)
+static int64_t ws_need(const ReqSrc &src, long long hint = 0)
 {
 	int64_t need = (int64_t)tuning().req_cap;
 	if (src.single_n > need)
 		need = src.single_n;
+	if (hint > need)
+		need = hint;                   // the caller's upper bound on the batch
 	if (need > kMaxReqCap)
 		need = kMaxReqCap;
 	return need;
@@ -2347,7 +2364,9 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 	Workspace *w = nullptr;
 	if (src.single_n > kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src), stream);
+	if (hint > kMaxReqCap)
+		return MKV_ETOOBIG;
+	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src, hint), stream);
 	if (rc != MKV_OK)
 		return rc;
 	if (src.single_n > 0 && hint <= 0)
@@ -2438,7 +2457,9 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_inpu
 	src.cnt_stride = 1;
 	mkv::Workspace *w = nullptr;
 	hipStream_t s = (hipStream_t)stream;
-	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
+	if (size_hint > mkv::kMaxReqCap)
+		return MKV_ETOOBIG;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	if (hipEventRecord(w->ev_fork, s) != hipSuccess || hipStreamWaitEvent(w->aux, w->ev_fork, 0) != hipSuccess)
@@ -2474,7 +2495,9 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	src.cnt_stride = 1;
 	mkv::Workspace *w = nullptr;
 	hipStream_t s = (hipStream_t)stream;
-	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
+	if (size_hint > mkv::kMaxReqCap)
+		return MKV_ETOOBIG;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	const int64_t search_blocks = (num_search + 255) / 256;      // U = 4: 256 requests per block
@@ -2581,7 +2604,9 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	src.nblk = (uint32_t)nslots;
 	src.cnt_stride = (uint32_t)slot_words;
 	mkv::Workspace *w = nullptr;
-	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src), s, mkv::kCycleSalt);
+	if (size_hint > mkv::kMaxReqCap)
+		return MKV_ETOOBIG;
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	const bool cuckoo = d.scheme == MKV_SCHEME_CUCKOO;

@@ -5,7 +5,6 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libmegakv_hip.so")
-WORKLOAD_PATH = os.path.join(_HERE, "_lib", "libmkv_workload.so")
 
 
 class LibraryMissing(RuntimeError):

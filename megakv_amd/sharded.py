@@ -30,7 +30,6 @@ import numpy as np
 import torch
 
 from .index import Geometry, HashIndex, _dev_ptr, _stream_ptr, _check
-from . import workload as W
 
 
 def shard_geometry(mem_p_local, world, scheme, iblock_p=3, max_cuckoo=5):
@@ -122,21 +121,24 @@ class NativeEngine:
     two in flight, enqueued by ONE library call.  The communicator is the library's own;
     `dist` (torch.distributed, any backend) only carries the 128-byte id to the ranks."""
 
-    def __init__(self, sh, dist):
+    def __init__(self, sh, dist, loopback=False):
+        """loopback: every peer is this process (the exchanges are device copies) -- the W-rank
+        schedule on one GPU, for tests (mkv_shard.hip, loopback_api)."""
         import os
         self.sh, self.lib = sh, sh.idx.lib
         self.h = ctypes.c_void_p(0)
         rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = b"loopback" if loopback else (rccl.encode() if os.path.exists(rccl) else None)
         rc = self.lib.mkv_shard_create(ctypes.byref(self.h), ctypes.byref(sh.idx._g), sh.world, sh.rank,
                                        _dev_ptr(sh.idx.table), sh.n_get, sh.n_set, sh.cap_get, sh.cap_set,
-                                       rccl.encode() if os.path.exists(rccl) else None)
+                                       path)
         self._check(rc, "mkv_shard_create")
         ident = [None]
         if sh.rank == 0:
             buf = ctypes.create_string_buffer(128)
             self._check(self.lib.mkv_shard_unique_id(self.h, buf), "mkv_shard_unique_id")
             ident = [buf.raw]
-        if sh.world > 1:
+        if sh.world > 1 and not loopback:
             dist.broadcast_object_list(ident, src=0)
         self._check(self.lib.mkv_shard_connect(self.h, ctypes.create_string_buffer(ident[0], 128)),
                     "mkv_shard_connect")
@@ -337,54 +339,13 @@ class ShardedIndex:
             ln.ev_done.record(ln.stream)
             main.wait_event(ln.ev_done)
 
-    # -- the engine interface bench.py drives --------------------------------------------------
-    def preload(self, P, keying):
-        g = self.geom
-        step = 1 << 22
-        self.idx.reserve(2 * step // self.world + 4096)
-        for lo in range(1, P, step):
-            k = np.arange(lo, min(lo + step, P), dtype=np.uint64).astype(np.uint32)
-            e = W.make_ielem(k, None, keying)
-            mine = np.take(e, np.flatnonzero(self.shard_of(e[:, 1]) == self.rank), axis=0)
-            blocks = W.bin_inserts(mine, g.mem_p, g.iblock_p, W.BIN_REGION)
-            self.idx.insert([torch.from_numpy(np.ascontiguousarray(b).view(np.int32)).to(self.device)
-                             for b in blocks])
-        torch.cuda.synchronize()
-
-    def stage(self, gets, sets):
-        dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(self.device)
-        return {"q": dev(gets), "s": dev(sets.reshape(-1, 3)),
-                "out": torch.zeros((gets.shape[0], 2), dtype=torch.int32, device=self.device)}
-
-    def reserve(self, stream):
-        self.idx.reserve(self.world * self.cap_set + 1024, stream)
-        for ln in self.lanes:
-            if ln.stream is not None:
-                self.idx.reserve(self.world * self.cap_set + 1024, ln.stream)
-
-    def make_timer(self, slots):
-        from .index import SearchTimer
-        return SearchTimer(slots)
-
-    def step(self, b, stream, pair):
-        self._timing = pair            # [timer, slot] or None
-        self.step_tensors(b["q"], b["s"], b["out"])
-        self._timing = None
-
-    def hit_rate(self, b):
-        o = b["out"]
-        return round(float(((o[:, 0] != 0) | (o[:, 1] != 0)).float().mean().item()), 6)
-
-    def search_requests_per_launch(self, sg):
-        return sg.n_get
-
     def overflowed(self):
         if self.native is not None and self.native.overflowed():
             return True
         return bool(self.overflow.item())
 
-    def enable_native(self, dist):
+    def enable_native(self, dist, loopback=False):
         """Switch run_pipelined to the C engine (its own RCCL communicator).  Collective:
         call on every rank.  Raises if the library cannot open RCCL or connect."""
-        self.native = NativeEngine(self, dist)
+        self.native = NativeEngine(self, dist, loopback)
         return self.native

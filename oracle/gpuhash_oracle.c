@@ -263,8 +263,7 @@ static void insert_cuckoo_one(const orc_geom_t *g, orc_bucket_t *table,
 		const orc_ielem_t *e, orc_stats_t *st)
 {
 	st->elems++;
-	if (e->sig == 0 && e->loc == 0) {	/* :259-262 */
-		printf("error, all is zero\n");
+	if (e->sig == 0 && e->loc == 0) {	/* :259-262: the kernel prints "error, all is zero"; counted here */
 		st->skipped_zero++;
 		return;
 	}
@@ -317,8 +316,7 @@ static void insert_2choice_one(const orc_geom_t *g, orc_bucket_t *table,
 		const orc_ielem_t *e, orc_stats_t *st)
 {
 	st->elems++;
-	if (e->sig == 0 && e->loc == 0) {	/* :101-104 */
-		printf("error, all is zero\n");
+	if (e->sig == 0 && e->loc == 0) {	/* :101-104: the kernel prints "error, all is zero"; counted here */
 		st->skipped_zero++;
 		return;
 	}

@@ -43,6 +43,26 @@ def build(force=False):
 
 
 _lib = None
+_native = False
+
+
+def use_native():
+    """cpu_baseline only: switch to the same source built -march=native ON THIS MACHINE (into
+    the temporary directory -- such an object must not travel with the tree).  Returns whether
+    the native flavour is in use; on any failure the portable build stays."""
+    global _lib, _SO, _native
+    if _native:
+        return True
+    import tempfile
+    out = os.path.join(tempfile.gettempdir(), f"mkv_oracle_native_{os.getuid()}")
+    try:
+        subprocess.check_call(["make", "-s", "-C", _HERE, "native", f"NATIVE_OUT={out}"])
+        so = os.path.join(out, "libgpuhash_oracle_native.so")
+        ctypes.CDLL(so)
+    except Exception:                                             # noqa: BLE001
+        return False
+    _SO, _lib, _native = so, None, True
+    return True
 
 
 def lib():

@@ -18,9 +18,6 @@ def _built():
     HIP library is built by __graft_entry__.build() and travels prebuilt."""
     from oracle import oracle as O
     O.build()
-    wl = os.path.join(ROOT, "megakv_amd", "_lib", "libmkv_workload.so")
-    if not os.path.exists(wl):
-        import subprocess
-        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "megakv_amd", "csrc"),
-                               "../_lib/libmkv_workload.so"])
+    import subprocess
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "workload")])
     yield

@@ -55,3 +55,57 @@ def run_and_check(world, mode, mem_p_local, scheme, seed, steps=4, timeout=600):
         nb_local = 1 << (mem_p_local - 6)
         for r in range(world):
             assert np.array_equal(data[r]["table"], agg[r * nb_local:(r + 1) * nb_local]), f"shard {r} differs"
+
+
+def run_and_check_zipf(world, mem_p_local, batch_log2, steps, timeout=900, scheme=0):
+    """BASELINE configs[4] shape: every rank feeds batches of bench.py's own Stream generator
+    (95/5 GET/SET, Zipf-0.99, K-mix keys, fresh SET ids per rank) into the sharded index after
+    bench.py's pre-load to load factor 0.2; all ranks share cuda:0, two batches in flight.
+    Checked against ONE aggregate oracle table of MEM_P = mem_p_local + log2(world)."""
+    import bench
+    import workload as W
+    port = free_port()
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MKV_ZIPF_BATCH_LOG2=str(batch_log2),
+                   MKV_ZIPF_STEPS=str(steps))
+        logs = [open(os.path.join(d, f"rank{r}.log"), "w") for r in range(world)]
+        procs = [subprocess.Popen([sys.executable, "-m", "tests.sharded_worker", str(r), str(world), str(port),
+                                   "gpu-zipf", d, str(mem_p_local), str(scheme), "0"], cwd=ROOT, env=env,
+                                  stdout=logs[r], stderr=subprocess.STDOUT)
+                 for r in range(world)]
+        try:
+            for p in procs:
+                p.wait(timeout=timeout)
+        finally:
+            for p in procs:
+                if p.poll() is None:
+                    p.kill()
+            for f in logs:
+                f.close()
+        for r, p in enumerate(procs):
+            tail = open(os.path.join(d, f"rank{r}.log")).read()[-3000:]
+            assert p.returncode == 0, f"rank {r} failed:\n{tail}"
+        data = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
+    k = world.bit_length() - 1
+    mem_p_agg = mem_p_local + k
+    og = O.geom(mem_p=mem_p_agg, scheme=scheme)
+    agg = O.new_table(og)
+    args = bench.parse(["--workload", "zipf95", "--mem-p", str(mem_p_local), "--batch-log2", str(batch_log2)])
+    bench.late_imports()
+    P = bench.Stream(args, 0, world, mem_p_agg).P
+    for lo in range(1, P, 1 << 22):
+        keys = np.arange(lo, min(lo + (1 << 22), P), dtype=np.uint32)
+        O.insert(og, agg, W.bin_inserts(W.make_ielem(keys, None, W.KEYING_MIX), mem_p_agg, 3, W.BIN_REGION))
+    hits = total = 0
+    for step in range(steps):
+        for r in range(world):
+            gets = np.ascontiguousarray(data[r][f"gets{step}"])
+            exp = O.search(og, agg, gets)
+            assert np.array_equal(data[r][f"out{step}"], exp), f"rank {r} step {step}: search results differ"
+            hits += int(((exp[:, 0] != 0) | (exp[:, 1] != 0)).sum())
+            total += gets.shape[0]
+        O.insert(og, agg, [np.ascontiguousarray(data[r][f"sets{step}"]) for r in range(world)])
+    assert hits == total, "every GET key of this workload was pre-loaded"
+    nb_local = 1 << (mem_p_local - 6)
+    for r in range(world):
+        assert np.array_equal(data[r]["table"], agg[r * nb_local:(r + 1) * nb_local]), f"shard {r} differs"

@@ -108,11 +108,46 @@ def make_requests(rng, n_get, n_set, sig_space, known):
     return gets, sets
 
 
+def zipf_main(rank, world, outdir, mem_p_local, scheme):
+    """BASELINE configs[4] shape on one GPU: bench.py's Stream of this rank (95/5 GET/SET,
+    Zipf-0.99, K-mix, fresh SET ids of this rank's range) through bench.py's pre-load and the
+    two-lane pipeline; exchange staged through host memory (all ranks share cuda:0)."""
+    import bench
+    bench.late_imports()
+    torch.cuda.set_device(0)
+    k = world.bit_length() - 1
+    batch_log2, steps = int(os.environ["MKV_ZIPF_BATCH_LOG2"]), int(os.environ["MKV_ZIPF_STEPS"])
+    args = bench.parse(["--workload", "zipf95", "--mem-p", str(mem_p_local), "--batch-log2", str(batch_log2),
+                        "--scheme", "cuckoo" if scheme == 0 else "2choice"])
+    sg = bench.Stream(args, rank, world, mem_p_local + k)
+    # a hot key sends all its GETs to one shard: slots twice the average share
+    sh = bench.sharded_engine(mem_p_local, world, rank, scheme, "cuda:0", sg.n_get, sg.n_set, StagedComm(dist),
+                              cap_factor=2.5)
+    sh.preload(sg.P, sg.keying)
+    rec, staged = {}, []
+    for step in range(steps):
+        gets, sets = sg.batch()
+        rec[f"gets{step}"], rec[f"sets{step}"] = gets, sets
+        staged.append(sh.stage(gets, sets))
+    sh.run_pipelined(staged)
+    torch.cuda.synchronize()
+    for step in range(steps):
+        rec[f"out{step}"] = staged[step]["out"].cpu().numpy().view(np.uint32)
+    dist.barrier()
+    assert int(sh.overflow[0]) == 0, "a slot overflowed"
+    rec["table"] = sh.idx.table_numpy()
+    np.savez(os.path.join(outdir, f"rank{rank}.npz"), **rec)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     mode, outdir = sys.argv[4], sys.argv[5]
     mem_p_local, scheme, seed = int(sys.argv[6]), int(sys.argv[7]), int(sys.argv[8])
     dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=world)
+    if mode == "gpu-zipf":
+        return zipf_main(rank, world, outdir, mem_p_local, scheme)
     n_get, n_set, steps = 3000, 1200, 4
     geom = shard_geometry(mem_p_local, world, scheme)
     if mode == "cpu":

@@ -6,7 +6,7 @@ import pytest
 import torch
 
 import megakv_amd as M
-from megakv_amd import workload as W
+import workload as W
 from oracle import oracle as O
 from tests.gpu_util import dev, host
 

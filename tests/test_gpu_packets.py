@@ -8,7 +8,7 @@ import pytest
 import torch
 
 from megakv_amd import Geometry, HashIndex
-from megakv_amd import workload as W
+import workload as W
 from megakv_amd.index import _dev_ptr, _stream_ptr
 from megakv_amd.lib import load_library
 from oracle import oracle as O

@@ -427,7 +427,7 @@ def test_baseline_config1_shape_through_the_library():
     GET batches of 32 767 = batch_max_search_job - 1) through the library: table image equal to the
     oracle's, every GET hits in its primary bucket with loc == key (tests/test_workload.py runs the
     same on the oracle alone)."""
-    from megakv_amd import workload as W
+    import workload as W
     mem_p = 25
     g = Geometry(mem_p=mem_p, scheme=1)
     og = ogeom(g)
@@ -482,7 +482,7 @@ def test_large_preload_with_chunks_and_carries_matches_oracle():
     call runs as 64 K chunks with a size hint, barriers appear as the table fills and
     their unresolved requests are carried from chunk to chunk.  Final table image and a
     search over all keys equal the oracle's."""
-    from megakv_amd import workload as W
+    import workload as W
     g = Geometry(mem_p=29)
     og = ogeom(g)
     idx = HashIndex(g)

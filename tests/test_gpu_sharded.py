@@ -88,8 +88,9 @@ def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
     one-GPU box can run -- against the oracle, results and final table."""
     import numpy as np
     import torch
-    from megakv_amd.sharded import ShardedIndex
+    from bench import late_imports, sharded_engine as ShardedIndex
     from oracle import oracle as O
+    late_imports()
     monkeypatch.setenv("MKV_SHARD_FUSED", str(fused))      # the engine reads it when it is created
     mem_p = 16
     rng = np.random.default_rng(77 + scheme)
@@ -122,5 +123,59 @@ def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
             assert np.array_equal(got, exp)
             O.insert(og, table, [np.ascontiguousarray(sets)])
         assert np.array_equal(sh.idx.table_numpy(), table)
+    finally:
+        sh.native.close()
+
+
+@pytest.mark.parametrize("world,fused,scheme", [(4, 1, 0), (4, 0, 0), (8, 1, 0), (2, 1, 1)])
+def test_native_engine_schedule_with_several_slots(world, fused, scheme, monkeypatch):
+    """The C engine's W-rank schedules (run_fused: one grouped exchange per batch, packs on
+    a stream of their own into alternating `where` arrays; and the plain two-lane one) with
+    every peer looped back to this process: W slots per batch, a different `where` array for
+    every batch, batches of different sizes, results of EVERY batch and the final table
+    against the oracle (canonical order of the local table = slot, then batch index).  Wrong
+    event placement between un-pack and the pack two batches on shows here."""
+    import numpy as np
+    import torch
+    from bench import late_imports, sharded_engine as ShardedIndex
+    from oracle import oracle as O
+    late_imports()
+    monkeypatch.setenv("MKV_SHARD_FUSED", str(fused))
+    mem_p = 18
+    k = world.bit_length() - 1
+    rng = np.random.default_rng(500 + world + fused)
+    n_get, n_set = 60000, 6000
+    sh = ShardedIndex(mem_p, world, 0, scheme, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6)
+    sh.enable_native(None, loopback=True)
+    try:
+        og = O.geom(mem_p=mem_p, scheme=scheme, iblock_p=3 - k)
+        table = O.new_table(og)
+        batches, host = [], []
+        for step in range(24):
+            ng = n_get if step % 5 != 3 else int(rng.integers(1, n_get))
+            ns = n_set if step % 7 != 4 else int(rng.integers(0, 50))
+            keys = rng.integers(1, 150000, size=ng + ns, dtype=np.uint64)
+            z = (keys * np.uint64(0x9E3779B97F4A7C15)) ^ (keys >> np.uint64(7))
+            sig = (z & np.uint64(0xffffffff)).astype(np.uint32)
+            sig[sig == 0] = 1
+            hsh = (z >> np.uint64(32)).astype(np.uint32)
+            gets = np.ascontiguousarray(np.stack([sig[:ng], hsh[:ng]], axis=1))
+            sets = np.stack([sig[ng:], hsh[ng:], rng.integers(1, 2**32, size=ns, dtype=np.uint64).astype(np.uint32)],
+                            axis=1).reshape(-1, 3)
+            host.append((gets, sets))
+            batches.append(sh.stage(gets, sets))
+        for rep in range(2):                        # the second run re-uses lanes, events and `where` arrays
+            for b in batches:
+                b["out"].fill_(-1)
+            sh.run_pipelined(batches)
+            torch.cuda.synchronize()
+            assert not sh.overflowed()
+            for i, ((gets, sets), b) in enumerate(zip(host, batches)):
+                exp = O.search(og, table, gets)
+                got = b["out"].cpu().numpy().view(np.uint32)
+                assert np.array_equal(got, exp), f"run {rep} batch {i}: results differ"
+                shard = sh.shard_of(sets[:, 1]).astype(np.int64)
+                O.insert(og, table, [np.ascontiguousarray(sets[shard == s]) for s in range(world)])
+            assert np.array_equal(sh.idx.table_numpy(), table)
     finally:
         sh.native.close()

@@ -274,7 +274,7 @@ def test_region_parallel_insert_equals_canonical_insert():
     table of the canonical single-thread insert; blocks that are not binned by region are
     refused (and run single-threaded)."""
     import numpy as np
-    from megakv_amd import workload as W
+    import workload as W
     g = O.geom(mem_p=18, scheme=O.SCHEME_CUCKOO)
     rng = np.random.default_rng(3)
     a, b = O.new_table(g), O.new_table(g)

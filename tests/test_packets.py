@@ -1,10 +1,10 @@
-"""SURVEY 8(f) row 3, CPU side: the LOCAL_TEST packet synthesis (megakv_amd/csrc/workload.c,
+"""SURVEY 8(f) row 3, CPU side: the LOCAL_TEST packet synthesis (workload/workload.c,
 after src/mega_recv.c:633-768) against the oracle's restatement of the receiver's parser
 (src/mega_recv.c:292-545) and against the workload definition (K-ref keying)."""
 import numpy as np
 import pytest
 
-from megakv_amd import workload as W
+import workload as W
 from oracle import oracle as O
 
 

@@ -1,4 +1,4 @@
-"""Workload generator (megakv_amd/csrc/workload.c) against the reference's own
+"""Workload generator (workload/workload.c) against the reference's own
 Zipf generator: committed known answers (tests/golden/zipf_kat.json, produced
 by tests/golden/make_golden.py from /root/reference/src/zipf.h) and, where the
 reference-built helper oracle/_ref/ref_zipf is present, a live cross-check.
@@ -11,7 +11,7 @@ import subprocess
 import numpy as np
 import pytest
 
-from megakv_amd import workload as W
+import workload as W
 from oracle import oracle as O
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -11,7 +11,7 @@ import torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import megakv_amd as M  # noqa: E402
-from megakv_amd import workload as W  # noqa: E402
+import workload as W  # noqa: E402
 
 
 def dev(a):

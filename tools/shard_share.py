@@ -2,7 +2,7 @@
 """Largest share of one shard (x the average) under the benchmark GET streams, per world size."""
 import numpy as np, sys
 sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
-from megakv_amd import workload as W
+import workload as W
 res={}
 for G in (8,4,2):
     k=G.bit_length()-1

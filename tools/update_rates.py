@@ -5,7 +5,7 @@ import os, sys
 import numpy as np, torch
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import megakv_amd as M
-from megakv_amd import workload as W
+import workload as W
 
 def dev(a): return torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).cuda()
 

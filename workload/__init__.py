@@ -1,4 +1,6 @@
-"""Synthetic request streams (numpy), binding megakv_amd/csrc/workload.c.
+"""Synthetic request streams (numpy), binding workload/workload.c.
+
+Benchmark and test input only: not part of the product package (megakv_amd).
 
 Restates the reference's LOCAL_TEST workload definition (src/mega_recv.c:633-768,
 src/zipf.h) -- see workload.c for the line-by-line citations and SURVEY 8(d):
@@ -12,7 +14,13 @@ import os
 
 import numpy as np
 
-from .lib import WORKLOAD_PATH, LibraryMissing
+_HERE = os.path.dirname(os.path.abspath(__file__))
+WORKLOAD_PATH = os.path.join(_HERE, "_lib", "libmkv_workload.so")
+
+
+class LibraryMissing(RuntimeError):
+    pass
+
 
 KEYING_REF = 0
 KEYING_MIX = 1
@@ -39,7 +47,8 @@ def _L():
     global _lib
     if _lib is None:
         if not os.path.exists(WORKLOAD_PATH):
-            raise LibraryMissing(f"{WORKLOAD_PATH} not found: run `make -C megakv_amd/csrc`")
+            import subprocess
+            subprocess.check_call(["make", "-s", "-C", _HERE])
         L = ctypes.CDLL(WORKLOAD_PATH)
         P = ctypes.c_void_p
         L.mkv_zipf_init.restype = ctypes.c_int
