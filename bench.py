@@ -386,7 +386,7 @@ def main():
     roofline = None
     inside = np.array(timer.elapsed_ms()) if timer else None
     if use_events and not args.graph and args.steps:
-        L = max(8, args.kernel_launches)
+        L = max(8, args.kernel_launches) + 4       # (4 more: the first ones are dropped below)
         post = [batches[args.warmup + (i % args.steps)] for i in range(L)]
         ptimer = engine.make_timer(L)
         with torch.cuda.stream(run_stream):
