@@ -114,8 +114,8 @@ extern "C" void mkv_timer_destroy(void *timer)
 }
 
 extern "C" int mkv_tuning_is_default_search(void);
-extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_input, int *blk_elem_num,
-		int num_blks, long long size_hint, void *stream);
+extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
 extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, long long size_hint, void *stream, int joined);
 extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
@@ -147,7 +147,7 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 			mkv_tuning_is_default_search();
 	const bool overlap = side;
 	if (side) {
-		rc = mkv_cycle_insert_begin(geom, blk_input, blk_elem_num, num_blks, insert_hint, stream);
+		rc = mkv_cycle_insert_begin(geom, table, blk_input, blk_elem_num, num_blks, insert_hint, stream);
 		if (rc != MKV_OK)
 			return rc;
 	}

@@ -37,6 +37,8 @@ inline bool make_dev_geom(const mkv_geom_t *g, DevGeom *d)
 		return false;
 	if (g->scheme != MKV_SCHEME_CUCKOO && g->scheme != MKV_SCHEME_2CHOICE)
 		return false;
+	if (g->max_cuckoo > 6)          // eviction-chain logs hold 7 evictions (reference MAX_CUCKOO_NUM = 5)
+		return false;
 	uint32_t bucket_bits = g->mem_p - 6;
 	if (bucket_bits > 31)
 		return false;

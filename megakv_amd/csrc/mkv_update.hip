@@ -82,6 +82,9 @@ constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished req
 constexpr int kTailAloneSpan = 131072; // ... or beyond this many request tags to scan
 constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
 constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
+constexpr int kViolCap = 128;       // order violations recorded per turn of the tail (more are met again later)
+constexpr int kDirtyCap = 1024;     // buckets whose later commits a violation drags along (beyond: the whole region suffix)
+constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
 constexpr uint32_t kGridAll = 1024;
 constexpr uint32_t kGridList = 256;
 
@@ -146,6 +149,15 @@ struct Ctl {
 	uint32_t g_rmin[2][kMaxRegions]; //   two sets used alternately (the idle one is reset meanwhile)
 	uint32_t g_progress[2], g_left[2];
 	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
+	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
+	uint32_t viol[kMaxRegions];      // tail: lowest index per region whose chain met a bucket a LATER request already used
+	uint32_t vlist_n;                // ... and the violations themselves: {index, bucket} (the first kViolCap of a turn)
+	uint2 vlist[kViolCap];
+	uint32_t tflags;                 // tail: bit 0 = a violation was recorded, bit 1 = the touched record is needed
+	uint32_t violations;             // order violations handled this call (each rolls back a region's later commits)
+	uint32_t hard_tail;              // hard requests the grid-wide rounds left to the tail this call
+	unsigned long long tstamp_next;  // next stamp of the touched record (persists across calls)
+	unsigned long long tstamp_cur;   // stamp a tail launch builds its touched record with (set by round 1)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
@@ -585,11 +597,43 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 		atomicAdd(&shards[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kShards - 1)], n);
 }
 
+// Mark pass, cuckoo: a request that LOOKS hard in the table as it stands (P and A full,
+// no duplicate) also registers on the buckets its eviction chain would go on to -- read-only
+// walk, same key, same owner table.  If it is still hard when its turn comes and the chain
+// still runs that way, the buckets are its own already (try_chain meets its own key), and the
+// requests of this batch that have one of them as their P or A line up behind or before it
+// through the ordinary reservation instead of being committed under the chain's feet.  Only
+// a hint: nothing depends on the walk being right (the table may change before the turn).
+__device__ __forceinline__ void prewalk_register(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P,
+		uint32_t A, unsigned long long *owner, unsigned long long key)
+{
+	uint4 lo, hi;
+	load_sig_row<false>(table, P, lo, hi);
+	if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
+		return;
+	if (A != P) {
+		load_sig_row<false>(table, A, lo, hi);
+		if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
+			return;
+	}
+	const uint32_t v = r.sig & 7u;              // victim slot: ORIGINAL signature (ref :360)
+	for (uint32_t k = 0; k < g.max_cuckoo; k++) {
+		const uint4 q = (v & 4u) ? hi : lo;
+		const uint32_t a = (v & 1u) ? q.y : q.x, c = (v & 1u) ? q.w : q.z;
+		const uint32_t vsig = (v & 2u) ? c : a;
+		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (ref :334)
+		atomicMin(&owner[nb], key);
+		load_sig_row<false>(table, nb, lo, hi);
+		if (eq_mask(lo, hi, vsig) | eq_mask(lo, hi, 0u))
+			return;
+	}
+}
+
 // ---- K1: mark -----------------------------------------------------------------
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap,
-		uint32_t lo_idx, uint32_t hi_idx)
+		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
@@ -645,6 +689,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		const uint32_t idx = base + t;
 		bool live = idx < end && idx >= start;
 		uint32_t P = 0, A = 0;
+		Req rq;
+		rq.sig = rq.hash = rq.loc = 0u;
 		if (live && idx < lo_idx) {
 			// carried range: unfinished tags ride along (reset to PENDING); commits of the
 			// earlier pass are closed here, so that a later roll-back never takes them for
@@ -655,6 +701,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 				state[idx] = live ? ST_PENDING : ST_DONE;
 			if (live) {
 				const uint4 rc = reqc[idx];
+				rq = req_of(rc);
 				P = rc.y & g.hash_mask;
 				A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			}
@@ -678,6 +725,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			r.hash = p[1];
 			r.loc = p[2];
 			reqc[idx] = make_uint4(r.sig, r.hash, r.loc, 0u);
+			rq = r;
 			if (OP != OP_DELETE && r.sig == 0u && r.loc == 0u) {
 				state[idx] = ST_DONE;               // skipped by the reference too (:259-262)
 				live = false;
@@ -688,6 +736,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			}
 		}
 		reserve_wave(owner, P, A, owner_key(stamp, idx), live);
+		if (OP == OP_CUCKOO && live && table)
+			prewalk_register(table, g, rq, P, A, owner, owner_key(stamp, idx));
 	}
 }
 
@@ -701,7 +751,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 // so its position in the order is immaterial.  Everything is logged for the
 // roll-back behind a barrier.  Follows ref gpu_hash.cu:357-423.
 __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint32_t A, uint32_t idx,
-		unsigned long long *owner1, unsigned long long stamp1, Ctl *ctl, ChainLog *logs, uint32_t *log_slot)
+		unsigned long long *owner1, unsigned long long stamp1, Ctl *ctl, ChainLog *logs, uint32_t *log_slot,
+		bool own_ok)
 {
 	if (g.max_cuckoo + 1u > (uint32_t)kChainLogWords / 2u)
 		return false;
@@ -729,9 +780,14 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 		sig = vsig;
 		loc = vloc;
 		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
+		// An entry of this pass that is not this request's own: someone of this batch may touch b.
+		// Its own (left by the mark pass's walk, prewalk_register) makes b this request's bucket
+		// in ROUND 1, where everybody's right to a bucket is read from this table; in round 2 the
+		// losers' rights are in the other table -- one of them may own b there -- so only a bucket
+		// nobody of the pass has entered will do.
 		const unsigned long long old = atomicMin(&owner1[b], mykey);
-		if ((old >> kIdxBits) == stamp_field && old != mykey) {
-			ok = false;                             // someone of this batch may touch b
+		if ((old >> kIdxBits) == stamp_field && (old != mykey || !own_ok)) {
+			ok = false;
 			break;
 		}
 		uint4 lo, hi;
@@ -771,9 +827,9 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 template <Op OP>
 __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
-		uint32_t hi_idx)
+		uint32_t hi_idx, const uint32_t *table)
 {
-	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx);
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx, table);
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -788,7 +844,8 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 	// mark blocks first: they are few and latency-bound, let them start early
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
-		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx);
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
+				reinterpret_cast<const uint32_t *>(table));
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
 }
@@ -803,20 +860,25 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 {
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
-		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx);
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
+				reinterpret_cast<const uint32_t *>(table));
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
 				g.blk_mask, chunks_per_slot);
 }
 
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
-// ROUND 1 iterates every request; ROUND 2 the list of round-1 losers, which it also
-// classifies against the round-1 registrant counts.
+// ROUND 1 iterates every request; ROUND 2 the round-1 losers.  A request that is the lowest
+// registrant of every bucket it needs executes with plain loads and stores and logs what it
+// overwrote.  A hard request (P and A full, no duplicate) runs its eviction chain if every
+// further bucket is free of registrants and other chains (try_chain), otherwise it is left
+// to the tail -- still registered, so that nothing later passes it on its own buckets.
+// No request waits for a request it shares no bucket with: an order violation between a
+// pending chain and something committed here is found when that chain walks (tail).
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
-		const unsigned long long *owner, unsigned long long *owner_next, unsigned long long *cnt,
-		const uint4 *reqc, uint8_t *state, Undo *undo, ChainLog *chain_logs, int dbg, uint32_t lo_idx,
-		uint32_t hi_idx)
+		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
+		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx)
 {
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
@@ -827,12 +889,12 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
 	const uint32_t span = gridDim.x * blockDim.x;
 	uint32_t ndone = 0;
-	// owner table holding the round-1 registrations of every request of this call
+	// owner table holding the round-1 registrations of every request of this pass (chains claim there)
 	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
 	const uint32_t carry = ctl->carry_lo;
 	const uint32_t start = carry < lo_idx ? carry : lo_idx;
-	// whole waves go round together (the losers' re-registration folds the atomics of lanes on
-	// one bucket): the loop variable is the work-group's first index
+	// whole waves go round together (the re-registration folds the atomics of lanes on one
+	// bucket): the loop variable is the work-group's first index
 	for (uint32_t base = start + blockIdx.x * blockDim.x; base < count && base >= start; base += span) {
 		const uint32_t idx = base + threadIdx.x;
 		const bool in_range = idx < count;
@@ -843,154 +905,66 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 		const Req r = req_of(rc);
 		const uint32_t P = r.hash & g.hash_mask;
 		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-		const uint32_t region = P >> g.region_shift;
 		const unsigned long long key = owner_key(stamp, idx);
-		// second round trip: reservation of P, barrier, primary bucket -- all independent.
-		// The reservation of A is only read if P cannot take the request: a request
-		// needs exclusive use of exactly the buckets it touches.
-		unsigned long long oP = 0, cP = 0, cA = 0;
-		uint32_t bar = kNone;
+		// second round trip: reservation of P and the primary bucket -- independent.  The
+		// reservation of A is only read if P cannot take the request: a request needs
+		// exclusive use of exactly the buckets it touches.
+		unsigned long long oP = 0;
 		Bkt kP;
 		kP.s0 = kP.s1 = kP.l0 = kP.l1 = make_uint4(0u, 0u, 0u, 0u);
 		if (pending) {
-			if (dbg & 4)
-				oP = key;
-			else if (dbg & 32)
-				oP = ld_agent(&owner[P]);
-			else if (dbg & 64)
-				oP = atomicMin(const_cast<unsigned long long *>(&owner[P]), key);
-			else
-				oP = owner[P];
-			if (OP == OP_CUCKOO) {
-				bar = ctl->barrier[region];
-				if (ROUND == 2) {
-					cP = cnt[P];
-					cA = cnt[A];
-				}
-			}
-			if (!(dbg & 8))
-				kP = load_bucket(table, P);
+			oP = owner[P];
+			kP = load_bucket(table, P);
 		}
-		bool done = false, lose = false, to_tail = false, bump_p = false, bump_a = false;
+		bool done = false, lose = false, to_tail = false, hard = false;
 		if (pending) {
-			// a barrier already published at or below this request: leave it to the tail
-			const bool blocked = OP == OP_CUCKOO && idx >= bar;
-			bool ownP = oP == key, ownA = true, hard = false;
-			if (ownP && !blocked) {
+			if (oP == key) {
 				Undo u;
 				u.word0 = kNoWord;
 				u.word1 = kNoWord;
 				u.old0 = 0u;
 				u.old1 = 0u;
-				if (dbg & 1)
-					done = true;
-				else
-					done = apply_primary<OP, OP == OP_CUCKOO>(table, r, P, kP, &u);
-				if (!done) {
-					// P cannot take it: the alternate bucket is needed, and its reservation
-					ownA = A == P || owner[A] == key;
-					bool chained = false;
-					if (ownA) {
-						done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
-						if (OP == OP_CUCKOO && !done) {
-							// hard: P and A full without duplicate -> eviction chain
-							atomicMin(&ctl->first_hard, idx);
-							uint32_t log_slot = 0;
-							// Round 1 only: round 2 classifies the requests still pending by what it
-							// reads in their buckets (a duplicate, free slots), and an eviction running
-							// beside that would pull a duplicate from under it.
-							chained = ROUND == 1 &&
-									try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot);
-							done = chained;
-							hard = !chained;
-							u.word0 = log_slot;
-						}
-					}
-					if (chained) {
-						state[idx] = ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2;
-						undo[idx] = u;
-						atomicAdd(&ctl->chain_ok, 1u);
-						ndone++;
-						done = true;
-						lose = false;
-						goto next_request;
+				bool chained = false;
+				done = apply_primary<OP, OP == OP_CUCKOO>(table, r, P, kP, &u);
+				if (!done && (A == P || owner[A] == key)) {
+					// P cannot take it: the alternate bucket is needed, and owned too
+					done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
+					if (OP == OP_CUCKOO && !done) {
+						// hard: P and A full without duplicate -> eviction chain
+						atomicMin(&ctl->first_hard, idx);
+						uint32_t log_slot = 0;
+						chained = try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1);
+						hard = !chained;
+						u.word0 = log_slot;
 					}
 				}
-				if (done) {
-					if (!(dbg & 16))
-						state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
-					if (OP == OP_CUCKOO && !(dbg & 2))
+				if (done || chained) {
+					state[idx] = chained ? (ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2) : (ROUND == 1 ? ST_ROUND1 : ST_ROUND2);
+					if (OP == OP_CUCKOO)
 						undo[idx] = u;
+					if (chained)
+						atomicAdd(&ctl->chain_ok, 1u);
 					ndone++;
+					done = true;
 				}
 			}
-			if (hard) {
-				// a chain that could not be run optimistically: it and everything after it
-				// in the region wait for the tail
-				atomicMin(&ctl->barrier[region], idx);
-				atomicAdd(&ctl->bar_chain, 1u);
-				to_tail = true;
-			} else if (!done) {
-				if (OP == OP_CUCKOO && ROUND == 2) {
-					// Lost round 1 AND still pending after round 2.  Round-1 commits behind
-					// it relied on its reach being static; could it turn hard before its
-					// turn?  Not if it holds a duplicate, or if P (or A, or both together)
-					// has more empty slots than other round-1 registrants (each takes at
-					// most one).  Otherwise it becomes the region's barrier.
-					// (signature 0 "matches" empty slots, which anybody may fill: no duplicate to rely on)
-					bool safe = r.sig != 0u && eq_mask(kP.s0, kP.s1, r.sig) != 0u;
-					if (!safe) {
-						const uint32_t roomP = (uint32_t)__popc(eq_mask(kP.s0, kP.s1, 0u));
-						const uint32_t othP = cnt_of(cP, stamp1);
-						safe = roomP >= 1u + othP;
-						if (!safe && A != P) {
-							uint4 lo, hi;
-							load_sig_row<false>(table, A, lo, hi);
-							const uint32_t roomA = (uint32_t)__popc(eq_mask(lo, hi, 0u));
-							const uint32_t othA = cnt_of(cA, stamp1);
-							safe = (r.sig != 0u && eq_mask(lo, hi, r.sig) != 0u) || roomA >= 1u + othA ||
-									roomP + roomA >= 1u + othP + othA;
-						}
-					}
-					if (!safe) {
-						atomicMin(&ctl->barrier[region], idx);
-						atomicAdd(&ctl->bar_class, 1u);
-					}
-				}
-				if (ROUND == 1 && !blocked) {
+			if (!done) {
+				if (ROUND == 1 && !hard)
 					lose = true;
-					if (OP == OP_CUCKOO) {
-						// registrant counts of round 1: every registrant that is not the
-						// owner adds itself (owners are counted as the +1 in the test above)
-						bump_p = !ownP;
-						bump_a = A != P && (ownP ? !ownA : owner[A] != key);
-					}
-				} else {
+				else
 					to_tail = true;
-				}
 			}
 		}
-next_request:
 		if (ROUND == 1) {
-			// The losers register for round 2 and count themselves (every lane comes by here).
-			// Many losers in one wave mean duplicates of a hot key: their atomics on one bucket
-			// are folded; the usual two or three losers go one atomic each (folding costs more
-			// instructions than it saves them).
-			if (__popcll(__ballot(lose)) >= 8) {
-				reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
-				if (OP == OP_CUCKOO) {
-					bump_wave(cnt, P, stamp1, false, lose && bump_p);
-					bump_wave(cnt, A, stamp1, false, lose && bump_a);
-				}
-			} else if (lose) {
+			// Losers register for round 2 -- and so do the hard requests left to the tail: they stay
+			// the lowest registrant of their buckets, nothing later passes them there in round 2.
+			// (Every lane comes by here.  Many in one wave mean duplicates of a hot key: their
+			// atomics on one bucket are folded; the usual two or three go one atomic each.)
+			const bool reg = lose || (hard && to_tail);
+			if (__popcll(__ballot(reg)) >= 8)
+				reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), reg);
+			else if (reg)
 				reserve(owner_next, P, A, owner_key(stamp + 1, idx));
-				if (OP == OP_CUCKOO) {
-					if (bump_p)
-						bump(cnt, P, stamp1);
-					if (bump_a)
-						bump(cnt, A, stamp1);
-				}
-			}
 		}
 		if (lose) {
 			state[idx] = ST_LOSER;
@@ -999,9 +973,117 @@ next_request:
 		if (to_tail) {
 			state[idx] = ST_TAIL;
 			ctl->any_tail = 1u;
+			if (hard) {
+				ctl->any_hard = 1u;
+				atomicAdd(&ctl->hard_tail, 1u);
+			}
 		}
 	}
 	count_add(ctl->committed[ROUND - 1], ndone);
+}
+
+// ---- order validation of eviction chains that run late ------------------------------
+// The grid-wide rounds commit a request as soon as it is the lowest registrant of the
+// buckets it needs -- without asking whether an EARLIER request that is still pending will
+// turn hard and walk its chain into one of those buckets.  That is found out when the chain
+// walks: the "touched record" holds, per bucket, the highest canonical index among the
+// requests of this pass that the grid-wide rounds have committed on it (built from the undo
+// and chain logs by the tail, only when a chain does run late); a chain of request j that
+// steps on a bucket touched by some k > j has met an order violation -- k should have run
+// after j.  Every logged commit >= j of that closed region is then rolled back and redone
+// behind j (roll_back_from).  Tail commits are never logged or undone: the tail only commits
+// a request when nothing pending below it in its region can still run a chain.
+struct Tv {
+	const unsigned long long *touched;   // per bucket: (stamp << kIdxBits) | highest committed index
+	unsigned long long tstamp;           // stamp of this pass's record; 0 = not built yet
+	uint32_t *viol;                      // per region: lowest violating index
+	uint32_t *flags;                     // bit 0: violation recorded; bit 1: record needed
+	uint32_t *vlist_n;                   // violations of this turn: {index of the chain's request, bucket}
+	uint2 *vlist;
+};
+constexpr uint32_t kTvViolation = 1u, kTvNeed = 2u;
+
+// entry of the touched record: stamp | highest committed index | bit 0 "several commits used this bucket"
+constexpr int kTouchedStampShift = kIdxBits + 1;
+__device__ __forceinline__ unsigned long long touched_key(unsigned long long tstamp, uint32_t idx)
+{
+	return (tstamp << kTouchedStampShift) | ((unsigned long long)idx << 1);
+}
+
+__device__ __forceinline__ uint32_t touched_idx(unsigned long long x)
+{
+	return (uint32_t)(x >> 1) & ((1u << kIdxBits) - 1u);
+}
+
+__device__ __forceinline__ void touched_enter(unsigned long long *touched, uint32_t b, unsigned long long key)
+{
+	const unsigned long long old = atomicMax(&touched[b], key);
+	if ((old >> kTouchedStampShift) == (key >> kTouchedStampShift) && touched_idx(old) != touched_idx(key))
+		atomicOr(&touched[b], 1ull);       // somebody else of this pass was committed here too
+}
+
+// true = a later request of this pass has already been committed on bucket b
+__device__ __forceinline__ bool touched_later(const Tv &tv, uint32_t b, uint32_t idx)
+{
+	const unsigned long long x = ld_agent(&tv.touched[b]);
+	return (x >> kTouchedStampShift) == tv.tstamp && touched_idx(x) > idx;
+}
+
+__device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g, uint32_t P, uint32_t idx,
+		uint32_t bucket)
+{
+	atomicMin(&tv.viol[P >> g.region_shift], idx);
+	const uint32_t at = atomicAdd(tv.vlist_n, 1u);
+	if (at < (uint32_t)kViolCap)
+		tv.vlist[at] = make_uint2(idx, bucket);
+	atomicOr(tv.flags, kTvViolation);
+}
+
+// One request run to completion, eviction chain included, at its place in the canonical
+// order (nothing else of its region runs meanwhile).  Every bucket the chain goes on to is
+// checked against the touched record first; the chain logs what it overwrites (it may come
+// back to a bucket it has used, so a read-only walk would not do) and restores it when it
+// has to give up.  0 = done, 1 = order violation, 2 = touched record needed (1, 2: nothing written).
+template <Op OP>
+__device__ __noinline__ int apply_serial_checked(uint32_t *table, const DevGeom &g, const Req &r, uint32_t idx, const Tv &tv)
+{
+	const uint32_t P = r.hash & g.hash_mask;
+	const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+	if (apply_static<OP, true, false>(table, r, P, A, nullptr))
+		return 0;
+	// cuckoo, P and A full without duplicate (ref :357-423)
+	if (tv.tstamp == 0ull) {
+		atomicOr(tv.flags, kTvNeed);
+		return 2;
+	}
+	uint32_t lw[kChainLogWords], lv[kChainLogWords];
+	uint32_t n = 0;
+	uint32_t sig = r.sig, loc = r.loc, b = A;
+	const uint32_t v = r.sig & 7u;          // victim slot: ORIGINAL signature (:360)
+	for (uint32_t k = 0;; k++) {
+		const uint64_t ws = sig_word(b, v), wl = loc_word(b, v);
+		const uint32_t vsig = ld_agent32(table + ws);
+		const uint32_t vloc = ld_agent32(table + wl);
+		lw[n] = (uint32_t)ws;
+		lv[n++] = vsig;
+		lw[n] = (uint32_t)wl;
+		lv[n++] = vloc;
+		table[ws] = sig;
+		table[wl] = loc;
+		if (k >= g.max_cuckoo)
+			return 0;                       // victim dropped (:414-423)
+		sig = vsig;
+		loc = vloc;
+		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
+		if (touched_later(tv, b, idx)) {
+			for (uint32_t i = n; i-- > 0;)
+				table[lw[i]] = lv[i];
+			report_violation(tv, g, P, idx, b);
+			return 1;
+		}
+		if (try_place<true, false>(table, b, sig, loc, r.sig, nullptr))
+			return 0;
+	}
 }
 
 // ---- K4: tail -------------------------------------------------------------------
@@ -1044,9 +1126,13 @@ __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 	ctl->g_left[0] = ctl->g_left[1] = 0;
 	ctl->g_dupw[0] = ctl->g_dupw[1] = 0;
 	ctl->tail_rounds_used = 0;
+	ctl->tflags = 0;
+	ctl->vlist_n = 0;
+	ctl->tstamp_cur = ctl->tstamp_next++;
 	for (int k = 0; k < kMaxRegions; k++) {
 		ctl->g_rbar[0][k] = ctl->g_rbar[1][k] = kNone;
 		ctl->g_rmin[0][k] = ctl->g_rmin[1][k] = kNone;
+		ctl->viol[k] = kNone;
 	}
 }
 
@@ -1088,45 +1174,44 @@ __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 
 // Replay of the sorted requests lkeys[0..n) one at a time per closed region, regions side
 // by side (one wave each): the region of every request is fetched by all threads at once,
-// then a region's wave walks the list with ballots and its first lane replays.  With
-// below_bar set, only requests up to their region's barrier index are replayed.
+// then a region's wave walks the list with ballots and its first lane replays.  A region
+// stops at the first request whose chain meets an order violation (or needs the touched
+// record): everything from there on stays pending.  Returns the number replayed.
 template <Op OP>
 __device__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
-		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const uint32_t *s_bar, bool below_bar,
-		uint32_t *s_count)
+		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const Tv &tv, uint32_t *s_count)
 {
 	const uint32_t t = threadIdx.x;
 	for (uint32_t i = t; i < n; i += blockDim.x) {
 		const uint32_t idx = lkeys[i];
 		const uint4 rc = reqc[idx];
-		const uint32_t region = (rc.y & g.hash_mask) >> g.region_shift;
-		const bool take = !below_bar || (s_bar[region] != kNone && idx <= s_bar[region]);
-		lreg[i] = take ? (uint8_t)region : (uint8_t)0xffu;
-		if (take) {
-			// touch both buckets: the replaying lane then finds them in L2
-			const uint32_t P = rc.y & g.hash_mask, A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
-			const uint32_t a = ld_agent32(table + sig_word(P, 0u)), b = ld_agent32(table + sig_word(A, 0u));
-			asm volatile("" ::"v"(a), "v"(b));
-		}
+		const uint32_t P = rc.y & g.hash_mask, A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+		lreg[i] = (uint8_t)(P >> g.region_shift);
+		// touch both buckets: the replaying lane then finds them in L2
+		const uint32_t a = ld_agent32(table + sig_word(P, 0u)), b = ld_agent32(table + sig_word(A, 0u));
+		asm volatile("" ::"v"(a), "v"(b));
 	}
 	__syncthreads();
 	const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
 	for (uint32_t region = wave; region < g.nregions; region += nwaves) {
-		if (below_bar && s_bar[region] == kNone)
-			continue;
 		uint32_t d = 0;
-		for (uint32_t base = 0; base < n; base += 64u) {
+		bool stop = false;
+		for (uint32_t base = 0; base < n && !stop; base += 64u) {
 			const uint32_t i = base + lane;
 			unsigned long long todo = __ballot(i < n && lreg[i] == (uint8_t)region);
-			while (todo) {
+			while (todo && !stop) {
 				const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
 				todo &= todo - 1ull;
+				int rc = 0;
 				if (lane == 0) {
 					const uint32_t idx = lkeys[base + j];
-					apply_serial<OP>(table, g, req_of(reqc[idx]));
-					state[idx] = ST_DONE;
-					d++;
+					rc = apply_serial_checked<OP>(table, g, req_of(reqc[idx]), idx, tv);
+					if (rc == 0) {
+						state[idx] = ST_DONE;
+						d++;
+					}
 				}
+				stop = __shfl(rc, 0) != 0;
 			}
 		}
 		if (lane == 0 && d)
@@ -1136,14 +1221,14 @@ __device__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint
 	return *s_count;
 }
 
-// The same for a list too long for LDS (final pass, one work-group): the pending
-// requests of [lo_idx, total) are first compacted IN INDEX ORDER into the global list
-// (each thread takes a contiguous run of tags: count, scan, write), then every region's
-// wave walks that list 64 entries at a time -- all lanes fetch their entry's hash and
-// touch its buckets (so the replaying lane finds them in L2), lane 0 replays its region's.
+// The same for a list too long for LDS (one work-group): the pending requests of
+// [lo_idx, total) are first compacted IN INDEX ORDER into the global list (each thread takes
+// a contiguous run of tags: count, scan, write), then every region's wave walks that list 64
+// entries at a time -- all lanes fetch their entry's hash and touch its buckets (so the
+// replaying lane finds them in L2), lane 0 replays its region's, stopping like replay_regions.
 template <Op OP>
 __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
-		uint32_t *glist, uint32_t *scratch1024, uint32_t lo_idx, uint32_t total, uint32_t *s_count)
+		uint32_t *glist, uint32_t *scratch1024, uint32_t lo_idx, uint32_t total, const Tv &tv, uint32_t *s_count)
 {
 	const uint32_t t = threadIdx.x;
 	const uint32_t lo16 = lo_idx & ~15u;
@@ -1191,7 +1276,8 @@ __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const
 	const uint32_t wave = t >> 6, lane = t & 63u, nwaves = blockDim.x >> 6;
 	for (uint32_t region = wave; region < g.nregions; region += nwaves) {
 		uint32_t d = 0;
-		for (uint32_t base = 0; base < n; base += 64u) {
+		bool stop = false;
+		for (uint32_t base = 0; base < n && !stop; base += 64u) {
 			const uint32_t i = base + lane;
 			uint32_t idx = 0;
 			bool mine = false;
@@ -1208,15 +1294,19 @@ __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const
 				}
 			}
 			unsigned long long todo = __ballot(mine);
-			while (todo) {
+			while (todo && !stop) {
 				const uint32_t j = (uint32_t)__ffsll((long long)todo) - 1u;
 				todo &= todo - 1ull;
 				const uint32_t ridx = __shfl(idx, (int)j);
+				int rc = 0;
 				if (lane == 0) {
-					apply_serial<OP>(table, g, req_of(reqc[ridx]));
-					state[ridx] = ST_DONE;
-					d++;
+					rc = apply_serial_checked<OP>(table, g, req_of(reqc[ridx]), ridx, tv);
+					if (rc == 0) {
+						state[ridx] = ST_DONE;
+						d++;
+					}
 				}
+				stop = __shfl(rc, 0) != 0;
 			}
 		}
 		if (lane == 0 && d)
@@ -1227,15 +1317,21 @@ __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const
 }
 
 // Tail rounds, decide phase: read-only walk of the eviction chain of a hard request
-// that owns P and A, claiming every further bucket in the round's owner table.
-// True = nobody registered or claimed any of them this round, the chain never
-// returns to a bucket it already used (so the walk saw what the real run will
-// see) -- the request may run its chain in this round's commit phase.
+// that owns P and A, claiming every further bucket in the round's owner table.  True =
+// nobody registered or claimed any of them this round (a bucket somebody else is on stops
+// the walk -- also a LATER request's: the classification "cannot turn hard" of pending
+// requests counts the free slots and duplicates of the buckets they registered, which no
+// chain may then change under them), the chain never returns to a bucket it already used (so
+// the walk saw what the real run will see), and no later request of this pass was COMMITTED
+// on one of them by the grid-wide rounds (touched record; else: order violation, reported)
+// -- the request may run its chain in this round's commit phase.
 __device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
-		uint32_t idx, unsigned long long *owner, unsigned long long stamp)
+		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv)
 {
-	if (g.max_cuckoo > 6u)
+	if (tv.tstamp == 0ull) {
+		atomicOr(tv.flags, kTvNeed);        // (the caller treats the request as this round's barrier)
 		return false;
+	}
 	const unsigned long long mykey = owner_key(stamp, idx);
 	const unsigned long long stamp_field = kStampMax - stamp;
 	const uint32_t v = r.sig & 7u;
@@ -1254,12 +1350,45 @@ __device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Re
 				return false;
 		const unsigned long long old = atomicMin(&owner[nb], mykey);
 		if ((old >> kIdxBits) == stamp_field && old != mykey)
+			return false;                           // another pending request is on nb
+		// a later request of this pass was committed on nb by the grid-wide rounds: order violation
+		if (touched_later(tv, nb, idx)) {
+			report_violation(tv, g, P, idx, nb);
 			return false;
+		}
 		seen[nseen++] = nb;
 		uint4 lo, hi;
 		load_sig_row<true>(table, nb, lo, hi);
 		if (eq_mask(lo, hi, vsig) || eq_mask(lo, hi, 0u))
 			return true;                            // the victim finds a duplicate or room here
+		b = nb;
+	}
+}
+
+// Commit phase: does the request tagged CHAIN_OK still own P, A and every bucket of the walk?
+// (An earlier chain that came by after this request's claim has lowered the entry -- and has
+// become the round's barrier, so this request is held back anyway; this is the belt to those
+// braces.)  Buckets it owns are written by nobody else in this phase, so the walk reads what
+// the decide phase read.
+__device__ bool chain_still_owned(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
+		uint32_t idx, const unsigned long long *owner, unsigned long long stamp)
+{
+	const unsigned long long mykey = owner_key(stamp, idx);
+	if (ld_agent(&owner[P]) != mykey || (A != P && ld_agent(&owner[A]) != mykey))
+		return false;
+	const uint32_t v = r.sig & 7u;
+	uint32_t b = A;
+	for (uint32_t k = 0;; k++) {
+		if (k >= g.max_cuckoo)
+			return true;
+		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
+		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);
+		if (ld_agent(&owner[nb]) != mykey)
+			return false;
+		uint4 lo, hi;
+		load_sig_row<true>(table, nb, lo, hi);
+		if (eq_mask(lo, hi, vsig) || eq_mask(lo, hi, 0u))
+			return true;
 		b = nb;
 	}
 }
@@ -1318,10 +1447,10 @@ template <Op OP>
 __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
-		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used)
+		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used, const Tv &tv, uint32_t stamp_skip)
 {
 	const uint32_t t = threadIdx.x;
-	const unsigned long long stamp0 = ctl->stamp_base + 2;
+	const unsigned long long stamp0 = ctl->stamp_base + 2 + stamp_skip;   // (stamps earlier calls of this launch used)
 	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
 	uint32_t left = m, recent = 0;
 	for (int round = 0; round < max_rounds && left != 0; round++) {
@@ -1401,7 +1530,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				bool bad = clean ? room == 0u : room < 1u + others;
 				if (bad && clean) {
 					// hard right now: it may still run this round if its chain is all its own
-					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp)) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv)) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
 					}
@@ -1438,7 +1567,11 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				const uint32_t bar = s_rbar[region];
 				const uint8_t st = state[idx];
 				if (idx == bar && idx == s_rmin[region]) {
-					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
+					// first of its region: exact, alone (its chain checked against the touched record)
+					if (apply_serial_checked<OP>(table, g, r, idx, tv) != 0) {
+						atomicAdd(s_left, 1u);
+						continue;
+					}
 					done = true;
 				} else if (idx >= bar || st == ST_DUPW) {
 					if (st >= ST_CHAIN_OK)
@@ -1446,6 +1579,11 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					atomicAdd(s_left, 1u);
 					continue;
 				} else if (st == ST_CHAIN_OK) {
+					if (!chain_still_owned(table, g, r, P, A, idx, owner, stamp)) {
+						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
+						atomicAdd(s_left, 1u);
+						continue;
+					}
 					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
 					done = true;
 				} else if (st == ST_DUPW_OK) {
@@ -1476,7 +1614,9 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		// a round that resolves less than the one-at-a-time replay would in its time
 		// (duplicates of one key, chains in a row) is not worth another
 		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
-		if (progress == 0 || (round >= 3 && recent < kMinRoundProgress))
+		// an order violation (or a chain waiting for the touched record) blocks its region until the
+		// caller has dealt with it
+		if (progress == 0 || (round >= 3 && recent < kMinRoundProgress) || ld_agent32(tv.flags) != 0u)
 			break;
 	}
 	return left;
@@ -1491,14 +1631,14 @@ template <Op OP>
 __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
-		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks)
+		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip)
 {
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
 	unsigned long long tick = wall_clock64();
 	// ticks[0..7]: register, its meeting, decide, its meeting, election + meeting, commit, its meeting
 #define MKV_GTICK(k) do { const unsigned long long now_ = wall_clock64(); ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
-	const unsigned long long stamp0 = ctl->stamp_base + 2;
+	const unsigned long long stamp0 = ctl->stamp_base + 2 + stamp_skip;
 	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
 	uint32_t left = m, nth = 0, used = 0, par = 0, recent = 0;
 	for (int round = 0; round < max_rounds && left != 0; round++) {
@@ -1582,7 +1722,7 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				}
 				bool bad = clean ? room == 0u : room < 1u + others;
 				if (bad && clean) {
-					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp)) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv)) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
 					}
@@ -1641,7 +1781,11 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 				const uint32_t bar = s_rbar[region];
 				const uint8_t st = state[idx];
 				if (idx == bar && idx == s_rmin[region]) {
-					apply_serial<OP>(table, g, r);      // first of its region: exact, alone
+					// first of its region: exact, alone (its chain checked against the touched record)
+					if (apply_serial_checked<OP>(table, g, r, idx, tv) != 0) {
+						my_left++;
+						continue;
+					}
 					done = true;
 				} else if (idx >= bar || st == ST_DUPW) {
 					if (st >= ST_CHAIN_OK)
@@ -1649,6 +1793,11 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 					my_left++;
 					continue;
 				} else if (st == ST_CHAIN_OK) {
+					if (!chain_still_owned(table, g, r, P, A, idx, owner, stamp)) {
+						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
+						my_left++;
+						continue;
+					}
 					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
 					done = true;
 				} else if (st == ST_DUPW_OK) {
@@ -1690,7 +1839,8 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 		// rounds go on while they resolve more than the one-at-a-time replay would in their
 		// time, judged over the last few (the round after a chain is often a thin one)
 		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
-		if (progress == 0 || (round >= 3 && recent < kMinGridProgress))
+		// (the flags were last written before the meeting above: every work-group reads the same)
+		if (progress == 0 || (round >= 3 && recent < kMinGridProgress) || ld_agent32(tv.flags) != 0u)
 			break;
 	}
 	*rounds_used = used;
@@ -1698,19 +1848,352 @@ __device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 	return left;
 }
 
+__device__ __forceinline__ bool tag_pending(uint32_t st)
+{
+	return st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK;
+}
+
+__device__ __forceinline__ bool tag_logged(uint32_t st)
+{
+	return st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2;
+}
+
+// The touched record of this pass: every request the grid-wide rounds have committed (its
+// tag says so) enters its index, under the stamp `tstamp`, on each bucket it used -- the
+// primary bucket always (examined even when full), the alternate bucket when the commit went
+// there, and every bucket of an eviction chain.  atomicMax keeps the highest index; stamps
+// only grow, so entries of earlier passes lose.  Shared by `nwg` work-groups (neighbouring
+// 16-tag groups go to different ones).
+__device__ __noinline__ void build_touched(const DevGeom &g, const uint8_t *state, const uint4 *reqc, const Undo *undo,
+		const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp, uint32_t lo_idx,
+		uint32_t total, uint32_t wg, uint32_t nwg)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+	for (uint32_t base = lo16 + (t * nwg + wg) * 16u; base < total && base >= lo16; base += nwg * blockDim.x * 16u) {
+		const uint4 v4 = st4[base >> 4];
+		const uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
+#pragma unroll
+		for (int kk = 0; kk < 16; kk++) {
+			const uint32_t st = (w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu;
+			const uint32_t idx = base + (uint32_t)kk;
+			if (idx < lo_idx || idx >= total || !tag_logged(st))
+				continue;
+			const uint32_t sig = reqw[(size_t)idx * 4u], hash = reqw[(size_t)idx * 4u + 1u];
+			const uint32_t P = hash & g.hash_mask;
+			const uint32_t A = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
+			const unsigned long long key = touched_key(tstamp, idx);
+			const Undo u = undo[idx];
+			touched_enter(touched, P, key);
+			if (st == ST_CHAIN1 || st == ST_CHAIN2) {
+				touched_enter(touched, A, key);
+				const ChainLog *L = &chain_logs[u.word0];
+				const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+				uint32_t last = A;
+				for (uint32_t i = 0; i < n; i++) {
+					const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
+					if (b != last)
+						touched_enter(touched, b, key);
+					last = b;
+				}
+			} else if ((u.word0 >> 4) != P) {
+				touched_enter(touched, A, key);
+			}
+		}
+	}
+}
+
+// The usual order violation is small: the chain of a pending request j steps on a bucket
+// that exactly ONE later commit k has used, and nothing was committed after k on any bucket
+// of k's reach.  Then k alone is taken back: its words restored, its tag back to pending, its
+// entries of the touched record cleared -- no sweep over the pass.  One lane per k; the lanes
+// of a turn work on different k (the caller sees to that) and, by the test below, on disjoint
+// buckets.  true = dealt with (or nothing to do any more); false = the general way is needed.
+__device__ __noinline__ bool undo_sole_commit(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
+		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp,
+		uint32_t j, uint32_t X, uint32_t *undone)
+{
+	const unsigned long long x = ld_agent(&touched[X]);
+	if ((x >> kTouchedStampShift) != tstamp || touched_idx(x) <= j)
+		return true;                        // already cleared by another undo of this turn: the chain walks again
+	if (x & 1ull)
+		return false;                       // several commits used X
+	const uint32_t k = touched_idx(x);
+	const uint32_t st = state[k];
+	if (!tag_logged(st))
+		return false;                       // (not expected: the record names commits only)
+	const uint4 rc = reqc[k];
+	const uint32_t P = rc.y & g.hash_mask;
+	const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+	const Undo u = undo[k];
+	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
+	const ChainLog *L = chain ? &chain_logs[u.word0] : nullptr;
+	const uint32_t n = chain ? (L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords) : 0u;
+	const unsigned long long mine = touched_key(tstamp, k);
+	const bool usedA = chain || (u.word0 >> 4) != P;
+	// every bucket k used must name k alone; the alternate bucket, if k did not use it, no later commit
+	if (ld_agent(&touched[P]) != mine)
+		return false;
+	if (A != P) {
+		const unsigned long long y = ld_agent(&touched[A]);
+		if (usedA ? y != mine : ((y >> kTouchedStampShift) == tstamp && touched_idx(y) > k))
+			return false;
+	}
+	for (uint32_t i = 0; i < n; i++)
+		if (ld_agent(&touched[L->word[i] >> 4]) != mine)
+			return false;
+	// take it back (newest store first)
+	if (chain) {
+		for (uint32_t i = n; i-- > 0;)
+			table[L->word[i]] = L->old[i];
+	} else {
+		if (u.word1 != kNoWord)
+			table[u.word1] = u.old1;
+		if (u.word0 != kNoWord)
+			table[u.word0] = u.old0;
+	}
+	state[k] = ST_TAIL;
+	atomicExch(&touched[P], 0ull);
+	if (usedA && A != P)
+		atomicExch(&touched[A], 0ull);
+	for (uint32_t i = 0; i < n; i++)
+		atomicExch(&touched[L->word[i] >> 4], 0ull);
+	(*undone)++;
+	return true;
+}
+
+// An order violation {j, X}: the chain of the pending request j steps on bucket X, which
+// a LATER request has already used.  Which commits of the grid-wide rounds have to go?
+//   (a) every logged commit k > j that has X in its reach (primary, alternate, chain buckets);
+//   (b) for every commit u taken back, every logged commit k' > u that has one of u's buckets
+//       in its reach: it ran there after u, and u will run again.
+// Fixed point over a list of {bucket, index} in LDS, seeded with the violations of this turn;
+// every sweep over the tags tests the commits not yet selected against the entries the sweep
+// before added.  Selected commits get the ST_SELECT flag on their tag (roll_back_from takes
+// them back).  Commits that keep their place ran on their buckets before everything selected
+// there -- or on other buckets -- so they stand.  Returns false when the list overflows: the
+// caller then takes back the whole region suffix (a superset).  One work-group.
+__device__ __noinline__ bool select_dependents(const DevGeom &g, uint8_t *state, const uint4 *reqc, const Undo *undo,
+		const ChainLog *chain_logs, const uint2 *seeds, uint32_t nseeds, uint32_t lo_idx, uint32_t total,
+		uint32_t *dB, uint32_t *dT, uint32_t *s_nd, uint32_t *s_flag)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+	uint4 *st4 = reinterpret_cast<uint4 *>(state);
+	for (uint32_t i = t; i < nseeds; i += blockDim.x) {
+		const uint32_t *sw = reinterpret_cast<const uint32_t *>(seeds + i);
+		dT[i] = ld_agent32(sw);            // {index of the chain's request, bucket it stepped on}
+		dB[i] = ld_agent32(sw + 1);
+	}
+	if (t == 0) {
+		*s_nd = nseeds;
+		*s_flag = 0;
+	}
+	__syncthreads();
+	uint32_t from = 0;
+	for (;;) {
+		const uint32_t nd = *s_nd;
+		__syncthreads();
+		if (from >= nd)
+			return true;
+		for (uint32_t base = lo16 + t * 16u; base < total && base >= lo16; base += blockDim.x * 16u) {
+			const uint4 v4 = st4[base >> 4];
+			uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
+			if (!((v4.x | v4.y | v4.z | v4.w) & 0x06060606u))
+				continue;                           // (no commit tag -- 2, 3, 6, 7 -- among these sixteen)
+			bool changed = false;
+#pragma nounroll
+			for (int kk = 0; kk < 16; kk++) {
+				const uint32_t sh = (uint32_t)(kk & 3) * 8u;
+				const uint32_t st = (w4[kk >> 2] >> sh) & 0xffu;
+				const uint32_t idx = base + (uint32_t)kk;
+				if (idx < lo_idx || idx >= total || !tag_logged(st))
+					continue;                       // (a selected tag carries ST_SELECT: not "logged" any more)
+				const uint32_t sig = reqw[(size_t)idx * 4u], hash = reqw[(size_t)idx * 4u + 1u];
+				uint32_t bk[2 + kChainLogWords / 2];
+				uint32_t nb = 0;
+				bk[nb++] = hash & g.hash_mask;
+				bk[nb++] = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
+				if (st == ST_CHAIN1 || st == ST_CHAIN2) {
+					const ChainLog *L = &chain_logs[undo[idx].word0];
+					const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+					uint32_t last = bk[1];
+					for (uint32_t i = 0; i < n; i++) {
+						const uint32_t b = L->word[i] >> 4;
+						if (b != last && nb < 2u + (uint32_t)kChainLogWords / 2u)
+							bk[nb++] = b;
+						last = b;
+					}
+				}
+				bool hit = false;
+				for (uint32_t i = from; i < nd && !hit; i++)
+					for (uint32_t q = 0; q < nb; q++)
+						hit |= bk[q] == dB[i] && idx > dT[i];
+				if (!hit)
+					continue;
+				w4[kk >> 2] |= (uint32_t)ST_SELECT << sh;
+				changed = true;
+				const uint32_t at = atomicAdd(s_nd, nb);
+				if (at + nb <= (uint32_t)kDirtyCap) {
+					for (uint32_t q = 0; q < nb; q++) {
+						dB[at + q] = bk[q];
+						dT[at + q] = idx;
+					}
+				} else {
+					*s_flag = 1u;
+				}
+			}
+			if (changed)
+				st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+		}
+		__syncthreads();
+		if (*s_flag)
+			return false;
+		from = nd;
+	}
+}
+
+// Roll back the commits of the grid-wide rounds that are flagged ST_SELECT (select_dependents)
+// or lie at or beyond thr[region of the request] (kNone: none by index in that region), newest
+// round first; the requests become pending again (tag TAIL).  A thread owns the 16 tags it loads; the loads of a step are issued together.
+// `nwg` work-groups share the scan and meet between the two rounds on `sync_counter`.
+// Returns the number this thread rolled back.
+__device__ __noinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
+		const Undo *undo, const ChainLog *chain_logs, const uint32_t *thr, uint32_t lo_idx, uint32_t total,
+		uint32_t wg, uint32_t nwg, uint32_t *sync_counter)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint32_t gfirst = lo16 + (t * nwg + wg) * 16u;
+	const uint32_t gstride = nwg * blockDim.x * 16u;
+	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+	uint4 *st4 = reinterpret_cast<uint4 *>(state);
+	uint32_t undone = 0;
+	for (int pass = 0; pass < 2; pass++) {
+		const uint32_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
+		const uint32_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
+		for (uint32_t base = gfirst; base < total && base >= lo16; base += gstride) {
+			const uint4 v4 = st4[base >> 4];
+			uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
+			uint32_t need = 0;
+#pragma unroll
+			for (int kk = 0; kk < 16; kk++) {
+				const uint32_t st = (w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu;
+				const uint32_t idx = base + (uint32_t)kk;
+				if (idx >= lo_idx && idx < total && ((st & 0x7fu) == tag || (st & 0x7fu) == ctag))
+					need |= 1u << kk;
+			}
+			if (!need)
+				continue;
+			// request hash (for the region) and undo record of every candidate, one batch
+			uint32_t hashes[16];
+			Undo us[16];
+#pragma unroll
+			for (int kk = 0; kk < 16; kk++) {
+				hashes[kk] = (need >> kk) & 1u ? reqw[(size_t)(base + (uint32_t)kk) * 4u + 1u] : 0u;
+				if ((need >> kk) & 1u)
+					us[kk] = undo[base + (uint32_t)kk];
+			}
+#pragma unroll
+			for (int kk = 0; kk < 16; kk++)
+				if (((need >> kk) & 1u) && !((w4[kk >> 2] >> ((kk & 3) * 8)) & (uint32_t)ST_SELECT) &&
+						base + (uint32_t)kk < thr[(hashes[kk] & g.hash_mask) >> g.region_shift])
+					need &= ~(1u << kk);
+			if (!need)
+				continue;
+#pragma unroll
+			for (int kk = 0; kk < 16; kk++) {
+				if (!((need >> kk) & 1u))
+					continue;
+				const uint32_t sh = (uint32_t)(kk & 3) * 8u;
+				const uint32_t st = (w4[kk >> 2] >> sh) & 0x7fu;
+				if (st == ctag) {
+					// the whole log record in one batch of loads, then the stores, newest first
+					static_assert(sizeof(ChainLog) == 128, "ChainLog is read as 8 x 16 bytes");
+					const uint4 *lp = reinterpret_cast<const uint4 *>(&chain_logs[us[kk].word0]);
+					uint4 q[8];
+#pragma unroll
+					for (int i = 0; i < 8; i++)
+						q[i] = lp[i];
+					const uint32_t lw[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
+							q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
+							q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w,
+							q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
+#pragma unroll
+					for (int i = kChainLogWords - 1; i >= 0; i--)
+						if ((uint32_t)i < lw[0])
+							table[lw[1 + i]] = lw[1 + kChainLogWords + i];
+				} else {
+					if (us[kk].word1 != kNoWord)
+						table[us[kk].word1] = us[kk].old1;
+					if (us[kk].word0 != kNoWord)
+						table[us[kk].word0] = us[kk].old0;
+				}
+				w4[kk >> 2] = (w4[kk >> 2] & ~(0xffu << sh)) | ((uint32_t)ST_TAIL << sh);
+				undone++;
+			}
+			st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+		}
+		if (pass == 0)
+			grid_sync(sync_counter, nwg);   // every round-2 undo lands before any round-1 undo
+	}
+	return undone;
+}
+
+// Gather the unfinished requests of [lo_idx, total) into list[] (any order), counting in
+// *counter (LDS for one work-group, the control block for several).
+__device__ void gather_pending(const uint8_t *state, uint32_t *list, uint32_t *counter, uint32_t lo_idx,
+		uint32_t total, uint32_t wg, uint32_t nwg)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+	for (uint32_t base = lo16 + (t * nwg + wg) * 16u; base < total && base >= lo16; base += nwg * blockDim.x * 16u) {
+		const uint4 v = st4[base >> 4];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		uint32_t take = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
+			const uint32_t idx = base + (uint32_t)k;
+			if (idx >= lo_idx && idx < total && tag_pending(st))
+				take |= 1u << k;
+		}
+		if (!take)
+			continue;
+		uint32_t at = atomicAdd(counter, (uint32_t)__popc(take));
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+			if ((take >> k) & 1u)
+				list[at++] = base + (uint32_t)k;
+	}
+}
+
+// ---- the tail launch ----------------------------------------------------------------------
+// Finishes what rounds 1 and 2 left: losers of both rounds and hard requests whose chain
+// could not run beside the other requests.  All work-groups share the scans when there is
+// much to scan (touched record, gather) and the rounds when much is left (grid_rounds);
+// otherwise the helpers leave at once and work-group 0 does the rest: reservation rounds,
+// then the in-order replay per closed region.  A chain that meets an order violation makes
+// the launch roll back the later commits of that region and take them on as well.
 template <Op OP>
 __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
-		unsigned long long *owner, unsigned long long *cnt, const uint4 *reqc, uint8_t *state,
-		const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds, uint32_t lo_idx,
-		uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min)
+		unsigned long long *owner, unsigned long long *cnt, unsigned long long *touched, const uint4 *reqc,
+		uint8_t *state, const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds,
+		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min)
 {
 	__shared__ uint32_t lkeys[kSortCap];
-	__shared__ uint8_t lreg[kSortCap];          // region of a gathered request (exact replay below a barrier)
-	__shared__ uint32_t s_bar[kMaxRegions];     // call-wide barrier (roll-back only)
+	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
+	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
+	__shared__ uint32_t dB[kDirtyCap], dT[kDirtyCap];   // select_dependents: {bucket, index} of what is taken back
+	__shared__ uint32_t s_nd, s_dflag;
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
-	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw;
-	__shared__ uint32_t s_carry;
+	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
+	__shared__ unsigned long long s_tstamp;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	unsigned long long tick = wall_clock64();
 	uint32_t phase_ticks[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -1720,27 +2203,19 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	const uint32_t carry_in = ctl->carry_lo;
 	if (carry_in < lo_idx)
 		lo_idx = carry_in;                        // this pass also covered the carried requests
-	const bool any_tail = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
-	if (t < kMaxRegions)
-		s_bar[t] = t < g.nregions ? ctl->barrier[t] : kNone;
+	const bool work_left = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
+	const bool any_hard = OP == OP_CUCKOO && ctl->any_hard != 0u;
 	if (t == 0) {
 		s_n = 0;
 		s_undone = 0;
 		s_par = 0;
 		s_serial = 0;
-		s_carry = kNone;
+		s_viols = 0;
 	}
-	__syncthreads();
-	bool any_bar = false;
-	for (uint32_t k = 0; k < g.nregions; k++)
-		any_bar |= s_bar[k] != kNone;
-	const bool work_left = any_tail || (OP == OP_CUCKOO && any_bar);
-	// The scans over the request tags (roll-back, gather) can be shared by all work-groups
-	// of the launch; everything after them is work-group 0's.  The helpers only stay when
-	// there is something to roll back or much left to gather -- judged by what every
-	// work-group reads alike: the barriers and the rounds' commit counters (both final, and
-	// only changed by the kernels before this one in the stream).
-	__shared__ uint32_t s_done12;
+	// The scans over the request tags can be shared by all work-groups of the launch;
+	// everything after them is work-group 0's (unless much is left).  The helpers only stay when
+	// that pays -- judged by what every work-group reads alike: the rounds' flags and commit
+	// counters (final: only the kernels before this one in the stream change them).
 	if (t < 64u) {
 		uint32_t c = ctl->committed[0][t] + ctl->committed[1][t];
 		for (int off = 32; off > 0; off >>= 1)
@@ -1751,294 +2226,195 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	__syncthreads();
 	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
 	const uint32_t pending_est = span > s_done12 ? span - s_done12 : 0u;
-	const bool use_helpers = nwg > 1u && ((OP == OP_CUCKOO && any_bar) || pending_est > (uint32_t)kTailAloneMax ||
-			span > (uint32_t)kTailAloneSpan);     // (a long tag range is worth sharing even if little is left in it)
+	const bool use_helpers = nwg > 1u && (pending_est > (uint32_t)kTailAloneMax || span > (uint32_t)kTailAloneSpan ||
+			(any_hard && span > 8192u));          // (a long tag range is worth sharing even if little is left in it)
 	if (wg != 0 && (!work_left || !use_helpers))
 		return;
 	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
-	const uint32_t lo16 = lo_idx & ~15u;
-	const uint32_t gfirst = lo16 + (t * nwg_eff + wg) * 16u;   // neighbouring 16-tag groups go to different work-groups
-	const uint32_t gstride = nwg_eff * blockDim.x * 16u;
-	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	uint4 *st4 = reinterpret_cast<uint4 *>(state);
-
-	// -- roll back optimistic commits at or beyond the barrier, newest round first.  A
-	// thread owns the 16 tags it loads; the loads of a step are issued together.
-	if (OP == OP_CUCKOO && any_bar) {
-		uint32_t undone = 0;
-		for (int pass = 0; pass < 2; pass++) {
-			const uint32_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
-			const uint32_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
-			for (uint32_t base = gfirst; base < total && base >= lo16; base += gstride) {
-				const uint4 v4 = st4[base >> 4];
-				uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
-				uint32_t need = 0;
-#pragma unroll
-				for (int kk = 0; kk < 16; kk++) {
-					const uint32_t st = (w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu;
-					const uint32_t idx = base + (uint32_t)kk;
-					if (idx >= lo_idx && idx < total && (st == tag || st == ctag))
-						need |= 1u << kk;
-				}
-				if (!need)
-					continue;
-				// request hash (for the region) and undo record of every candidate, one batch
-				uint32_t hashes[16];
-				Undo us[16];
-#pragma unroll
-				for (int kk = 0; kk < 16; kk++) {
-					hashes[kk] = (need >> kk) & 1u ? reqw[(size_t)(base + (uint32_t)kk) * 4u + 1u] : 0u;
-					if ((need >> kk) & 1u)
-						us[kk] = undo[base + (uint32_t)kk];
-				}
-#pragma unroll
-				for (int kk = 0; kk < 16; kk++)
-					if (((need >> kk) & 1u) &&
-							base + (uint32_t)kk < s_bar[(hashes[kk] & g.hash_mask) >> g.region_shift])
-						need &= ~(1u << kk);
-				if (!need)
-					continue;
-#pragma unroll
-				for (int kk = 0; kk < 16; kk++) {
-					if (!((need >> kk) & 1u))
-						continue;
-					const uint32_t sh = (uint32_t)(kk & 3) * 8u;
-					const uint32_t st = (w4[kk >> 2] >> sh) & 0xffu;
-					if (st == ctag) {
-						// the whole log record in one batch of loads, then the stores, newest first
-						static_assert(sizeof(ChainLog) == 128, "ChainLog is read as 8 x 16 bytes");
-						const uint4 *lp = reinterpret_cast<const uint4 *>(&chain_logs[us[kk].word0]);
-						uint4 q[8];
-#pragma unroll
-						for (int i = 0; i < 8; i++)
-							q[i] = lp[i];
-						const uint32_t lw[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
-								q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
-								q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w,
-								q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
-#pragma unroll
-						for (int i = kChainLogWords - 1; i >= 0; i--)
-							if ((uint32_t)i < lw[0])
-								table[lw[1 + i]] = lw[1 + kChainLogWords + i];
-					} else {
-						if (us[kk].word1 != kNoWord)
-							table[us[kk].word1] = us[kk].old1;
-						if (us[kk].word0 != kNoWord)
-							table[us[kk].word0] = us[kk].old0;
-					}
-					w4[kk >> 2] = (w4[kk >> 2] & ~(0xffu << sh)) | ((uint32_t)ST_TAIL << sh);
-					undone++;
-				}
-				st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
-			}
-			if (pass == 0)
-				grid_sync(&ctl->sync[0], nwg_eff);   // every round-2 undo lands before any round-1 undo
-		}
-		if (undone)
-			atomicAdd(&s_undone, undone);
-	}
-	MKV_PHASE(0);
-	// A non-final chunk hands its unresolved requests to the next chunk's grid-wide
-	// pass instead of working them off in this one work-group -- unless there are too
-	// many to sort in LDS, in which case it behaves like the final chunk.
-	bool full_tail = last_chunk != 0;
+	unsigned long long tstamp = 0;
 	bool grid_mode = false;
 	if (work_left) {
-		// -- gather what is left (tags TAIL / LOSER / PENDING / CHAIN_OK) into the global list,
-		// same tag ownership as the roll-back (a thread sees the tags it rewrote).  Of a
-		// non-final chunk only what must be resolved here is listed: pending requests up to
-		// their region's barrier index; the lowest index of the rest is the next carry.
-		uint32_t mine = kNone;
-		for (uint32_t base = gfirst; base < total && base >= lo16; base += gstride) {
-			const uint4 v = st4[base >> 4];
-			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-			uint32_t take = 0;
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-				const uint32_t idx = base + (uint32_t)k;
-				if (idx >= lo_idx && idx < total &&
-						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK))
-					take |= 1u << k;
-			}
-			if (!take)
-				continue;
-			if (!last_chunk) {
-				uint32_t keep = 0;
-				if (OP == OP_CUCKOO && any_bar) {
-					uint32_t hashes[16];
-#pragma unroll
-					for (int k = 0; k < 16; k++)
-						hashes[k] = (take >> k) & 1u ? reqw[(size_t)(base + (uint32_t)k) * 4u + 1u] : 0u;
-#pragma unroll
-					for (int k = 0; k < 16; k++) {
-						const uint32_t bar = s_bar[(hashes[k] & g.hash_mask) >> g.region_shift];
-						if (((take >> k) & 1u) && bar != kNone && base + (uint32_t)k <= bar)
-							keep |= 1u << k;        // (a region without barrier carries all it has left)
-					}
-				}
-				const uint32_t rest = take & ~keep;
-				if (rest) {
-					const uint32_t idx = base + (uint32_t)__ffs((int)rest) - 1u;
-					if (idx < mine)
-						mine = idx;
-				}
-				take = keep;
-				if (!take)
-					continue;
-			}
-			uint32_t at = atomicAdd(&ctl->glist_n, (uint32_t)__popc(take));
-#pragma unroll
-			for (int k = 0; k < 16; k++)
-				if ((take >> k) & 1u)
-					glist[at++] = base + (uint32_t)k;
+		// hard requests were left to the tail: their chains will be checked against the touched record
+		if (any_hard) {
+			tstamp = ctl->tstamp_cur;
+			build_touched(g, state, reqc, undo, chain_logs, touched, tstamp, lo_idx, total, wg, nwg_eff);
 		}
+		MKV_PHASE(0);
+		gather_pending(state, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff);
 		MKV_PHASE(6);
-		// one global atomic per work-group (same-address atomics are slow): wave, LDS, global
-		for (int off = 32; off > 0; off >>= 1) {
-			const uint32_t o = __shfl_down(mine, off);
-			mine = o < mine ? o : mine;
-		}
-		if ((t & 63u) == 0u && mine != kNone)
-			atomicMin(&s_carry, mine);
-		__syncthreads();
-		if (t == 0) {
-			if (s_carry != kNone)
-				atomicMin(&ctl->carry_next, s_carry);
-			s_carry = kNone;
-			if (wg != 0 && s_undone)
-				atomicAdd(&ctl->undone_acc, s_undone);
-		}
 		grid_sync(&ctl->sync[1], nwg_eff);
-		// a final pass left with a long list keeps every work-group for its rounds
+		// a launch left with a long list keeps every work-group for its rounds
 		const uint32_t m_all = ld_agent32(&ctl->glist_n);
-		grid_mode = last_chunk != 0 && max_rounds > 0 && nwg_eff > 1u && m_all > grid_min;
+		grid_mode = max_rounds > 0 && nwg_eff > 1u && m_all > grid_min;
 		if (wg != 0 && !grid_mode)
 			return;
 		MKV_PHASE(7);
-		if (t == 0) {
-			s_n = m_all;
-			s_undone += ld_agent32(&ctl->undone_acc);
-		}
-		__syncthreads();
-		if (s_n > (uint32_t)kSortCap)
-			full_tail = true;
-	}
-	if (work_left && full_tail && !last_chunk) {
-		// too many to resolve from LDS: fall back to the complete tail; gather everything
-		__syncthreads();
 		if (t == 0)
-			s_n = 0;
-		__syncthreads();
-		for (uint32_t base = lo16 + t * 16u; base < total && base >= lo16; base += blockDim.x * 16u) {
-			const uint4 v = st4[base >> 4];
-			const uint32_t w[4] = {v.x, v.y, v.z, v.w};
-#pragma unroll
-			for (int k = 0; k < 16; k++) {
-				const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
-				const uint32_t idx = base + (uint32_t)k;
-				if (idx >= lo_idx && idx < total &&
-						(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK))
-					glist[atomicAdd(&s_n, 1u)] = idx;
-			}
-		}
+			s_n = m_all;
 		__syncthreads();
 	}
 	MKV_PHASE(1);
-	if (work_left && !full_tail) {
+	Tv tv;
+	tv.touched = touched;
+	tv.tstamp = tstamp;
+	tv.viol = ctl->viol;
+	tv.flags = &ctl->tflags;
+	tv.vlist_n = &ctl->vlist_n;
+	tv.vlist = ctl->vlist;
+	uint32_t rounds_total = 0;
+	while (work_left) {
 		const uint32_t m = s_n;
-		// The requests that raised a region's barrier must not be carried unresolved: next
-		// pass their chain could meet buckets registered by requests stuck behind them,
-		// for ever.  So every pending request of a region up to that region's barrier index
-		// is replayed exactly here, in canonical order (they are few); the rest is carried.
-		if (OP == OP_CUCKOO && any_bar && m != 0) {
-			uint32_t n2 = 1;
+		if (m == 0)
+			break;
+		uint32_t used = 0, left = 0;
+		bool in_lds = false;
+		uint32_t n2 = 1;
+		if (grid_mode) {
+			uint32_t par = 0;
+			left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin, &s_progress,
+					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total);
+			if (wg != 0)
+				return;
+			grid_mode = false;                     // (later turns of this loop are work-group 0's alone)
+			if (t == 0)
+				s_par += par;
+			__syncthreads();
+		} else {
+			// work list: LDS when it fits, else the global list it was gathered into
+			in_lds = m <= (uint32_t)kSortCap;
+			uint32_t *keys = in_lds ? lkeys : glist;
 			while (n2 < m)
 				n2 <<= 1;
-			for (uint32_t i = t; i < n2; i += blockDim.x)
-				lkeys[i] = i < m ? glist[i] : kNone;
-			__syncthreads();
-			lds_sort(lkeys, n2);
-			replay_regions<OP>(table, g, reqc, state, lkeys, lreg, m, s_bar, true, &s_serial);
-		}
-		MKV_PHASE(2);
-		// Tags stay as they are: the mark pass of the next chunk closes the commits and resets
-		// the unfinished ones (it starts at the carry index; nothing below is scanned again).
-		if (t == 0)
-			s_carry = ld_agent32(&ctl->carry_next);
-		__syncthreads();
-		MKV_PHASE(3);
-	}
-	const uint32_t m = (work_left && full_tail) ? s_n : 0u;
-	uint32_t rounds_used = 0;
-	if (m != 0 && grid_mode) {
-		uint32_t par = 0;
-		const uint32_t left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin,
-				&s_progress, &s_left, &s_dupw, kGridRoundsMax, &rounds_used, &par, phase_ticks + 8);
-		if (wg != 0)
-			return;
-		if (t == 0)
-			s_par += par;
-		MKV_PHASE(4);
-		if (left != 0) {
-			// what the rounds left: into LDS if it fits, then canonical order, one at a time
-			if (t == 0)
-				s_left = 0;
-			__syncthreads();
-			for (uint32_t i = t; i < m; i += blockDim.x) {
-				const uint32_t k = glist[i];
-				if (k != kNone) {
-					const uint32_t at = atomicAdd(&s_left, 1u);
-					if (at < (uint32_t)kSortCap)
-						lkeys[at] = k;
-				}
-			}
-			__syncthreads();
-			const uint32_t nleft = s_left;
-			if (nleft <= (uint32_t)kSortCap) {
-				uint32_t n2 = 1;
-				while (n2 < nleft)
-					n2 <<= 1;
-				for (uint32_t i = nleft + t; i < n2; i += blockDim.x)
+			if (in_lds) {
+				for (uint32_t i = t; i < m; i += blockDim.x)
+					lkeys[i] = glist[i];
+				for (uint32_t i = m + t; i < n2; i += blockDim.x)
 					lkeys[i] = kNone;
-				__syncthreads();
-				lds_sort(lkeys, n2);
-				replay_regions<OP>(table, g, reqc, state, lkeys, lreg, nleft, s_bar, false, &s_serial);
-			} else {
-				replay_pending_scan<OP>(table, g, reqc, state, glist, lkeys, lo_idx, total, &s_serial);
 			}
+			wg_sync();
+			// a handful of requests: the in-order replay is done before a round would be
+			left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin, &s_progress,
+					&s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &used, tv, rounds_total);
 		}
-	} else if (m != 0) {
-		// work list: LDS when it fits, else the global list it was gathered into
-		const bool in_lds = m <= (uint32_t)kSortCap;
-		uint32_t *keys = in_lds ? lkeys : glist;
-		uint32_t n2 = 1;
-		while (n2 < m)
-			n2 <<= 1;
-		if (in_lds) {
-			for (uint32_t i = t; i < m; i += blockDim.x)
-				lkeys[i] = glist[i];
-			for (uint32_t i = m + t; i < n2; i += blockDim.x)
-				lkeys[i] = kNone;
+		rounds_total += used;
+		MKV_PHASE(4);
+		if (left != 0 && ld_agent32(&ctl->tflags) == 0u) {
+			// what the rounds left: canonical order, one request at a time per closed region
+			if (!in_lds) {
+				// (the global list, finished entries marked kNone): into LDS if it fits
+				if (t == 0)
+					s_left = 0;
+				__syncthreads();
+				for (uint32_t i = t; i < m; i += blockDim.x) {
+					const uint32_t k = glist[i];
+					if (k != kNone) {
+						const uint32_t at = atomicAdd(&s_left, 1u);
+						if (at < (uint32_t)kSortCap)
+							lkeys[at] = k;
+					}
+				}
+				__syncthreads();
+				left = s_left;
+				n2 = 1;
+				while (n2 < left)
+					n2 <<= 1;
+				if (left <= (uint32_t)kSortCap)
+					for (uint32_t i = left + t; i < n2; i += blockDim.x)
+						lkeys[i] = kNone;
+				__syncthreads();
+			}
+			if (left <= (uint32_t)kSortCap) {
+				lds_sort(lkeys, n2);
+				replay_regions<OP>(table, g, reqc, state, lkeys, lreg, left, tv, &s_serial);
+			} else {
+				replay_pending_scan<OP>(table, g, reqc, state, glist, lkeys, lo_idx, total, tv, &s_serial);
+			}
 		}
 		wg_sync();
-		// a handful of requests: the in-order replay is done before a round would be
-		const uint32_t left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin,
-				&s_progress, &s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &rounds_used);
-		MKV_PHASE(4);
-		if (left != 0 && in_lds) {
-			// what is left: canonical order, one request at a time
-			lds_sort(lkeys, n2);
-			replay_regions<OP>(table, g, reqc, state, lkeys, lreg, left, s_bar, false, &s_serial);
-		} else if (left != 0) {
-			// too much left for LDS
-			replay_pending_scan<OP>(table, g, reqc, state, glist, lkeys, lo_idx, total, &s_serial);
+		MKV_PHASE(5);
+		const uint32_t flags = ld_agent32(&ctl->tflags);
+		if (flags == 0u)
+			break;                                 // everything is done
+		// -- a chain met an order violation, or needs the touched record ------------------------
+		bool rebuild = (flags & kTvNeed) != 0u;
+		if (flags & kTvViolation) {
+			uint32_t nseeds = ld_agent32(&ctl->vlist_n);
+			nseeds = nseeds < (uint32_t)kViolCap ? nseeds : (uint32_t)kViolCap;
+			// the small case first, one lane per violation: the bucket was used by one later commit,
+			// which nothing depends on (undo_sole_commit).  Two violations may name the same commit
+			// (the lower lane takes it).
+			if (t == 0)
+				s_dflag = 0;
+			uint32_t sj = kNone, sX = 0, sk = kNone;
+			if (t < nseeds) {
+				const uint32_t *sw = reinterpret_cast<const uint32_t *>(ctl->vlist + t);
+				sj = ld_agent32(sw);
+				sX = ld_agent32(sw + 1);
+				const unsigned long long x = ld_agent(&touched[sX]);
+				if ((x >> kTouchedStampShift) == tstamp && touched_idx(x) > sj)
+					sk = touched_idx(x);
+			}
+			if (t < (uint32_t)kViolCap)
+				dB[t] = sk;
+			__syncthreads();
+			if (sk != kNone) {
+				bool first = true;
+				for (uint32_t i = 0; i < t; i++)
+					first &= dB[i] != sk;
+				uint32_t u = 0;
+				if (first && !undo_sole_commit(g, table, state, reqc, undo, chain_logs, touched, tstamp, sj, sX, &u))
+					s_dflag = 1u;
+				if (u)
+					atomicAdd(&s_undone, u);
+			}
+			if (t == 0)
+				s_viols += nseeds;
+			wg_sync();
+			if (s_dflag) {
+				// the general way: take back the later commits that used the buckets the chains stepped
+				// on, and what depends on them; if that list outgrows LDS, the whole region suffix
+				const bool targeted = select_dependents(g, state, reqc, undo, chain_logs, ctl->vlist, nseeds, lo_idx,
+						total, dB, dT, &s_nd, &s_dflag);
+				if (t < kMaxRegions)
+					s_thr[t] = (!targeted && t < g.nregions) ? ld_agent32(&ctl->viol[t]) : kNone;
+				__syncthreads();
+				const uint32_t u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u,
+						1u, nullptr);
+				if (u)
+					atomicAdd(&s_undone, u);
+				rebuild = true;                    // the record names requests that are pending again
+			}
 		}
+		wg_sync();
+		MKV_PHASE(2);
+		// the record is (re)built under a new stamp (the old one names requests that are pending again)
+		if (t == 0) {
+			if (rebuild) {
+				s_tstamp = ctl->tstamp_next;
+				ctl->tstamp_next = s_tstamp + 1ull;
+			} else {
+				s_tstamp = tstamp;
+			}
+			s_n = 0;
+		}
+		if (t < kMaxRegions)
+			atomicExch(&ctl->viol[t], kNone);
+		if (t == 0) {
+			atomicExch(&ctl->tflags, 0u);
+			atomicExch(&ctl->vlist_n, 0u);
+		}
+		__syncthreads();
+		tstamp = s_tstamp;
+		tv.tstamp = tstamp;
+		if (rebuild)
+			build_touched(g, state, reqc, undo, chain_logs, touched, tstamp, lo_idx, total, 0u, 1u);
+		gather_pending(state, glist, &s_n, lo_idx, total, 0u, 1u);
+		wg_sync();
+		MKV_PHASE(3);
 	}
 	__syncthreads();
-	MKV_PHASE(5);
 	if (t < 64) {
-		// statistics shards: one wave sums and clears them
+		// statistics shards: one wave sums them
 		uint32_t c1 = ctl->committed[0][t], c2 = ctl->committed[1][t];      // (cleared by the next mark pass)
 		for (int off = 32; off > 0; off >>= 1) {
 			c1 += __shfl_down(c1, off);
@@ -2057,41 +2433,37 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
 		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + s_serial;
 		ctl->last.undone = (first_chunk ? 0u : ctl->last.undone) + s_undone;
-		ctl->last.tail_rounds = (first_chunk ? 0u : ctl->last.tail_rounds) + rounds_used;
+		ctl->last.tail_rounds = (first_chunk ? 0u : ctl->last.tail_rounds) + rounds_total;
 		const uint32_t fh = ctl->first_hard;
 		ctl->last.first_hard = first_chunk ? fh : (fh < ctl->last.first_hard ? fh : ctl->last.first_hard);
 		ctl->last.overflow = ctl->overflow;
 		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
-		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + ctl->bar_chain;
-		// bit 0: this call met region barriers; bit 1: the 40-bit round stamps are nearly used
-		// up -- the host clears the reservation tables before a later call (ensure_ws)
+		// (the two "barrier" fields of the diagnostics now count: order violations handled, and hard
+		// requests the grid-wide rounds left to the tail)
+		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + s_viols;
+		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->hard_tail;
+		// bit 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
+		// an order violation grows with the square of the pass size); bit 1: the 40-bit round stamps
+		// are nearly used up -- the host clears the reservation tables before a later call
+		// (ensure_ws); bit 2 (sticky): a batch exceeded the workspace and was dropped
 		if (last_chunk && host_flag)
-			*host_flag = ((ctl->last.bar_chain + ctl->bar_chain + ctl->last.bar_class + ctl->bar_class) != 0u ? 1u : 0u) |
+			*host_flag = ((ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u) |
 					(ctl->stamp_base > kStampMax - kStampReserve ? 2u : 0u) |
-					(ctl->overflow ? 4u : (*host_flag & 4u));     // bit 2 is sticky: the host reports it
-		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->bar_class;
-		ctl->bar_chain = 0;
-		ctl->bar_class = 0;
+					(ctl->overflow ? 4u : (*host_flag & 4u));
+		ctl->hard_tail = 0;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
 		ctl->any_tail = 0;
+		ctl->any_hard = 0;
 		ctl->first_hard = kNone;
 		ctl->total = 0;
 		// stamps: rounds 1 and 2, what the tail's rounds took, one spare
-		const unsigned long long st = ctl->stamp_base + 3ull + rounds_used;
+		const unsigned long long st = ctl->stamp_base + 3ull + rounds_total;
 		ctl->stamp_base = st;
 		ctl->next_stamp = st;
+		ctl->carry_lo = kNone;
 	}
-	if (t < kMaxRegions)
-		ctl->barrier[t] = kNone;
-	// The next pass's carry is published LAST.  A helper work-group that only gets to run
-	// now reads the control block while it is being reset: everything above changes towards
-	// "nothing to do" (it leaves), only the carry could widen the range it would scan -- once
-	// it sees the new carry it also sees the rest reset.  (Only work-group 0 comes here.)
-	__syncthreads();
-	if (t == 0)
-		ctl->carry_lo = s_carry;
 }
 
 __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
@@ -2111,6 +2483,10 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
 		ctl->carry_lo = kNone;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
+		ctl->any_hard = 0;
+		ctl->violations = 0;
+		ctl->hard_tail = 0;
+		ctl->tstamp_next = 1;
 		reset_tail_scratch(ctl);
 	}
 	if (t < kMaxRegions)
@@ -2130,6 +2506,7 @@ struct Workspace {
 	int64_t req_cap = 0;
 	unsigned long long *owner[2] = {nullptr, nullptr};
 	unsigned long long *cnt = nullptr;
+	unsigned long long *touched = nullptr;   // per bucket: highest index committed there by the grid-wide rounds
 	uint8_t *state = nullptr;
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
@@ -2159,6 +2536,7 @@ static void free_ws(Workspace *w)
 	for (int i = 0; i < 2; i++)
 		if (w->owner[i]) (void)hipFree(w->owner[i]);
 	if (w->cnt) (void)hipFree(w->cnt);
+	if (w->touched) (void)hipFree(w->touched);
 	if (w->state) (void)hipFree(w->state);
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
@@ -2203,6 +2581,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 			bool ok = hipMemsetAsync(w->owner[0], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->owner[1], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 16, stream) == hipSuccess;
+			ok = ok && hipMemsetAsync(w->touched, 0, w->nbuckets * 8, stream) == hipSuccess;
 			if (!ok)
 				return MKV_EHIP;
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull);
@@ -2225,6 +2604,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	for (int i = 0; i < 2 && ok; i++)
 		ok = ok && hipMalloc(&w->owner[i], nb * 8) == hipSuccess;
 	ok = ok && hipMalloc(&w->cnt, nb * 16) == hipSuccess;     // registrant counts, then the election words
+	ok = ok && hipMalloc(&w->touched, nb * 8) == hipSuccess;
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
@@ -2247,6 +2627,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = ok && hipMemsetAsync(w->owner[0], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->owner[1], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 16, stream) == hipSuccess;
+		ok = ok && hipMemsetAsync(w->touched, 0, nb * 8, stream) == hipSuccess;
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
 					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1));
@@ -2279,10 +2660,10 @@ static int64_t ws_need(const ReqSrc &src, long long hint = 0)
 // K1 alone: touches the requests and the workspace, never the table.
 template <Op OP>
 static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream,
-		uint32_t lo = 0, uint32_t hi = kNone)
+		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
 	hipLaunchKernelGGL((k_mark<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi);
+			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table);
 }
 
 template <Op OP>
@@ -2330,10 +2711,9 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	if (hint <= c)
 		return k;
 	const long long n = (hint + c - 1) / c;
-	// one flush pass takes what the last data chunk carried; with barriers around, a second
-	// one keeps a barrier met in the first from ending up in the single-work-group tail
-	k.flush = barriers_lately ? 2 : 1;
-	k.passes = (n > 250 ? 250 : (int)n) + k.flush;
+	// (every pass finishes its own requests: no trailing flush passes)
+	k.flush = 0;
+	k.passes = n > 250 ? 250 : (int)n;
 	k.step = (uint32_t)c;
 	return k;
 }
@@ -2376,7 +2756,7 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 	for (int c = 0; c < nchunks; c++) {
 		uint32_t lo, hi;
 		chunk_range(c, ck, &lo, &hi);
-		launch_mark<OP>(w, g, src, stream, lo, hi);
+		launch_mark<OP>(w, g, src, stream, table, lo, hi);
 		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1);
 		if (rc != MKV_OK)
 			return rc;
@@ -2393,12 +2773,11 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, tuning().debug_skip,
-			lo, hi);
+			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->cnt, w->reqc, w->state, w->undo, w->chain_logs, 0, lo, hi);
+			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
+			w->cnt, w->touched, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
@@ -2441,8 +2820,8 @@ extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_
 // enqueued on the workspace's side stream right after `fork` (everything already
 // on `stream` is complete before it starts, this cycle's search is not waited
 // for), the rounds follow on `stream` once mark has joined.
-extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_input, int *blk_elem_num,
-		int num_blks, long long size_hint, void *stream)
+extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *table, ielem_t **blk_input,
+		int *blk_elem_num, int num_blks, long long size_hint, void *stream)
 {
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || num_blks <= 0 || num_blks > mkv::kMaxBlocks || !blk_input ||
@@ -2468,9 +2847,9 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, ielem_t **blk_inpu
 	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
 	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
-		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux, lo, hi);
+		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux, nullptr, lo, hi);
 	else
-		mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, w->aux, lo, hi);
+		mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, w->aux, reinterpret_cast<const uint32_t *>(table), lo, hi);
 	if (hipEventRecord(w->ev_join, w->aux) != hipSuccess)
 		return MKV_EHIP;
 	return MKV_OK;
@@ -2550,11 +2929,11 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 		mkv::chunk_range(c, ck, &lo, &hi);
 		if (d.scheme == MKV_SCHEME_2CHOICE) {
 			if (c > 0)
-				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, lo, hi);
+				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
 		} else {
 			if (c > 0)
-				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, lo, hi);
+				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
 		}
 		if (rc != MKV_OK)
@@ -2633,11 +3012,11 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 		mkv::chunk_range(c, ck, &lo, &hi);
 		if (cuckoo) {
 			if (c > 0)
-				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, lo, hi);
+				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
 		} else {
 			if (c > 0)
-				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, lo, hi);
+				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
 		}
 		if (rc != MKV_OK)
