@@ -91,7 +91,8 @@ def parse(argv=None):
     ap.add_argument("--cpu-batches", type=int, default=400,
                     help="batches of the same workload replayed on the CPU oracle (~10 s single-threaded)")
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
-    ap.add_argument("--debug-skip", type=int, default=0, help="diagnostics: mkv_set_tuning('debug_skip')")
+    ap.add_argument("--update-info", action="store_true",
+                    help="diagnostics on stderr: the library's statistics of the last insert of the timed region")
     return ap.parse_args(argv)
 
 
@@ -253,7 +254,6 @@ def main():
                 engine.native.close()
             engine.native = None
         native = engine.native is not None
-    dbg_skip = args.debug_skip
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
     t0 = time.time()
@@ -278,9 +278,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    if dbg_skip:
-        from megakv_amd.lib import load_library
-        load_library().mkv_set_tuning(b"debug_skip", dbg_skip)
     with torch.cuda.stream(run_stream):
         engine.reserve(run_stream)
         # a collective that never completes would hang the box: give the warm-up a deadline
@@ -347,6 +344,9 @@ def main():
 
     n_ops = (1 << args.batch_log2) * args.steps * world
     value = n_ops / elapsed / 1e6
+    if args.update_info and not sharded:
+        print("update info:", engine.idx.last_update_info(run_stream, cycle_insert=True),
+              "tail phases us:", engine.idx.tail_phases_us(run_stream, cycle_insert=True), file=sys.stderr)
 
     # the results of the LAST timed batch, checked like those of the warm-up: every GET of a
     # pre-loaded key must have come back with its own key id in its own place (all ranks)

@@ -243,8 +243,9 @@ void mkv_shard_destroy(mkv_shard_t *e);
  *            "barrier_sticky", "barrier_split", "mark_blocks", "req_cap" (default request
  *            capacity of an update workspace);
  *   sharded: "pack_three_pass";
- *   tests:   "debug_first_stamp", "debug_skip" (breaks results: timing experiments only).
- * Results never depend on them (debug_skip aside); they exist for measurement and tests. */
+ *   tests:   "debug_first_stamp", "debug_skip" (1 / 2: the tail takes the general way / the
+ *            region-suffix fall-back for every order violation of an eviction chain).
+ * Results never depend on them; they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);
 
 const char *mkv_version(void);

@@ -95,8 +95,9 @@ struct Tuning {
 	int calm_factor;        // chunk size multiplier while no region barrier was met lately
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)
 	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)
-	int debug_skip;      // diagnostics only (breaks results): bit0 no table stores, bit1 no undo log,
-	                     // bit2 no owner loads, bit3 no bucket load, bit4 no state store
+	int debug_skip;      // tests only (results unchanged): how the tail deals with an order violation --
+	                     // 0 as designed, 1 always the general way (resolve_violations), 2 always the
+	                     // region-suffix fall-back
 };
 Tuning &tuning();
 

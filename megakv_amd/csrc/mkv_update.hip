@@ -85,6 +85,8 @@ constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state 
 constexpr int kViolCap = 128;       // order violations recorded per turn of the tail (more are met again later)
 constexpr int kDirtyCap = 1024;     // buckets whose later commits a violation drags along (beyond: the whole region suffix)
 constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
+constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
+                                    // launch stays free of scratch memory and calls)
 constexpr uint32_t kGridAll = 1024;
 constexpr uint32_t kGridList = 256;
 
@@ -118,6 +120,7 @@ struct Info {
 // Log of an optimistic eviction chain: every word it overwrote, in order.
 constexpr int kChainLogWords = 14;      // 6 evictions x 2 words, or 5 x 2 + final placement
 constexpr uint32_t kChainLogCap = 1u << 16;
+constexpr uint32_t kTailLanes = 64u * 1024u;    // lanes of the largest tail launch (Tuning::tail_groups <= 64)
 struct ChainLog {
 	uint32_t n;
 	uint32_t word[kChainLogWords];
@@ -1000,6 +1003,7 @@ struct Tv {
 	uint32_t *flags;                     // bit 0: violation recorded; bit 1: record needed
 	uint32_t *vlist_n;                   // violations of this turn: {index of the chain's request, bucket}
 	uint2 *vlist;
+	ChainLog *lane_logs;                 // one log per lane of the tail launch (apply_serial_checked)
 };
 constexpr uint32_t kTvViolation = 1u, kTvNeed = 2u;
 
@@ -1045,7 +1049,7 @@ __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g,
 // back to a bucket it has used, so a read-only walk would not do) and restores it when it
 // has to give up.  0 = done, 1 = order violation, 2 = touched record needed (1, 2: nothing written).
 template <Op OP>
-__device__ __noinline__ int apply_serial_checked(uint32_t *table, const DevGeom &g, const Req &r, uint32_t idx, const Tv &tv)
+__device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGeom &g, const Req &r, uint32_t idx, const Tv &tv)
 {
 	const uint32_t P = r.hash & g.hash_mask;
 	const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
@@ -1056,7 +1060,9 @@ __device__ __noinline__ int apply_serial_checked(uint32_t *table, const DevGeom 
 		atomicOr(tv.flags, kTvNeed);
 		return 2;
 	}
-	uint32_t lw[kChainLogWords], lv[kChainLogWords];
+	// (the log lives in this lane's slot of global memory: local arrays would cost the launch its
+	// scratch-free dispatch)
+	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
 	uint32_t n = 0;
 	uint32_t sig = r.sig, loc = r.loc, b = A;
 	const uint32_t v = r.sig & 7u;          // victim slot: ORIGINAL signature (:360)
@@ -1064,10 +1070,10 @@ __device__ __noinline__ int apply_serial_checked(uint32_t *table, const DevGeom 
 		const uint64_t ws = sig_word(b, v), wl = loc_word(b, v);
 		const uint32_t vsig = ld_agent32(table + ws);
 		const uint32_t vloc = ld_agent32(table + wl);
-		lw[n] = (uint32_t)ws;
-		lv[n++] = vsig;
-		lw[n] = (uint32_t)wl;
-		lv[n++] = vloc;
+		L->word[n] = (uint32_t)ws;
+		L->old[n++] = vsig;
+		L->word[n] = (uint32_t)wl;
+		L->old[n++] = vloc;
 		table[ws] = sig;
 		table[wl] = loc;
 		if (k >= g.max_cuckoo)
@@ -1077,7 +1083,7 @@ __device__ __noinline__ int apply_serial_checked(uint32_t *table, const DevGeom 
 		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
 		if (touched_later(tv, b, idx)) {
 			for (uint32_t i = n; i-- > 0;)
-				table[lw[i]] = lv[i];
+				table[L->word[i]] = L->old[i];
 			report_violation(tv, g, P, idx, b);
 			return 1;
 		}
@@ -1152,7 +1158,7 @@ __device__ __forceinline__ void grid_sync_nth(uint32_t *counter, uint32_t nwg, u
 }
 
 // bitonic sort of n2 (power of two) keys in LDS, ascending
-__device__ void lds_sort(uint32_t *keys, uint32_t n2)
+__device__ __forceinline__ void lds_sort(uint32_t *keys, uint32_t n2)
 {
 	const uint32_t t = threadIdx.x;
 	for (uint32_t k = 2; k <= n2; k <<= 1) {
@@ -1178,7 +1184,7 @@ __device__ void lds_sort(uint32_t *keys, uint32_t n2)
 // stops at the first request whose chain meets an order violation (or needs the touched
 // record): everything from there on stays pending.  Returns the number replayed.
 template <Op OP>
-__device__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
+__device__ __forceinline__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
 		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const Tv &tv, uint32_t *s_count)
 {
 	const uint32_t t = threadIdx.x;
@@ -1227,7 +1233,7 @@ __device__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint
 // entries at a time -- all lanes fetch their entry's hash and touch its buckets (so the
 // replaying lane finds them in L2), lane 0 replays its region's, stopping like replay_regions.
 template <Op OP>
-__device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
+__device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
 		uint32_t *glist, uint32_t *scratch1024, uint32_t lo_idx, uint32_t total, const Tv &tv, uint32_t *s_count)
 {
 	const uint32_t t = threadIdx.x;
@@ -1325,7 +1331,7 @@ __device__ uint32_t replay_pending_scan(uint32_t *table, const DevGeom &g, const
 // the walk saw what the real run will see), and no later request of this pass was COMMITTED
 // on one of them by the grid-wide rounds (touched record; else: order violation, reported)
 // -- the request may run its chain in this round's commit phase.
-__device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
+__device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
 		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv)
 {
 	if (tv.tstamp == 0ull) {
@@ -1370,7 +1376,7 @@ __device__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Re
 // become the round's barrier, so this request is held back anyway; this is the belt to those
 // braces.)  Buckets it owns are written by nobody else in this phase, so the walk reads what
 // the decide phase read.
-__device__ bool chain_still_owned(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
+__device__ __forceinline__ bool chain_still_owned(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
 		uint32_t idx, const unsigned long long *owner, unsigned long long stamp)
 {
 	const unsigned long long mykey = owner_key(stamp, idx);
@@ -1444,7 +1450,7 @@ __device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom
 // in that round -- after which the requests behind it are parallel work again.
 // Returns the number of requests still pending.
 template <Op OP>
-__device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
+__device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
 		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used, const Tv &tv, uint32_t stamp_skip)
@@ -1628,7 +1634,7 @@ __device__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, uns
 // work-group in LDS first.  Four grid-wide meetings per round.  All groups read the
 // same totals after the third and so leave the loop together.
 template <Op OP>
-__device__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
+__device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
 		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip)
@@ -1864,43 +1870,37 @@ __device__ __forceinline__ bool tag_logged(uint32_t st)
 // there, and every bucket of an eviction chain.  atomicMax keeps the highest index; stamps
 // only grow, so entries of earlier passes lose.  Shared by `nwg` work-groups (neighbouring
 // 16-tag groups go to different ones).
-__device__ __noinline__ void build_touched(const DevGeom &g, const uint8_t *state, const uint4 *reqc, const Undo *undo,
+__device__ __forceinline__ void build_touched(const DevGeom &g, const uint8_t *state, const uint4 *reqc, const Undo *undo,
 		const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp, uint32_t lo_idx,
 		uint32_t total, uint32_t wg, uint32_t nwg)
 {
-	const uint32_t t = threadIdx.x;
-	const uint32_t lo16 = lo_idx & ~15u;
-	const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+	// one request per lane and step (most of a pass is committed: every lane has work, and the
+	// atomics -- whose old value is waited for -- of a wave go out together)
 	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	for (uint32_t base = lo16 + (t * nwg + wg) * 16u; base < total && base >= lo16; base += nwg * blockDim.x * 16u) {
-		const uint4 v4 = st4[base >> 4];
-		const uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
-#pragma unroll
-		for (int kk = 0; kk < 16; kk++) {
-			const uint32_t st = (w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu;
-			const uint32_t idx = base + (uint32_t)kk;
-			if (idx < lo_idx || idx >= total || !tag_logged(st))
-				continue;
-			const uint32_t sig = reqw[(size_t)idx * 4u], hash = reqw[(size_t)idx * 4u + 1u];
-			const uint32_t P = hash & g.hash_mask;
-			const uint32_t A = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
-			const unsigned long long key = touched_key(tstamp, idx);
-			const Undo u = undo[idx];
-			touched_enter(touched, P, key);
-			if (st == ST_CHAIN1 || st == ST_CHAIN2) {
-				touched_enter(touched, A, key);
-				const ChainLog *L = &chain_logs[u.word0];
-				const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-				uint32_t last = A;
-				for (uint32_t i = 0; i < n; i++) {
-					const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
-					if (b != last)
-						touched_enter(touched, b, key);
-					last = b;
-				}
-			} else if ((u.word0 >> 4) != P) {
-				touched_enter(touched, A, key);
+	for (uint32_t idx = lo_idx + wg * blockDim.x + threadIdx.x; idx < total && idx >= lo_idx;
+			idx += nwg * blockDim.x) {
+		const uint32_t st = state[idx];
+		if (!tag_logged(st))
+			continue;
+		const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);   // {sig, hash}
+		const Undo u = undo[idx];
+		const uint32_t P = sh.y & g.hash_mask;
+		const uint32_t A = alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask);
+		const unsigned long long key = touched_key(tstamp, idx);
+		touched_enter(touched, P, key);
+		if (st == ST_CHAIN1 || st == ST_CHAIN2) {
+			touched_enter(touched, A, key);
+			const ChainLog *L = &chain_logs[u.word0];
+			const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+			uint32_t last = A;
+			for (uint32_t i = 0; i < n; i++) {
+				const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
+				if (b != last)
+					touched_enter(touched, b, key);
+				last = b;
 			}
+		} else if ((u.word0 >> 4) != P) {
+			touched_enter(touched, A, key);
 		}
 	}
 }
@@ -1911,7 +1911,7 @@ __device__ __noinline__ void build_touched(const DevGeom &g, const uint8_t *stat
 // entries of the touched record cleared -- no sweep over the pass.  One lane per k; the lanes
 // of a turn work on different k (the caller sees to that) and, by the test below, on disjoint
 // buckets.  true = dealt with (or nothing to do any more); false = the general way is needed.
-__device__ __noinline__ bool undo_sole_commit(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
+__device__ __forceinline__ bool undo_sole_commit(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
 		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp,
 		uint32_t j, uint32_t X, uint32_t *undone)
 {
@@ -1965,187 +1965,266 @@ __device__ __noinline__ bool undo_sole_commit(const DevGeom &g, uint32_t *table,
 }
 
 // An order violation {j, X}: the chain of the pending request j steps on bucket X, which
-// a LATER request has already used.  Which commits of the grid-wide rounds have to go?
+// a LATER request has already used.  The general way, when undo_sole_commit does not apply.
+// Which commits of the grid-wide rounds have to go?
 //   (a) every logged commit k > j that has X in its reach (primary, alternate, chain buckets);
 //   (b) for every commit u taken back, every logged commit k' > u that has one of u's buckets
 //       in its reach: it ran there after u, and u will run again.
-// Fixed point over a list of {bucket, index} in LDS, seeded with the violations of this turn;
-// every sweep over the tags tests the commits not yet selected against the entries the sweep
-// before added.  Selected commits get the ST_SELECT flag on their tag (roll_back_from takes
-// them back).  Commits that keep their place ran on their buckets before everything selected
-// there -- or on other buckets -- so they stand.  Returns false when the list overflows: the
-// caller then takes back the whole region suffix (a superset).  One work-group.
-__device__ __noinline__ bool select_dependents(const DevGeom &g, uint8_t *state, const uint4 *reqc, const Undo *undo,
-		const ChainLog *chain_logs, const uint2 *seeds, uint32_t nseeds, uint32_t lo_idx, uint32_t total,
-		uint32_t *dB, uint32_t *dT, uint32_t *s_nd, uint32_t *s_flag)
+// Fixed point over a list of {bucket, index} in LDS (a 4096-bit filter in front of it),
+// seeded with the violations of this turn; every sweep over the requests of the pass -- one
+// request per lane and step, so the loads coalesce -- tests the commits not yet selected
+// against the entries the sweep before added.  Selected commits get the ST_SELECT flag on
+// their tag.  Commits that keep their place ran on their buckets before everything selected
+// there -- or on other buckets -- so they stand.  Then the selected commits are taken back,
+// newest round first, and the touched record is repaired for the buckets of the list only
+// (cleared, then entered again by the commits that stay).  Returns false when the list
+// overflows, with nothing taken back yet: the caller then takes back the whole region suffix
+// (a superset; roll_back_from also clears the flags) and builds the record anew.
+// One work-group.  *undone counts per lane.
+struct Dirty {
+	uint32_t *bucket, *index;    // [kDirtyCap]
+	uint32_t *filter;            // [128] words
+	uint32_t *n, *flag;
+	uint32_t *sel, *nbr;         // [kSelCap] selected commits, [kNbrCap] commits that stay but share a listed bucket
+	uint32_t *nsel, *nnbr;
+};
+constexpr uint32_t kSelCap = 2048, kNbrCap = 4096;
+
+// 0 = bucket b is not on the list (entries [from, nd)); 1 = it is, for a later request only;
+// 2 = it is, and idx lies beyond that entry's index
+__device__ __forceinline__ uint32_t dirty_test(const Dirty &d, uint32_t b, uint32_t idx, uint32_t from, uint32_t nd)
 {
-	const uint32_t t = threadIdx.x;
-	const uint32_t lo16 = lo_idx & ~15u;
+	const uint32_t h = (b * 0x9e3779b1u) >> 20;
+	if (!((d.filter[h >> 5] >> (h & 31u)) & 1u))
+		return 0u;
+	uint32_t r = 0u;
+	for (uint32_t i = from; i < nd; i++)
+		if (d.bucket[i] == b)
+			r |= idx > d.index[i] ? 2u : 1u;
+	return r;
+}
+
+// puts the buckets of the list that commit idx has used back into the touched record
+__device__ __forceinline__ void touched_reenter(const DevGeom &g, const Dirty &d, uint32_t nd, uint32_t st, uint32_t idx, const uint4 *reqc,
+		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp)
+{
 	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	uint4 *st4 = reinterpret_cast<uint4 *>(state);
-	for (uint32_t i = t; i < nseeds; i += blockDim.x) {
-		const uint32_t *sw = reinterpret_cast<const uint32_t *>(seeds + i);
-		dT[i] = ld_agent32(sw);            // {index of the chain's request, bucket it stepped on}
-		dB[i] = ld_agent32(sw + 1);
-	}
-	if (t == 0) {
-		*s_nd = nseeds;
-		*s_flag = 0;
-	}
-	__syncthreads();
-	uint32_t from = 0;
-	for (;;) {
-		const uint32_t nd = *s_nd;
-		__syncthreads();
-		if (from >= nd)
-			return true;
-		for (uint32_t base = lo16 + t * 16u; base < total && base >= lo16; base += blockDim.x * 16u) {
-			const uint4 v4 = st4[base >> 4];
-			uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
-			if (!((v4.x | v4.y | v4.z | v4.w) & 0x06060606u))
-				continue;                           // (no commit tag -- 2, 3, 6, 7 -- among these sixteen)
-			bool changed = false;
-#pragma nounroll
-			for (int kk = 0; kk < 16; kk++) {
-				const uint32_t sh = (uint32_t)(kk & 3) * 8u;
-				const uint32_t st = (w4[kk >> 2] >> sh) & 0xffu;
-				const uint32_t idx = base + (uint32_t)kk;
-				if (idx < lo_idx || idx >= total || !tag_logged(st))
-					continue;                       // (a selected tag carries ST_SELECT: not "logged" any more)
-				const uint32_t sig = reqw[(size_t)idx * 4u], hash = reqw[(size_t)idx * 4u + 1u];
-				uint32_t bk[2 + kChainLogWords / 2];
-				uint32_t nb = 0;
-				bk[nb++] = hash & g.hash_mask;
-				bk[nb++] = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
-				if (st == ST_CHAIN1 || st == ST_CHAIN2) {
-					const ChainLog *L = &chain_logs[undo[idx].word0];
-					const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-					uint32_t last = bk[1];
-					for (uint32_t i = 0; i < n; i++) {
-						const uint32_t b = L->word[i] >> 4;
-						if (b != last && nb < 2u + (uint32_t)kChainLogWords / 2u)
-							bk[nb++] = b;
-						last = b;
-					}
-				}
-				bool hit = false;
-				for (uint32_t i = from; i < nd && !hit; i++)
-					for (uint32_t q = 0; q < nb; q++)
-						hit |= bk[q] == dB[i] && idx > dT[i];
-				if (!hit)
-					continue;
-				w4[kk >> 2] |= (uint32_t)ST_SELECT << sh;
-				changed = true;
-				const uint32_t at = atomicAdd(s_nd, nb);
-				if (at + nb <= (uint32_t)kDirtyCap) {
-					for (uint32_t q = 0; q < nb; q++) {
-						dB[at + q] = bk[q];
-						dT[at + q] = idx;
-					}
-				} else {
-					*s_flag = 1u;
-				}
-			}
-			if (changed)
-				st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+	const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);
+	const uint32_t P = sh.y & g.hash_mask;
+	const uint32_t A = alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask);
+	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
+	const unsigned long long key = touched_key(tstamp, idx);
+	const Undo u = undo[idx];
+	if (dirty_test(d, P, idx, 0u, nd))
+		touched_enter(touched, P, key);
+	if (A != P && (chain || (u.word0 >> 4) != P) && dirty_test(d, A, idx, 0u, nd))
+		touched_enter(touched, A, key);
+	if (chain) {
+		const ChainLog *L = &chain_logs[u.word0];
+		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+		uint32_t last = A;
+		for (uint32_t i = 0; i < n; i++) {
+			const uint32_t b = L->word[i] >> 4;
+			if (b != last && b != P && dirty_test(d, b, idx, 0u, nd))
+				touched_enter(touched, b, key);
+			last = b;
 		}
-		__syncthreads();
-		if (*s_flag)
-			return false;
-		from = nd;
 	}
 }
 
-// Roll back the commits of the grid-wide rounds that are flagged ST_SELECT (select_dependents)
+__device__ __forceinline__ bool resolve_violations(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
+		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp,
+		const uint2 *seeds, uint32_t nseeds, uint32_t lo_idx, uint32_t total, const Dirty &d, uint32_t *undone)
+{
+	const uint32_t t = threadIdx.x;
+	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+	for (uint32_t i = t; i < 128u; i += blockDim.x)
+		d.filter[i] = 0u;
+	if (t == 0) {
+		*d.n = nseeds;
+		*d.flag = 0;
+		*d.nsel = 0;
+		*d.nnbr = 0;
+	}
+	__syncthreads();
+	for (uint32_t i = t; i < nseeds; i += blockDim.x) {
+		const uint32_t *sw = reinterpret_cast<const uint32_t *>(seeds + i);
+		d.index[i] = ld_agent32(sw);        // {index of the chain's request, bucket it stepped on}
+		const uint32_t b = ld_agent32(sw + 1);
+		d.bucket[i] = b;
+		const uint32_t h = (b * 0x9e3779b1u) >> 20;
+		atomicOr(&d.filter[h >> 5], 1u << (h & 31u));
+	}
+	__syncthreads();
+	// -- select: sweeps over the requests of the pass, kBatch of them per lane and step with
+	// their loads issued together
+	constexpr int kBatch = 8;
+	uint32_t from = 0;
+	for (;;) {
+		const uint32_t nd = *d.n;
+		__syncthreads();
+		if (from >= nd)
+			break;
+		for (uint32_t base = lo_idx + t; base < total && base >= lo_idx; base += kBatch * blockDim.x) {
+			uint32_t stq[kBatch];
+			uint2 shq[kBatch];
+#pragma unroll
+			for (int q = 0; q < kBatch; q++) {
+				const uint32_t idx = base + (uint32_t)q * blockDim.x;
+				stq[q] = idx < total ? state[idx] : (uint32_t)ST_DONE;
+			}
+#pragma unroll
+			for (int q = 0; q < kBatch; q++) {
+				const uint32_t idx = base + (uint32_t)q * blockDim.x;
+				shq[q] = tag_logged(stq[q]) ? *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u) : make_uint2(0u, 0u);
+			}
+#pragma unroll
+			for (int q = 0; q < kBatch; q++) {
+				const uint32_t st = stq[q];
+				if (!tag_logged(st))
+					continue;                       // (a selected tag carries ST_SELECT: not "logged" any more)
+				const uint32_t idx = base + (uint32_t)q * blockDim.x;
+				const uint32_t P = shq[q].y & g.hash_mask;
+				const uint32_t A = alt_bucket(shq[q].y, shq[q].x, g.hash_mask, g.blk_mask);
+				const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
+				const ChainLog *L = chain ? &chain_logs[undo[idx].word0] : nullptr;
+				const uint32_t n = chain ? (L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords) : 0u;
+				uint32_t hit = dirty_test(d, P, idx, from, nd) | dirty_test(d, A, idx, from, nd);
+				for (uint32_t i = 0; i < n; i += 2)     // (a bucket's words are logged in pairs, or one at the end)
+					hit |= dirty_test(d, L->word[i] >> 4, idx, from, nd);
+				if (!hit)
+					continue;
+				if (!(hit & 2u)) {
+					// shares a listed bucket but ran there before: it stays, and goes back into the record
+					const uint32_t at = atomicAdd(d.nnbr, 1u);
+					if (at < kNbrCap)
+						d.nbr[at] = idx;
+					continue;
+				}
+				state[idx] = (uint8_t)(st | ST_SELECT);
+				const uint32_t as = atomicAdd(d.nsel, 1u);
+				if (as < kSelCap)
+					d.sel[as] = idx;
+				const uint32_t nb = 2u + (n + 1u) / 2u;
+				const uint32_t at = atomicAdd(d.n, nb);
+				if (at + nb <= (uint32_t)kDirtyCap) {
+					for (uint32_t k = 0; k < nb; k++) {
+						const uint32_t bkt = k == 0 ? P : (k == 1 ? A : L->word[(k - 2u) * 2u] >> 4);
+						d.bucket[at + k] = bkt;
+						d.index[at + k] = idx;
+						const uint32_t h = (bkt * 0x9e3779b1u) >> 20;
+						atomicOr(&d.filter[h >> 5], 1u << (h & 31u));
+					}
+				} else {
+					*d.flag = 1u;
+				}
+			}
+		}
+		__syncthreads();
+		if (*d.flag || *d.nsel > kSelCap)
+			return false;
+		from = nd;
+	}
+	const uint32_t nd = *d.n, nsel = *d.nsel, nnbr = *d.nnbr;
+	// -- take back, newest round first
+	for (int pass = 0; pass < 2; pass++) {
+		const uint32_t tag = (pass == 0 ? ST_ROUND2 : ST_ROUND1) | ST_SELECT;
+		const uint32_t ctag = (pass == 0 ? ST_CHAIN2 : ST_CHAIN1) | ST_SELECT;
+		for (uint32_t i = t; i < nsel; i += blockDim.x) {
+			const uint32_t idx = d.sel[i];
+			const uint32_t st = state[idx];
+			if (st != tag && st != ctag)
+				continue;
+			const Undo u = undo[idx];
+			if (st == ctag) {
+				const ChainLog *L = &chain_logs[u.word0];
+				const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+				for (uint32_t k = n; k-- > 0;)
+					table[L->word[k]] = L->old[k];
+			} else {
+				if (u.word1 != kNoWord)
+					table[u.word1] = u.old1;
+				if (u.word0 != kNoWord)
+					table[u.word0] = u.old0;
+			}
+			state[idx] = ST_TAIL;
+			(*undone)++;
+		}
+		wg_sync();                              // every round-2 undo lands before any round-1 undo
+	}
+	// -- repair the touched record for the buckets of the list: cleared, then entered again by
+	// the commits that stay (those that shared a listed bucket were noted during the sweeps)
+	for (uint32_t i = t; i < nd; i += blockDim.x)
+		atomicExch(&touched[d.bucket[i]], 0ull);
+	wg_sync();
+	if (nnbr <= kNbrCap) {
+		for (uint32_t i = t; i < nnbr; i += blockDim.x) {
+			const uint32_t idx = d.nbr[i];
+			const uint32_t st = state[idx];
+			if (tag_logged(st))
+				touched_reenter(g, d, nd, st, idx, reqc, undo, chain_logs, touched, tstamp);
+		}
+	} else {
+		for (uint32_t idx = lo_idx + t; idx < total && idx >= lo_idx; idx += blockDim.x) {
+			const uint32_t st = state[idx];
+			if (tag_logged(st))
+				touched_reenter(g, d, nd, st, idx, reqc, undo, chain_logs, touched, tstamp);
+		}
+	}
+	wg_sync();
+	return true;
+}
+
+// Roll back the commits of the grid-wide rounds that are flagged ST_SELECT (resolve_violations)
 // or lie at or beyond thr[region of the request] (kNone: none by index in that region), newest
 // round first; the requests become pending again (tag TAIL).  A thread owns the 16 tags it loads; the loads of a step are issued together.
 // `nwg` work-groups share the scan and meet between the two rounds on `sync_counter`.
 // Returns the number this thread rolled back.
-__device__ __noinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
+__device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
 		const Undo *undo, const ChainLog *chain_logs, const uint32_t *thr, uint32_t lo_idx, uint32_t total,
 		uint32_t wg, uint32_t nwg, uint32_t *sync_counter)
 {
-	const uint32_t t = threadIdx.x;
-	const uint32_t lo16 = lo_idx & ~15u;
-	const uint32_t gfirst = lo16 + (t * nwg + wg) * 16u;
-	const uint32_t gstride = nwg * blockDim.x * 16u;
 	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	uint4 *st4 = reinterpret_cast<uint4 *>(state);
 	uint32_t undone = 0;
 	for (int pass = 0; pass < 2; pass++) {
 		const uint32_t tag = pass == 0 ? ST_ROUND2 : ST_ROUND1;
 		const uint32_t ctag = pass == 0 ? ST_CHAIN2 : ST_CHAIN1;
-		for (uint32_t base = gfirst; base < total && base >= lo16; base += gstride) {
-			const uint4 v4 = st4[base >> 4];
-			uint32_t w4[4] = {v4.x, v4.y, v4.z, v4.w};
-			uint32_t need = 0;
-#pragma unroll
-			for (int kk = 0; kk < 16; kk++) {
-				const uint32_t st = (w4[kk >> 2] >> ((kk & 3) * 8)) & 0xffu;
-				const uint32_t idx = base + (uint32_t)kk;
-				if (idx >= lo_idx && idx < total && ((st & 0x7fu) == tag || (st & 0x7fu) == ctag))
-					need |= 1u << kk;
-			}
-			if (!need)
+		for (uint32_t idx = lo_idx + wg * blockDim.x + threadIdx.x; idx < total && idx >= lo_idx;
+				idx += nwg * blockDim.x) {
+			const uint32_t st = state[idx];
+			if ((st & 0x7fu) != tag && (st & 0x7fu) != ctag)
 				continue;
-			// request hash (for the region) and undo record of every candidate, one batch
-			uint32_t hashes[16];
-			Undo us[16];
-#pragma unroll
-			for (int kk = 0; kk < 16; kk++) {
-				hashes[kk] = (need >> kk) & 1u ? reqw[(size_t)(base + (uint32_t)kk) * 4u + 1u] : 0u;
-				if ((need >> kk) & 1u)
-					us[kk] = undo[base + (uint32_t)kk];
-			}
-#pragma unroll
-			for (int kk = 0; kk < 16; kk++)
-				if (((need >> kk) & 1u) && !((w4[kk >> 2] >> ((kk & 3) * 8)) & (uint32_t)ST_SELECT) &&
-						base + (uint32_t)kk < thr[(hashes[kk] & g.hash_mask) >> g.region_shift])
-					need &= ~(1u << kk);
-			if (!need)
-				continue;
-#pragma unroll
-			for (int kk = 0; kk < 16; kk++) {
-				if (!((need >> kk) & 1u))
+			if (!(st & (uint32_t)ST_SELECT)) {
+				const uint32_t hash = reqw[(size_t)idx * 4u + 1u];
+				if (idx < thr[(hash & g.hash_mask) >> g.region_shift])
 					continue;
-				const uint32_t sh = (uint32_t)(kk & 3) * 8u;
-				const uint32_t st = (w4[kk >> 2] >> sh) & 0x7fu;
-				if (st == ctag) {
-					// the whole log record in one batch of loads, then the stores, newest first
-					static_assert(sizeof(ChainLog) == 128, "ChainLog is read as 8 x 16 bytes");
-					const uint4 *lp = reinterpret_cast<const uint4 *>(&chain_logs[us[kk].word0]);
-					uint4 q[8];
-#pragma unroll
-					for (int i = 0; i < 8; i++)
-						q[i] = lp[i];
-					const uint32_t lw[32] = {q[0].x, q[0].y, q[0].z, q[0].w, q[1].x, q[1].y, q[1].z, q[1].w,
-							q[2].x, q[2].y, q[2].z, q[2].w, q[3].x, q[3].y, q[3].z, q[3].w,
-							q[4].x, q[4].y, q[4].z, q[4].w, q[5].x, q[5].y, q[5].z, q[5].w,
-							q[6].x, q[6].y, q[6].z, q[6].w, q[7].x, q[7].y, q[7].z, q[7].w};
-#pragma unroll
-					for (int i = kChainLogWords - 1; i >= 0; i--)
-						if ((uint32_t)i < lw[0])
-							table[lw[1 + i]] = lw[1 + kChainLogWords + i];
-				} else {
-					if (us[kk].word1 != kNoWord)
-						table[us[kk].word1] = us[kk].old1;
-					if (us[kk].word0 != kNoWord)
-						table[us[kk].word0] = us[kk].old0;
-				}
-				w4[kk >> 2] = (w4[kk >> 2] & ~(0xffu << sh)) | ((uint32_t)ST_TAIL << sh);
-				undone++;
 			}
-			st4[base >> 4] = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+			const Undo u = undo[idx];
+			if ((st & 0x7fu) == ctag) {
+				const ChainLog *L = &chain_logs[u.word0];
+				const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+				for (uint32_t k = n; k-- > 0;)
+					table[L->word[k]] = L->old[k];
+			} else {
+				if (u.word1 != kNoWord)
+					table[u.word1] = u.old1;
+				if (u.word0 != kNoWord)
+					table[u.word0] = u.old0;
+			}
+			state[idx] = ST_TAIL;
+			undone++;
 		}
 		if (pass == 0)
 			grid_sync(sync_counter, nwg);   // every round-2 undo lands before any round-1 undo
+		else
+			wg_sync();
 	}
 	return undone;
 }
 
 // Gather the unfinished requests of [lo_idx, total) into list[] (any order), counting in
 // *counter (LDS for one work-group, the control block for several).
-__device__ void gather_pending(const uint8_t *state, uint32_t *list, uint32_t *counter, uint32_t lo_idx,
+__device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *list, uint32_t *counter, uint32_t lo_idx,
 		uint32_t total, uint32_t wg, uint32_t nwg)
 {
 	const uint32_t t = threadIdx.x;
@@ -2180,16 +2259,18 @@ __device__ void gather_pending(const uint8_t *state, uint32_t *list, uint32_t *c
 // then the in-order replay per closed region.  A chain that meets an order violation makes
 // the launch roll back the later commits of that region and take them on as well.
 template <Op OP>
-__global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
+__global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *cnt, unsigned long long *touched, const uint4 *reqc,
 		uint8_t *state, const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds,
-		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min)
+		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min,
+		int dbg_path)
 {
 	__shared__ uint32_t lkeys[kSortCap];
 	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
 	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
-	__shared__ uint32_t dB[kDirtyCap], dT[kDirtyCap];   // select_dependents: {bucket, index} of what is taken back
-	__shared__ uint32_t s_nd, s_dflag;
+	__shared__ uint32_t dB[kDirtyCap], dT[kDirtyCap];   // resolve_violations: {bucket, index} of what is taken back
+	__shared__ uint32_t dF[128];
+	__shared__ uint32_t s_nd, s_dflag, s_nsel, s_nnbr;
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
@@ -2261,6 +2342,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 	tv.flags = &ctl->tflags;
 	tv.vlist_n = &ctl->vlist_n;
 	tv.vlist = ctl->vlist;
+	tv.lane_logs = const_cast<ChainLog *>(chain_logs) + kChainLogCap;
 	uint32_t rounds_total = 0;
 	while (work_left) {
 		const uint32_t m = s_n;
@@ -2337,7 +2419,7 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			break;                                 // everything is done
 		// -- a chain met an order violation, or needs the touched record ------------------------
 		bool rebuild = (flags & kTvNeed) != 0u;
-		if (flags & kTvViolation) {
+		if (OP == OP_CUCKOO && (flags & kTvViolation)) {
 			uint32_t nseeds = ld_agent32(&ctl->vlist_n);
 			nseeds = nseeds < (uint32_t)kViolCap ? nseeds : (uint32_t)kViolCap;
 			// the small case first, one lane per violation: the bucket was used by one later commit,
@@ -2362,7 +2444,9 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 				for (uint32_t i = 0; i < t; i++)
 					first &= dB[i] != sk;
 				uint32_t u = 0;
-				if (first && !undo_sole_commit(g, table, state, reqc, undo, chain_logs, touched, tstamp, sj, sX, &u))
+				// (dbg_path: tests force the general way / the region-suffix fall-back)
+				if (first && (dbg_path != 0 ||
+						!undo_sole_commit(g, table, state, reqc, undo, chain_logs, touched, tstamp, sj, sX, &u)))
 					s_dflag = 1u;
 				if (u)
 					atomicAdd(&s_undone, u);
@@ -2373,16 +2457,29 @@ __global__ __launch_bounds__(1024) void k_tail(Ctl *ctl, DevGeom g, uint32_t *ta
 			if (s_dflag) {
 				// the general way: take back the later commits that used the buckets the chains stepped
 				// on, and what depends on them; if that list outgrows LDS, the whole region suffix
-				const bool targeted = select_dependents(g, state, reqc, undo, chain_logs, ctl->vlist, nseeds, lo_idx,
-						total, dB, dT, &s_nd, &s_dflag);
-				if (t < kMaxRegions)
-					s_thr[t] = (!targeted && t < g.nregions) ? ld_agent32(&ctl->viol[t]) : kNone;
-				__syncthreads();
-				const uint32_t u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u,
-						1u, nullptr);
+				Dirty dd;
+				dd.bucket = dB;
+				dd.index = dT;
+				dd.filter = dF;
+				dd.n = &s_nd;
+				dd.flag = &s_dflag;
+				dd.nbr = lkeys;                    // (the work list is gathered anew after this)
+				dd.sel = lkeys + kNbrCap;
+				dd.nsel = &s_nsel;
+				dd.nnbr = &s_nnbr;
+				static_assert(kNbrCap + kSelCap <= (uint32_t)kSortCap, "lists share the LDS of the work list");
+				uint32_t u = 0;
+				const bool targeted = dbg_path != 2 && resolve_violations(g, table, state, reqc, undo, chain_logs,
+						touched, tstamp, ctl->vlist, nseeds, lo_idx, total, dd, &u);
+				if (!targeted) {
+					if (t < kMaxRegions)
+						s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[t]) : kNone;
+					__syncthreads();
+					u += roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr);
+					rebuild = true;                // the record names requests that are pending again
+				}
 				if (u)
 					atomicAdd(&s_undone, u);
-				rebuild = true;                    // the record names requests that are pending again
 			}
 		}
 		wg_sync();
@@ -2511,7 +2608,8 @@ struct Workspace {
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
 	uint32_t *glist = nullptr;
-	ChainLog *chain_logs = nullptr;
+	ChainLog *chain_logs = nullptr;        // kChainLogCap logs of the grid-wide rounds' chains, then one per lane
+	                                       // of the tail launch (kTailLanes)
 	Ctl *ctl = nullptr;
 	// mkv_cycle only: side stream on which the table-independent mark pass of the
 	// insert overlaps the search kernel, and the fork/join events
@@ -2609,7 +2707,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
 	ok = ok && hipMalloc(&w->glist, (size_t)rc * 4) == hipSuccess;
-	ok = ok && hipMalloc(&w->chain_logs, (size_t)kChainLogCap * sizeof(ChainLog)) == hipSuccess;
+	ok = ok && hipMalloc(&w->chain_logs, ((size_t)kChainLogCap + kTailLanes) * sizeof(ChainLog)) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
 	if (ok) {
 		void *hf = nullptr;
@@ -2776,9 +2874,9 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
-	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(1024), 0, stream, w->ctl, g, table, w->owner[0],
+	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->touched, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min);
+			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, tuning().debug_skip);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

@@ -23,6 +23,7 @@ def _defaults():
     L.mkv_set_tuning(b"tail_groups", 32)
     L.mkv_set_tuning(b"grid_min", 2048)
     L.mkv_set_tuning(b"calm_factor", 4)
+    L.mkv_set_tuning(b"debug_skip", 0)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
@@ -48,6 +49,37 @@ def test_signature_zero_request_turns_hard_behind_others():
     _run(2136, {b"tail_groups": 32, b"grid_min": 0, b"tail_rounds": 48})
 
 
+@pytest.mark.parametrize("path", [0, 1, 2])
+@pytest.mark.parametrize("chunk", [4096, 65536])
+def test_order_violations_of_late_chains(path, chunk):
+    """A well-filled table, many inserts: eviction chains that could not run beside the other
+    requests walk late and step on buckets later requests were already committed on.  Each of
+    the three ways of taking those commits back (a sole commit alone / the commits involved /
+    the region suffix) must leave the oracle's table."""
+    L = load_library()
+    L.mkv_set_tuning(b"debug_skip", path)
+    L.mkv_set_tuning(b"insert_chunk", chunk)
+    L.mkv_set_tuning(b"calm_factor", 1)
+    g = Geometry(mem_p=20)
+    og = ogeom(g)
+    rng = np.random.default_rng(31 + path)
+    exp = random_table(g, rng, 0.75, 1 << 31)
+    idx = HashIndex(g)
+    idx.load_table(exp)
+    violations = late = 0
+    for step in range(4):
+        e = random_requests(g, rng, 50000, 1 << 31, hot=0.02 * step)
+        blocks = split_blocks(e, g, rng, "region")
+        O.insert(og, exp, blocks)
+        idx.insert([dev(b) for b in blocks])
+        info = idx.last_update_info()
+        violations += info["bar_chain"]
+        late += info["bar_class"]
+        got = idx.table_numpy()
+        assert np.array_equal(got, exp), (path, chunk, step, first_diff(got, exp), info)
+    assert late > 0 and violations > 0, (late, violations)     # the paths in question were taken
+
+
 def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
     L = load_library()
@@ -65,7 +97,10 @@ def _run(seed, forced):
     L.mkv_set_tuning(b"tail_groups", int(rng2.choice([1, 2, 5, 32])))
     L.mkv_set_tuning(b"grid_min", int(rng2.choice([0, 0, 64, 2048])))
     L.mkv_set_tuning(b"calm_factor", int(rng2.choice([1, 4])))
-    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk"):   # bisecting aid
+    # how the tail deals with an order violation of a late eviction chain: as designed (a sole later
+    # commit is taken back alone), always the general way, always the region-suffix fall-back
+    L.mkv_set_tuning(b"debug_skip", int(np.random.default_rng(11000 + seed).choice([0, 0, 1, 2])))
+    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"debug_skip"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
             L.mkv_set_tuning(name, int(v))

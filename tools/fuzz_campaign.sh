@@ -10,3 +10,6 @@ run MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=0
 run MKV_FUZZ_TAIL_GROUPS=7 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=16 MKV_FUZZ_INSERT_CHUNK=1024
 run MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=3 MKV_FUZZ_INSERT_CHUNK=2048 MKV_FUZZ_CALM_FACTOR=1
 run MKV_FUZZ_TAIL_GROUPS=2 MKV_FUZZ_TAIL_ROUNDS=0 MKV_FUZZ_INSERT_CHUNK=65536
+# how order violations of late chains are taken back: always the general way / the region suffix
+run MKV_FUZZ_DEBUG_SKIP=1 MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=48
+run MKV_FUZZ_DEBUG_SKIP=2 MKV_FUZZ_TAIL_GROUPS=5 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_INSERT_CHUNK=8192
