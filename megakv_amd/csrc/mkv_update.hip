@@ -83,7 +83,6 @@ constexpr int kTailAloneSpan = 131072; // ... or beyond this many request tags t
 constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
 constexpr int kSortCap = 8192;      // tail requests held in LDS; beyond: state scan
 constexpr int kViolCap = 128;       // order violations recorded per turn of the tail (more are met again later)
-constexpr int kDirtyCap = 1024;     // buckets whose later commits a violation drags along (beyond: the whole region suffix)
 constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
 constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
                                     // launch stays free of scratch memory and calls)
@@ -101,7 +100,10 @@ constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_
 		ST_CHAIN1 = 6, ST_CHAIN2 = 7,   // committed with an eviction chain (log in the chain log)
 		ST_CHAIN_OK = 8,                // tail rounds: chain walked and all its buckets claimed
 		ST_DUPW = 9,                    // tail rounds: holds a duplicate nothing can evict -- a pure loc write
-		ST_DUPW_OK = 10;                // ... and takes part in this round's last-writer election of its bucket
+		ST_DUPW_OK = 10,                // ... and takes part in this round's last-writer election of its bucket
+		ST_DEFER = 11;                  // tail: a commit taken back because an earlier chain needs its bucket sits
+		                                // out one round unregistered (as that round's barrier), so that the chain
+		                                // finds the bucket free
 constexpr int kShards = 64;         // statistics counters are spread over this many words
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
@@ -162,6 +164,7 @@ struct Ctl {
 	unsigned long long tstamp_next;  // next stamp of the touched record (persists across calls)
 	unsigned long long tstamp_cur;   // stamp a tail launch builds its touched record with (set by round 1)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
+	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
 };
@@ -997,40 +1000,54 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 // behind j (roll_back_from).  Tail commits are never logged or undone: the tail only commits
 // a request when nothing pending below it in its region can still run a chain.
 struct Tv {
-	const unsigned long long *touched;   // per bucket: (stamp << kIdxBits) | highest committed index
+	const unsigned long long *touched;   // per bucket: head of the list of the commits that used it
+	const uint2 *tnodes;                 // the lists' nodes
 	unsigned long long tstamp;           // stamp of this pass's record; 0 = not built yet
 	uint32_t *viol;                      // per region: lowest violating index
 	uint32_t *flags;                     // bit 0: violation recorded; bit 1: record needed
 	uint32_t *vlist_n;                   // violations of this turn: {index of the chain's request, bucket}
 	uint2 *vlist;
 	ChainLog *lane_logs;                 // one log per lane of the tail launch (apply_serial_checked)
+	uint32_t *dbg;
 };
 constexpr uint32_t kTvViolation = 1u, kTvNeed = 2u;
 
-// entry of the touched record: stamp | highest committed index | bit 0 "several commits used this bucket"
-constexpr int kTouchedStampShift = kIdxBits + 1;
-__device__ __forceinline__ unsigned long long touched_key(unsigned long long tstamp, uint32_t idx)
+// The touched record: per bucket, the list of the commits of this pass that used it.
+//   head  touched[b] = (stamp << kNodeBits) | (node + 1)     (another stamp: empty)
+//   node  tnodes[n]  = {index of the commit (kNone: taken back since), next node + 1 (0: end)}
+// Node numbers are static: 2 idx for a commit's primary bucket, 2 idx + 1 for its alternate
+// bucket, node_base + 8 slot + i for the i-th further bucket of the chain logged in `slot`.
+constexpr int kNodeBits = 26;
+
+__device__ __forceinline__ void touched_enter(unsigned long long *touched, uint2 *tnodes, unsigned long long tstamp,
+		uint32_t b, uint32_t node, uint32_t idx)
 {
-	return (tstamp << kTouchedStampShift) | ((unsigned long long)idx << 1);
+	const unsigned long long old = atomicExch(&touched[b], (tstamp << kNodeBits) | (unsigned long long)(node + 1u));
+	const uint32_t next = (old >> kNodeBits) == tstamp ? (uint32_t)(old & ((1ull << kNodeBits) - 1ull)) : 0u;
+	tnodes[node] = make_uint2(idx, next);
 }
 
-__device__ __forceinline__ uint32_t touched_idx(unsigned long long x)
+// lowest... any commit later than idx on bucket b (its index), or kNone
+__device__ __forceinline__ uint32_t touched_later_who(const Tv &tv, uint32_t b, uint32_t idx)
 {
-	return (uint32_t)(x >> 1) & ((1u << kIdxBits) - 1u);
-}
-
-__device__ __forceinline__ void touched_enter(unsigned long long *touched, uint32_t b, unsigned long long key)
-{
-	const unsigned long long old = atomicMax(&touched[b], key);
-	if ((old >> kTouchedStampShift) == (key >> kTouchedStampShift) && touched_idx(old) != touched_idx(key))
-		atomicOr(&touched[b], 1ull);       // somebody else of this pass was committed here too
+	const unsigned long long x = ld_agent(&tv.touched[b]);
+	if ((x >> kNodeBits) != tv.tstamp)
+		return kNone;
+	uint32_t n = (uint32_t)(x & ((1ull << kNodeBits) - 1ull));
+	for (int guard = 0; n != 0u && guard < 64; guard++) {
+		const uint32_t *nw = reinterpret_cast<const uint32_t *>(tv.tnodes + (n - 1u));
+		const uint32_t who = ld_agent32(nw);
+		if (who != kNone && who > idx)
+			return who;
+		n = ld_agent32(nw + 1);
+	}
+	return kNone;
 }
 
 // true = a later request of this pass has already been committed on bucket b
 __device__ __forceinline__ bool touched_later(const Tv &tv, uint32_t b, uint32_t idx)
 {
-	const unsigned long long x = ld_agent(&tv.touched[b]);
-	return (x >> kTouchedStampShift) == tv.tstamp && touched_idx(x) > idx;
+	return touched_later_who(tv, b, idx) != kNone;
 }
 
 __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g, uint32_t P, uint32_t idx,
@@ -1323,16 +1340,19 @@ __device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const D
 }
 
 // Tail rounds, decide phase: read-only walk of the eviction chain of a hard request
-// that owns P and A, claiming every further bucket in the round's owner table.  True =
-// nobody registered or claimed any of them this round (a bucket somebody else is on stops
-// the walk -- also a LATER request's: the classification "cannot turn hard" of pending
-// requests counts the free slots and duplicates of the buckets they registered, which no
-// chain may then change under them), the chain never returns to a bucket it already used (so
-// the walk saw what the real run will see), and no later request of this pass was COMMITTED
-// on one of them by the grid-wide rounds (touched record; else: order violation, reported)
-// -- the request may run its chain in this round's commit phase.
+// that owns P and A, claiming every further bucket in the round's owner table.  A bucket an
+// EARLIER pending request is on stops the walk (that request goes first).  From a LATER one
+// the bucket is taken over, and the later request is made a barrier of this round: the
+// classification "cannot turn hard" of pending requests counts the free slots and duplicates
+// of the buckets they registered, which a chain may only change under a request if neither
+// that request nor anything behind it commits in the same round.  True = the walk got
+// through, the chain never returns to a bucket it already used (so the walk saw what the real
+// run will see), and no later request of this pass was COMMITTED on one of the buckets by the
+// grid-wide rounds (touched record; else: order violation, reported) -- the request may run
+// its chain in this round's commit phase if it still owns everything then (chain_still_owned:
+// an earlier chain may come by after it).
 __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
-		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv)
+		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv, uint32_t *rbar)
 {
 	if (tv.tstamp == 0ull) {
 		atomicOr(tv.flags, kTvNeed);        // (the caller treats the request as this round's barrier)
@@ -1349,14 +1369,28 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 			return true;                            // last eviction drops its victim: no further bucket
 		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
 		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);
-		if (nb == P || nb == A)
+		if (nb == P || nb == A) {
+			atomicAdd(tv.dbg + 7, 1u);
 			return false;
+		}
 		for (uint32_t i = 0; i < nseen; i++)
-			if (seen[i] == nb)
+			if (seen[i] == nb) {
+				atomicAdd(tv.dbg + 7, 1u);
 				return false;
+			}
 		const unsigned long long old = atomicMin(&owner[nb], mykey);
-		if ((old >> kIdxBits) == stamp_field && old != mykey)
-			return false;                           // another pending request is on nb
+		if ((old >> kIdxBits) == stamp_field && old != mykey) {
+			if (old < mykey) {
+				atomicAdd(tv.dbg + 3, 1u);
+				return false;                       // an earlier pending request is on nb: it goes first
+			}
+			// A LATER pending request was the lowest on nb: the bucket is taken over (the atomicMin
+			// has done that), and that request becomes a barrier of this round -- neither it nor
+			// anything behind it in the region commits now, whatever it concluded from the bucket's
+			// free slots and duplicates; it finds at commit time that it no longer owns the bucket.
+			atomicAdd(tv.dbg + 0, 1u);
+			atomicMin(&rbar[P >> g.region_shift], (uint32_t)(old & ((1ull << kIdxBits) - 1ull)));
+		}
 		// a later request of this pass was committed on nb by the grid-wide rounds: order violation
 		if (touched_later(tv, nb, idx)) {
 			report_violation(tv, g, P, idx, nb);
@@ -1372,10 +1406,9 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 }
 
 // Commit phase: does the request tagged CHAIN_OK still own P, A and every bucket of the walk?
-// (An earlier chain that came by after this request's claim has lowered the entry -- and has
-// become the round's barrier, so this request is held back anyway; this is the belt to those
-// braces.)  Buckets it owns are written by nobody else in this phase, so the walk reads what
-// the decide phase read.
+// (An earlier chain that came by after this request's claim has taken the bucket over.)
+// Buckets it owns are written by nobody else in this phase, so the walk reads what the decide
+// phase read.
 __device__ __forceinline__ bool chain_still_owned(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
 		uint32_t idx, const unsigned long long *owner, unsigned long long stamp)
 {
@@ -1481,10 +1514,11 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint4 rc = live ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
-			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), live);
+			const bool reg = live && state[idx] != ST_DEFER;      // (a deferred request sits this round out)
+			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), reg);
 			if (OP != OP_DELETE) {
-				bump_wave(cnt, P, stamp, A == P, live);
-				bump_wave(cnt, A, stamp, true, live && A != P);
+				bump_wave(cnt, P, stamp, A == P, reg);
+				bump_wave(cnt, A, stamp, true, reg && A != P);
 				if (live)
 					atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
@@ -1500,6 +1534,11 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				const uint32_t P = rc.y & g.hash_mask;
 				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 				const uint32_t region = P >> g.region_shift;
+				if (state[idx] == ST_DEFER) {
+					atomicMin(&s_rbar[region], idx);        // not registered: nothing of its region passes it
+					state[idx] = ST_TAIL;                   // (back in line next round)
+					continue;
+				}
 				if (state[idx] >= ST_DUPW)
 					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
@@ -1534,11 +1573,15 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
 				}
 				bool bad = clean ? room == 0u : room < 1u + others;
+				if (bad && !clean)
+					atomicAdd(&ctl->dbg[2], 1u);
 				if (bad && clean) {
 					// hard right now: it may still run this round if its chain is all its own
-					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv)) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar)) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
+					} else {
+						atomicAdd(&ctl->dbg[1], 1u);
 					}
 				}
 				if (bad)
@@ -1614,8 +1657,12 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 		wg_sync();
 		const uint32_t progress = *s_progress;
 		left = *s_left;
-		if (t == 0)
+		if (t == 0) {
 			*s_par += progress;
+			ctl->dbg[5] += progress + left;
+			ctl->dbg[6] += 1u;
+			ctl->dbg[4] += progress;
+		}
 		__syncthreads();
 		// a round that resolves less than the one-at-a-time replay would in its time
 		// (duplicates of one key, chains in a row) is not worth another
@@ -1669,10 +1716,11 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint4 rc = live ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
-			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), live);
+			const bool reg = live && state[idx] != ST_DEFER;      // (a deferred request sits this round out)
+			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), reg);
 			if (OP != OP_DELETE) {
-				bump_wave(cnt, P, stamp, A == P, live);
-				bump_wave(cnt, A, stamp, true, live && A != P);
+				bump_wave(cnt, P, stamp, A == P, reg);
+				bump_wave(cnt, A, stamp, true, reg && A != P);
 				if (live)
 					atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
@@ -1693,6 +1741,11 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 				const uint32_t P = rc.y & g.hash_mask;
 				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 				const uint32_t region = P >> g.region_shift;
+				if (state[idx] == ST_DEFER) {
+					atomicMin(&s_rbar[region], idx);        // not registered: nothing of its region passes it
+					state[idx] = ST_TAIL;                   // (back in line next round)
+					continue;
+				}
 				if (state[idx] >= ST_DUPW)
 					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
@@ -1728,7 +1781,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 				}
 				bool bad = clean ? room == 0u : room < 1u + others;
 				if (bad && clean) {
-					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv)) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar)) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
 					}
@@ -1871,11 +1924,11 @@ __device__ __forceinline__ bool tag_logged(uint32_t st)
 // only grow, so entries of earlier passes lose.  Shared by `nwg` work-groups (neighbouring
 // 16-tag groups go to different ones).
 __device__ __forceinline__ void build_touched(const DevGeom &g, const uint8_t *state, const uint4 *reqc, const Undo *undo,
-		const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp, uint32_t lo_idx,
-		uint32_t total, uint32_t wg, uint32_t nwg)
+		const ChainLog *chain_logs, unsigned long long *touched, uint2 *tnodes, uint32_t node_base,
+		unsigned long long tstamp, uint32_t lo_idx, uint32_t total, uint32_t wg, uint32_t nwg)
 {
 	// one request per lane and step (most of a pass is committed: every lane has work, and the
-	// atomics -- whose old value is waited for -- of a wave go out together)
+	// exchanges -- whose old value is waited for -- of a wave go out together)
 	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
 	for (uint32_t idx = lo_idx + wg * blockDim.x + threadIdx.x; idx < total && idx >= lo_idx;
 			idx += nwg * blockDim.x) {
@@ -1886,296 +1939,117 @@ __device__ __forceinline__ void build_touched(const DevGeom &g, const uint8_t *s
 		const Undo u = undo[idx];
 		const uint32_t P = sh.y & g.hash_mask;
 		const uint32_t A = alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask);
-		const unsigned long long key = touched_key(tstamp, idx);
-		touched_enter(touched, P, key);
+		touched_enter(touched, tnodes, tstamp, P, 2u * idx, idx);
 		if (st == ST_CHAIN1 || st == ST_CHAIN2) {
-			touched_enter(touched, A, key);
+			if (A != P)
+				touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
 			const ChainLog *L = &chain_logs[u.word0];
 			const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-			uint32_t last = A;
+			uint32_t last = A, k = 0;
 			for (uint32_t i = 0; i < n; i++) {
 				const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
-				if (b != last)
-					touched_enter(touched, b, key);
+				if (b != last && b != P && b != A && k < 8u)
+					touched_enter(touched, tnodes, tstamp, b, node_base + 8u * u.word0 + k++, idx);
 				last = b;
 			}
 		} else if ((u.word0 >> 4) != P) {
-			touched_enter(touched, A, key);
+			touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
 		}
 	}
-}
-
-// The usual order violation is small: the chain of a pending request j steps on a bucket
-// that exactly ONE later commit k has used, and nothing was committed after k on any bucket
-// of k's reach.  Then k alone is taken back: its words restored, its tag back to pending, its
-// entries of the touched record cleared -- no sweep over the pass.  One lane per k; the lanes
-// of a turn work on different k (the caller sees to that) and, by the test below, on disjoint
-// buckets.  true = dealt with (or nothing to do any more); false = the general way is needed.
-__device__ __forceinline__ bool undo_sole_commit(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
-		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp,
-		uint32_t j, uint32_t X, uint32_t *undone)
-{
-	const unsigned long long x = ld_agent(&touched[X]);
-	if ((x >> kTouchedStampShift) != tstamp || touched_idx(x) <= j)
-		return true;                        // already cleared by another undo of this turn: the chain walks again
-	if (x & 1ull)
-		return false;                       // several commits used X
-	const uint32_t k = touched_idx(x);
-	const uint32_t st = state[k];
-	if (!tag_logged(st))
-		return false;                       // (not expected: the record names commits only)
-	const uint4 rc = reqc[k];
-	const uint32_t P = rc.y & g.hash_mask;
-	const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
-	const Undo u = undo[k];
-	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
-	const ChainLog *L = chain ? &chain_logs[u.word0] : nullptr;
-	const uint32_t n = chain ? (L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords) : 0u;
-	const unsigned long long mine = touched_key(tstamp, k);
-	const bool usedA = chain || (u.word0 >> 4) != P;
-	// every bucket k used must name k alone; the alternate bucket, if k did not use it, no later commit
-	if (ld_agent(&touched[P]) != mine)
-		return false;
-	if (A != P) {
-		const unsigned long long y = ld_agent(&touched[A]);
-		if (usedA ? y != mine : ((y >> kTouchedStampShift) == tstamp && touched_idx(y) > k))
-			return false;
-	}
-	for (uint32_t i = 0; i < n; i++)
-		if (ld_agent(&touched[L->word[i] >> 4]) != mine)
-			return false;
-	// take it back (newest store first)
-	if (chain) {
-		for (uint32_t i = n; i-- > 0;)
-			table[L->word[i]] = L->old[i];
-	} else {
-		if (u.word1 != kNoWord)
-			table[u.word1] = u.old1;
-		if (u.word0 != kNoWord)
-			table[u.word0] = u.old0;
-	}
-	state[k] = ST_TAIL;
-	atomicExch(&touched[P], 0ull);
-	if (usedA && A != P)
-		atomicExch(&touched[A], 0ull);
-	for (uint32_t i = 0; i < n; i++)
-		atomicExch(&touched[L->word[i] >> 4], 0ull);
-	(*undone)++;
-	return true;
 }
 
 // An order violation {j, X}: the chain of the pending request j steps on bucket X, which
-// a LATER request has already used.  The general way, when undo_sole_commit does not apply.
-// Which commits of the grid-wide rounds have to go?
-//   (a) every logged commit k > j that has X in its reach (primary, alternate, chain buckets);
-//   (b) for every commit u taken back, every logged commit k' > u that has one of u's buckets
-//       in its reach: it ran there after u, and u will run again.
-// Fixed point over a list of {bucket, index} in LDS (a 4096-bit filter in front of it),
-// seeded with the violations of this turn; every sweep over the requests of the pass -- one
-// request per lane and step, so the loads coalesce -- tests the commits not yet selected
-// against the entries the sweep before added.  Selected commits get the ST_SELECT flag on
-// their tag.  Commits that keep their place ran on their buckets before everything selected
-// there -- or on other buckets -- so they stand.  Then the selected commits are taken back,
-// newest round first, and the touched record is repaired for the buckets of the list only
-// (cleared, then entered again by the commits that stay).  Returns false when the list
-// overflows, with nothing taken back yet: the caller then takes back the whole region suffix
-// (a superset; roll_back_from also clears the flags) and builds the record anew.
-// One work-group.  *undone counts per lane.
-struct Dirty {
-	uint32_t *bucket, *index;    // [kDirtyCap]
-	uint32_t *filter;            // [128] words
-	uint32_t *n, *flag;
-	uint32_t *sel, *nbr;         // [kSelCap] selected commits, [kNbrCap] commits that stay but share a listed bucket
-	uint32_t *nsel, *nnbr;
-};
-constexpr uint32_t kSelCap = 2048, kNbrCap = 4096;
+// a LATER commit of the grid-wide rounds has used.  What has to go:
+//   (a) every logged commit k > j on the list of X;
+//   (b) for every commit u taken back, every logged commit k' > u on the list of one of the
+//       buckets of u's reach (primary, alternate -- used or not: u will run again and may need
+//       it --, chain buckets): it ran there after u.
+// Commits that keep their place ran on their buckets before everything taken back there -- or
+// on other buckets -- so they stand.  One lane per violation walks the lists (they are short),
+// with a stack of {bucket, index} in LDS; a commit is selected by flagging its tag ST_SELECT
+// (a plain byte store: two lanes selecting the same commit do no harm) and noting it in the
+// list `sel`.  Returns false if its stack or the list overflowed (the caller then takes back
+// the whole region suffix).  Nothing is written to the table here.
+constexpr uint32_t kSelCap = 2048, kLaneStack = 24;
 
-// 0 = bucket b is not on the list (entries [from, nd)); 1 = it is, for a later request only;
-// 2 = it is, and idx lies beyond that entry's index
-__device__ __forceinline__ uint32_t dirty_test(const Dirty &d, uint32_t b, uint32_t idx, uint32_t from, uint32_t nd)
+__device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, const uint4 *reqc, const Undo *undo,
+		const ChainLog *chain_logs, const Tv &tv, uint32_t j, uint32_t X, uint2 *stack, uint32_t *sel,
+		uint32_t *nsel)
 {
-	const uint32_t h = (b * 0x9e3779b1u) >> 20;
-	if (!((d.filter[h >> 5] >> (h & 31u)) & 1u))
-		return 0u;
-	uint32_t r = 0u;
-	for (uint32_t i = from; i < nd; i++)
-		if (d.bucket[i] == b)
-			r |= idx > d.index[i] ? 2u : 1u;
-	return r;
-}
-
-// puts the buckets of the list that commit idx has used back into the touched record
-__device__ __forceinline__ void touched_reenter(const DevGeom &g, const Dirty &d, uint32_t nd, uint32_t st, uint32_t idx, const uint4 *reqc,
-		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp)
-{
-	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);
-	const uint32_t P = sh.y & g.hash_mask;
-	const uint32_t A = alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask);
-	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
-	const unsigned long long key = touched_key(tstamp, idx);
-	const Undo u = undo[idx];
-	if (dirty_test(d, P, idx, 0u, nd))
-		touched_enter(touched, P, key);
-	if (A != P && (chain || (u.word0 >> 4) != P) && dirty_test(d, A, idx, 0u, nd))
-		touched_enter(touched, A, key);
-	if (chain) {
-		const ChainLog *L = &chain_logs[u.word0];
-		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-		uint32_t last = A;
-		for (uint32_t i = 0; i < n; i++) {
-			const uint32_t b = L->word[i] >> 4;
-			if (b != last && b != P && dirty_test(d, b, idx, 0u, nd))
-				touched_enter(touched, b, key);
-			last = b;
-		}
-	}
-}
-
-__device__ __forceinline__ bool resolve_violations(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
-		const Undo *undo, const ChainLog *chain_logs, unsigned long long *touched, unsigned long long tstamp,
-		const uint2 *seeds, uint32_t nseeds, uint32_t lo_idx, uint32_t total, const Dirty &d, uint32_t *undone)
-{
-	const uint32_t t = threadIdx.x;
-	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	for (uint32_t i = t; i < 128u; i += blockDim.x)
-		d.filter[i] = 0u;
-	if (t == 0) {
-		*d.n = nseeds;
-		*d.flag = 0;
-		*d.nsel = 0;
-		*d.nnbr = 0;
-	}
-	__syncthreads();
-	for (uint32_t i = t; i < nseeds; i += blockDim.x) {
-		const uint32_t *sw = reinterpret_cast<const uint32_t *>(seeds + i);
-		d.index[i] = ld_agent32(sw);        // {index of the chain's request, bucket it stepped on}
-		const uint32_t b = ld_agent32(sw + 1);
-		d.bucket[i] = b;
-		const uint32_t h = (b * 0x9e3779b1u) >> 20;
-		atomicOr(&d.filter[h >> 5], 1u << (h & 31u));
-	}
-	__syncthreads();
-	// -- select: sweeps over the requests of the pass, kBatch of them per lane and step with
-	// their loads issued together
-	constexpr int kBatch = 8;
-	uint32_t from = 0;
-	for (;;) {
-		const uint32_t nd = *d.n;
-		__syncthreads();
-		if (from >= nd)
-			break;
-		for (uint32_t base = lo_idx + t; base < total && base >= lo_idx; base += kBatch * blockDim.x) {
-			uint32_t stq[kBatch];
-			uint2 shq[kBatch];
-#pragma unroll
-			for (int q = 0; q < kBatch; q++) {
-				const uint32_t idx = base + (uint32_t)q * blockDim.x;
-				stq[q] = idx < total ? state[idx] : (uint32_t)ST_DONE;
-			}
-#pragma unroll
-			for (int q = 0; q < kBatch; q++) {
-				const uint32_t idx = base + (uint32_t)q * blockDim.x;
-				shq[q] = tag_logged(stq[q]) ? *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u) : make_uint2(0u, 0u);
-			}
-#pragma unroll
-			for (int q = 0; q < kBatch; q++) {
-				const uint32_t st = stq[q];
-				if (!tag_logged(st))
-					continue;                       // (a selected tag carries ST_SELECT: not "logged" any more)
-				const uint32_t idx = base + (uint32_t)q * blockDim.x;
-				const uint32_t P = shq[q].y & g.hash_mask;
-				const uint32_t A = alt_bucket(shq[q].y, shq[q].x, g.hash_mask, g.blk_mask);
-				const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
-				const ChainLog *L = chain ? &chain_logs[undo[idx].word0] : nullptr;
-				const uint32_t n = chain ? (L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords) : 0u;
-				uint32_t hit = dirty_test(d, P, idx, from, nd) | dirty_test(d, A, idx, from, nd);
-				for (uint32_t i = 0; i < n; i += 2)     // (a bucket's words are logged in pairs, or one at the end)
-					hit |= dirty_test(d, L->word[i] >> 4, idx, from, nd);
-				if (!hit)
-					continue;
-				if (!(hit & 2u)) {
-					// shares a listed bucket but ran there before: it stays, and goes back into the record
-					const uint32_t at = atomicAdd(d.nnbr, 1u);
-					if (at < kNbrCap)
-						d.nbr[at] = idx;
-					continue;
-				}
-				state[idx] = (uint8_t)(st | ST_SELECT);
-				const uint32_t as = atomicAdd(d.nsel, 1u);
-				if (as < kSelCap)
-					d.sel[as] = idx;
-				const uint32_t nb = 2u + (n + 1u) / 2u;
-				const uint32_t at = atomicAdd(d.n, nb);
-				if (at + nb <= (uint32_t)kDirtyCap) {
-					for (uint32_t k = 0; k < nb; k++) {
-						const uint32_t bkt = k == 0 ? P : (k == 1 ? A : L->word[(k - 2u) * 2u] >> 4);
-						d.bucket[at + k] = bkt;
-						d.index[at + k] = idx;
-						const uint32_t h = (bkt * 0x9e3779b1u) >> 20;
-						atomicOr(&d.filter[h >> 5], 1u << (h & 31u));
-					}
-				} else {
-					*d.flag = 1u;
-				}
-			}
-		}
-		__syncthreads();
-		if (*d.flag || *d.nsel > kSelCap)
-			return false;
-		from = nd;
-	}
-	const uint32_t nd = *d.n, nsel = *d.nsel, nnbr = *d.nnbr;
-	// -- take back, newest round first
-	for (int pass = 0; pass < 2; pass++) {
-		const uint32_t tag = (pass == 0 ? ST_ROUND2 : ST_ROUND1) | ST_SELECT;
-		const uint32_t ctag = (pass == 0 ? ST_CHAIN2 : ST_CHAIN1) | ST_SELECT;
-		for (uint32_t i = t; i < nsel; i += blockDim.x) {
-			const uint32_t idx = d.sel[i];
-			const uint32_t st = state[idx];
-			if (st != tag && st != ctag)
+	uint32_t sp = 0;
+	stack[sp++] = make_uint2(X, j);
+	bool ok = true;
+	while (sp != 0u) {
+		const uint2 e = stack[--sp];
+		const unsigned long long x = ld_agent(&tv.touched[e.x]);
+		if ((x >> kNodeBits) != tv.tstamp)
+			continue;
+		uint32_t n = (uint32_t)(x & ((1ull << kNodeBits) - 1ull));
+		for (int guard = 0; n != 0u && guard < 64; guard++) {
+			const uint32_t *nw = reinterpret_cast<const uint32_t *>(tv.tnodes + (n - 1u));
+			const uint32_t u = ld_agent32(nw);
+			n = ld_agent32(nw + 1);
+			if (u == kNone || u <= e.y)
 				continue;
-			const Undo u = undo[idx];
-			if (st == ctag) {
-				const ChainLog *L = &chain_logs[u.word0];
-				const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-				for (uint32_t k = n; k-- > 0;)
-					table[L->word[k]] = L->old[k];
-			} else {
-				if (u.word1 != kNoWord)
-					table[u.word1] = u.old1;
-				if (u.word0 != kNoWord)
-					table[u.word0] = u.old0;
+			const uint32_t st = state[u];
+			if (!tag_logged(st))
+				continue;                           // selected already (by this lane or another), or no commit
+			state[u] = (uint8_t)(st | ST_SELECT);
+			const uint32_t at = atomicAdd(nsel, 1u);
+			if (at < kSelCap)
+				sel[at] = u;
+			else
+				ok = false;
+			const uint4 rc = reqc[u];
+			const uint32_t P = rc.y & g.hash_mask;
+			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
+			const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
+			const ChainLog *L = chain ? &chain_logs[undo[u].word0] : nullptr;
+			const uint32_t nl = chain ? (L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords) : 0u;
+			if (sp + 2u + (nl + 1u) / 2u > kLaneStack) {
+				ok = false;
+				continue;
 			}
-			state[idx] = ST_TAIL;
-			(*undone)++;
-		}
-		wg_sync();                              // every round-2 undo lands before any round-1 undo
-	}
-	// -- repair the touched record for the buckets of the list: cleared, then entered again by
-	// the commits that stay (those that shared a listed bucket were noted during the sweeps)
-	for (uint32_t i = t; i < nd; i += blockDim.x)
-		atomicExch(&touched[d.bucket[i]], 0ull);
-	wg_sync();
-	if (nnbr <= kNbrCap) {
-		for (uint32_t i = t; i < nnbr; i += blockDim.x) {
-			const uint32_t idx = d.nbr[i];
-			const uint32_t st = state[idx];
-			if (tag_logged(st))
-				touched_reenter(g, d, nd, st, idx, reqc, undo, chain_logs, touched, tstamp);
-		}
-	} else {
-		for (uint32_t idx = lo_idx + t; idx < total && idx >= lo_idx; idx += blockDim.x) {
-			const uint32_t st = state[idx];
-			if (tag_logged(st))
-				touched_reenter(g, d, nd, st, idx, reqc, undo, chain_logs, touched, tstamp);
+			stack[sp++] = make_uint2(P, u);
+			if (A != P)
+				stack[sp++] = make_uint2(A, u);
+			uint32_t last = A;
+			for (uint32_t i = 0; i < nl; i++) {
+				const uint32_t b = L->word[i] >> 4;
+				if (b != last && b != P && b != A)
+					stack[sp++] = make_uint2(b, u);
+				last = b;
+			}
 		}
 	}
-	wg_sync();
-	return true;
+	return ok;
 }
 
-// Roll back the commits of the grid-wide rounds that are flagged ST_SELECT (resolve_violations)
+// takes the selected commit u (tag already checked) back: its words restored, its nodes of the
+// touched record marked dead, its tag ST_DEFER (pending, sitting out one round)
+__device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
+		const Undo *undo, const ChainLog *chain_logs, uint2 *tnodes, uint32_t node_base, uint32_t u, bool chain)
+{
+	const Undo ur = undo[u];
+	if (chain) {
+		const ChainLog *L = &chain_logs[ur.word0];
+		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+		for (uint32_t k = n; k-- > 0;)
+			table[L->word[k]] = L->old[k];
+		for (uint32_t k = 0; k < 8u; k++)
+			tnodes[node_base + 8u * ur.word0 + k].x = kNone;   // (nodes it never entered are in no list)
+	} else {
+		if (ur.word1 != kNoWord)
+			table[ur.word1] = ur.old1;
+		if (ur.word0 != kNoWord)
+			table[ur.word0] = ur.old0;
+	}
+	tnodes[2u * u].x = kNone;
+	tnodes[2u * u + 1u].x = kNone;
+	state[u] = ST_DEFER;
+}
+
+// Roll back the commits of the grid-wide rounds that are flagged ST_SELECT (select_from)
 // or lie at or beyond thr[region of the request] (kNone: none by index in that region), newest
 // round first; the requests become pending again (tag TAIL).  A thread owns the 16 tags it loads; the loads of a step are issued together.
 // `nwg` work-groups share the scan and meet between the two rounds on `sync_counter`.
@@ -2260,17 +2134,16 @@ __device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *l
 // the launch roll back the later commits of that region and take them on as well.
 template <Op OP>
 __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
-		unsigned long long *owner, unsigned long long *cnt, unsigned long long *touched, const uint4 *reqc,
-		uint8_t *state, const Undo *undo, const ChainLog *chain_logs, uint32_t *glist, int max_rounds,
+		unsigned long long *owner, unsigned long long *cnt, unsigned long long *touched, uint2 *tnodes,
+		uint32_t node_base, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
+		uint32_t *glist, int max_rounds,
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min,
 		int dbg_path)
 {
 	__shared__ uint32_t lkeys[kSortCap];
 	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
 	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
-	__shared__ uint32_t dB[kDirtyCap], dT[kDirtyCap];   // resolve_violations: {bucket, index} of what is taken back
-	__shared__ uint32_t dF[128];
-	__shared__ uint32_t s_nd, s_dflag, s_nsel, s_nnbr;
+	__shared__ uint32_t s_dflag, s_nsel;
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
@@ -2318,7 +2191,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		// hard requests were left to the tail: their chains will be checked against the touched record
 		if (any_hard) {
 			tstamp = ctl->tstamp_cur;
-			build_touched(g, state, reqc, undo, chain_logs, touched, tstamp, lo_idx, total, wg, nwg_eff);
+			build_touched(g, state, reqc, undo, chain_logs, touched, tnodes, node_base, tstamp, lo_idx, total, wg,
+					nwg_eff);
 		}
 		MKV_PHASE(0);
 		gather_pending(state, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff);
@@ -2337,12 +2211,14 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	MKV_PHASE(1);
 	Tv tv;
 	tv.touched = touched;
+	tv.tnodes = tnodes;
 	tv.tstamp = tstamp;
 	tv.viol = ctl->viol;
 	tv.flags = &ctl->tflags;
 	tv.vlist_n = &ctl->vlist_n;
 	tv.vlist = ctl->vlist;
 	tv.lane_logs = const_cast<ChainLog *>(chain_logs) + kChainLogCap;
+	tv.dbg = ctl->dbg;
 	uint32_t rounds_total = 0;
 	while (work_left) {
 		const uint32_t m = s_n;
@@ -2422,65 +2298,52 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		if (OP == OP_CUCKOO && (flags & kTvViolation)) {
 			uint32_t nseeds = ld_agent32(&ctl->vlist_n);
 			nseeds = nseeds < (uint32_t)kViolCap ? nseeds : (uint32_t)kViolCap;
-			// the small case first, one lane per violation: the bucket was used by one later commit,
-			// which nothing depends on (undo_sole_commit).  Two violations may name the same commit
-			// (the lower lane takes it).
-			if (t == 0)
-				s_dflag = 0;
-			uint32_t sj = kNone, sX = 0, sk = kNone;
-			if (t < nseeds) {
-				const uint32_t *sw = reinterpret_cast<const uint32_t *>(ctl->vlist + t);
-				sj = ld_agent32(sw);
-				sX = ld_agent32(sw + 1);
-				const unsigned long long x = ld_agent(&touched[sX]);
-				if ((x >> kTouchedStampShift) == tstamp && touched_idx(x) > sj)
-					sk = touched_idx(x);
-			}
-			if (t < (uint32_t)kViolCap)
-				dB[t] = sk;
-			__syncthreads();
-			if (sk != kNone) {
-				bool first = true;
-				for (uint32_t i = 0; i < t; i++)
-					first &= dB[i] != sk;
-				uint32_t u = 0;
-				// (dbg_path: tests force the general way / the region-suffix fall-back)
-				if (first && (dbg_path != 0 ||
-						!undo_sole_commit(g, table, state, reqc, undo, chain_logs, touched, tstamp, sj, sX, &u)))
-					s_dflag = 1u;
-				if (u)
-					atomicAdd(&s_undone, u);
-			}
-			if (t == 0)
+			// one lane per violation selects what has to go (select_from); the work list's LDS holds
+			// the lanes' stacks and the list of what they selected (it is gathered anew afterwards)
+			static_assert((uint32_t)kViolCap * kLaneStack * 2u + kSelCap <= (uint32_t)kSortCap, "LDS of the work list");
+			uint32_t *sel = lkeys + (uint32_t)kViolCap * kLaneStack * 2u;
+			if (t == 0) {
+				s_dflag = dbg_path == 2 ? 1u : 0u;      // (tests: always the region-suffix fall-back)
+				s_nsel = 0;
 				s_viols += nseeds;
-			wg_sync();
-			if (s_dflag) {
-				// the general way: take back the later commits that used the buckets the chains stepped
-				// on, and what depends on them; if that list outgrows LDS, the whole region suffix
-				Dirty dd;
-				dd.bucket = dB;
-				dd.index = dT;
-				dd.filter = dF;
-				dd.n = &s_nd;
-				dd.flag = &s_dflag;
-				dd.nbr = lkeys;                    // (the work list is gathered anew after this)
-				dd.sel = lkeys + kNbrCap;
-				dd.nsel = &s_nsel;
-				dd.nnbr = &s_nnbr;
-				static_assert(kNbrCap + kSelCap <= (uint32_t)kSortCap, "lists share the LDS of the work list");
-				uint32_t u = 0;
-				const bool targeted = dbg_path != 2 && resolve_violations(g, table, state, reqc, undo, chain_logs,
-						touched, tstamp, ctl->vlist, nseeds, lo_idx, total, dd, &u);
-				if (!targeted) {
-					if (t < kMaxRegions)
-						s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[t]) : kNone;
-					__syncthreads();
-					u += roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr);
-					rebuild = true;                // the record names requests that are pending again
-				}
-				if (u)
-					atomicAdd(&s_undone, u);
 			}
+			__syncthreads();
+			if (t < nseeds && dbg_path != 2) {
+				const uint32_t *sw = reinterpret_cast<const uint32_t *>(ctl->vlist + t);
+				const uint32_t sj = ld_agent32(sw), sX = ld_agent32(sw + 1);
+				if (!select_from(g, state, reqc, undo, chain_logs, tv, sj, sX,
+						reinterpret_cast<uint2 *>(lkeys) + t * kLaneStack, sel, &s_nsel))
+					s_dflag = 1u;
+			}
+			wg_sync();
+			uint32_t u = 0;
+			if (!s_dflag) {
+				// take them back, newest round first (two commits of one round never share a bucket)
+				const uint32_t nsel = s_nsel;
+				for (int pass = 0; pass < 2; pass++) {
+					const uint32_t tag = (pass == 0 ? ST_ROUND2 : ST_ROUND1) | ST_SELECT;
+					const uint32_t ctag = (pass == 0 ? ST_CHAIN2 : ST_CHAIN1) | ST_SELECT;
+					for (uint32_t i = t; i < nsel; i += blockDim.x) {
+						const uint32_t k = sel[i];
+						const uint32_t st = state[k];
+						if (st != tag && st != ctag)
+							continue;
+						take_back(g, table, state, reqc, undo, chain_logs, tnodes, node_base, k, st == ctag);
+						u++;
+					}
+					wg_sync();
+				}
+			} else {
+				// a stack or the list overflowed: the whole suffix of the regions concerned, and the
+				// record anew (roll_back_from also takes back what is flagged already)
+				if (t < kMaxRegions)
+					s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[t]) : kNone;
+				__syncthreads();
+				u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr);
+				rebuild = true;
+			}
+			if (u)
+				atomicAdd(&s_undone, u);
 		}
 		wg_sync();
 		MKV_PHASE(2);
@@ -2504,7 +2367,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		tstamp = s_tstamp;
 		tv.tstamp = tstamp;
 		if (rebuild)
-			build_touched(g, state, reqc, undo, chain_logs, touched, tstamp, lo_idx, total, 0u, 1u);
+			build_touched(g, state, reqc, undo, chain_logs, touched, tnodes, node_base, tstamp, lo_idx, total, 0u, 1u);
 		gather_pending(state, glist, &s_n, lo_idx, total, 0u, 1u);
 		wg_sync();
 		MKV_PHASE(3);
@@ -2526,6 +2389,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		// diagnostics of this call (summed over its chunks), then the control block of the next pass
 		for (int k = 0; k < 16; k++)
 			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + phase_ticks[k];
+		for (int k = 0; k < 8; k++) {                  // (diagnostic counts ride in the slots of the grid-wide rounds' ticks)
+			ctl->tail_phase[8 + k] += ctl->dbg[k] * 100u;
+			ctl->dbg[k] = 0;
+		}
 		ctl->last.total = total_all;
 		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
 		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + s_serial;
@@ -2584,6 +2451,8 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
 		ctl->violations = 0;
 		ctl->hard_tail = 0;
 		ctl->tstamp_next = 1;
+		for (int k = 0; k < 8; k++)
+			ctl->dbg[k] = 0;
 		reset_tail_scratch(ctl);
 	}
 	if (t < kMaxRegions)
@@ -2603,7 +2472,8 @@ struct Workspace {
 	int64_t req_cap = 0;
 	unsigned long long *owner[2] = {nullptr, nullptr};
 	unsigned long long *cnt = nullptr;
-	unsigned long long *touched = nullptr;   // per bucket: highest index committed there by the grid-wide rounds
+	unsigned long long *touched = nullptr;   // per bucket: head of the list of the commits of a pass that used it
+	uint2 *tnodes = nullptr;                 // ... and the lists' nodes (2 per request + 8 per chain log)
 	uint8_t *state = nullptr;
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
@@ -2635,6 +2505,7 @@ static void free_ws(Workspace *w)
 		if (w->owner[i]) (void)hipFree(w->owner[i]);
 	if (w->cnt) (void)hipFree(w->cnt);
 	if (w->touched) (void)hipFree(w->touched);
+	if (w->tnodes) (void)hipFree(w->tnodes);
 	if (w->state) (void)hipFree(w->state);
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
@@ -2703,6 +2574,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = ok && hipMalloc(&w->owner[i], nb * 8) == hipSuccess;
 	ok = ok && hipMalloc(&w->cnt, nb * 16) == hipSuccess;     // registrant counts, then the election words
 	ok = ok && hipMalloc(&w->touched, nb * 8) == hipSuccess;
+	ok = ok && hipMalloc(&w->tnodes, ((size_t)rc * 2 + (size_t)kChainLogCap * 8) * sizeof(uint2)) == hipSuccess;
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
@@ -2875,7 +2747,8 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->touched, w->reqc, w->state, w->undo, w->chain_logs, w->glist, tail_rounds, lo, hi, first_chunk,
+			w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, tuning().debug_skip);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
