@@ -114,7 +114,7 @@ Tuning &tuning()
 		v.grid_min = s ? atoi(s) : 2048;
 		if (v.grid_min < 0) v.grid_min = 0;
 		s = getenv("MKV_CALM_FACTOR");
-		v.calm_factor = s ? atoi(s) : 2;
+		v.calm_factor = s ? atoi(s) : 1;
 		if (v.calm_factor < 1) v.calm_factor = 1;
 		if (v.calm_factor > 64) v.calm_factor = 64;
 		s = getenv("MKV_TAIL_GROUPS");
@@ -122,7 +122,7 @@ Tuning &tuning()
 		if (v.tail_groups < 1) v.tail_groups = 1;
 		if (v.tail_groups > 64) v.tail_groups = 64;
 		s = getenv("MKV_INSERT_CHUNK");
-		v.insert_chunk = s ? atoll(s) : 131072;
+		v.insert_chunk = s ? atoll(s) : 524288;
 		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
 		v.insert_chunk &= ~15ll;
 		return v;

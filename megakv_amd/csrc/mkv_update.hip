@@ -87,7 +87,6 @@ constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- 
 constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
                                     // launch stays free of scratch memory and calls)
 constexpr uint32_t kGridAll = 1024;
-constexpr uint32_t kGridList = 256;
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 
@@ -155,6 +154,7 @@ struct Ctl {
 	uint32_t g_progress[2], g_left[2];
 	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
 	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
+	uint32_t record_by_r2;           // round 2 has kept the touched record of this pass (the tail need not build it)
 	uint32_t viol[kMaxRegions];      // tail: lowest index per region whose chain met a bucket a LATER request already used
 	uint32_t vlist_n;                // ... and the violations themselves: {index, bucket} (the first kViolCap of a turn)
 	uint2 vlist[kViolCap];
@@ -873,6 +873,51 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 				g.blk_mask, chunks_per_slot);
 }
 
+__device__ __forceinline__ bool tag_logged(uint32_t st)
+{
+	return st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2;
+}
+
+// The touched record: per bucket, the list of the commits of this pass that used it.
+//   head  touched[b] = (stamp << kNodeBits) | (node + 1)     (another stamp: empty)
+//   node  tnodes[n]  = {index of the commit (kNone: taken back since), next node + 1 (0: end)}
+// Node numbers are static: 2 idx for a commit's primary bucket, 2 idx + 1 for its alternate
+// bucket, node_base + 8 slot + i for the i-th further bucket of the chain logged in `slot`.
+constexpr int kNodeBits = 26;
+
+__device__ __forceinline__ void touched_enter(unsigned long long *touched, uint2 *tnodes, unsigned long long tstamp,
+		uint32_t b, uint32_t node, uint32_t idx)
+{
+	const unsigned long long old = atomicExch(&touched[b], (tstamp << kNodeBits) | (unsigned long long)(node + 1u));
+	const uint32_t next = (old >> kNodeBits) == tstamp ? (uint32_t)(old & ((1ull << kNodeBits) - 1ull)) : 0u;
+	tnodes[node] = make_uint2(idx, next);
+}
+
+// enters the commit idx (tag st, undo record u) on the list of every bucket it used
+__device__ __forceinline__ void enter_commit(const DevGeom &g, const ChainLog *chain_logs, unsigned long long *touched,
+		uint2 *tnodes, uint32_t node_base, unsigned long long tstamp, uint32_t idx, uint32_t st, uint32_t sig,
+		uint32_t hash, const Undo &u)
+{
+	const uint32_t P = hash & g.hash_mask;
+	const uint32_t A = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
+	touched_enter(touched, tnodes, tstamp, P, 2u * idx, idx);
+	if (st == ST_CHAIN1 || st == ST_CHAIN2) {
+		if (A != P)
+			touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
+		const ChainLog *L = &chain_logs[u.word0];
+		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+		uint32_t last = A, k = 0;
+		for (uint32_t i = 0; i < n; i++) {
+			const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
+			if (b != last && b != P && b != A && k < 8u)
+				touched_enter(touched, tnodes, tstamp, b, node_base + 8u * u.word0 + k++, idx);
+			last = b;
+		}
+	} else if ((u.word0 >> 4) != P) {
+		touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
+	}
+}
+
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
 // ROUND 1 iterates every request; ROUND 2 the round-1 losers.  A request that is the lowest
 // registrant of every bucket it needs executes with plain loads and stores and logs what it
@@ -884,10 +929,19 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
-		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx)
+		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, unsigned long long *touched,
+		uint2 *tnodes, uint32_t node_base, int record_hint)
 {
-	if (ROUND == 2 && ctl->any_loser == 0u)
+	// Round 2 also keeps the touched record when round 1 has left hard requests to the tail: its
+	// many idle lanes enter round 1's commits (final by now), its losers their own as they
+	// commit -- the tail, with far fewer lanes, then need not build it.
+	// (record_hint: chains have been running late in recent calls -- one may only turn up in this round)
+	const bool record = ROUND == 2 && OP == OP_CUCKOO && (ctl->any_hard != 0u || record_hint != 0);
+	if (ROUND == 2 && ctl->any_loser == 0u && !record)
 		return;
+	const unsigned long long tstamp = record ? ctl->tstamp_cur : 0ull;
+	if (record && blockIdx.x == 0 && threadIdx.x == 0)
+		ctl->record_by_r2 = 1u;
 	if (ROUND == 1 && blockIdx.x == 0 && threadIdx.x == 0)
 		reset_tail_scratch(ctl);
 	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
@@ -948,6 +1002,9 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					state[idx] = chained ? (ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2) : (ROUND == 1 ? ST_ROUND1 : ST_ROUND2);
 					if (OP == OP_CUCKOO)
 						undo[idx] = u;
+					if (record)
+						enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx,
+								chained ? ST_CHAIN2 : ST_ROUND2, r.sig, r.hash, u);
 					if (chained)
 						atomicAdd(&ctl->chain_ok, 1u);
 					ndone++;
@@ -986,6 +1043,16 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 		}
 	}
 	count_add(ctl->committed[ROUND - 1], ndone);
+	if (record) {
+		const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
+		for (uint32_t idx = start + blockIdx.x * blockDim.x + threadIdx.x; idx < count && idx >= start; idx += span) {
+			const uint32_t st = state[idx];
+			if (st != ST_ROUND1 && st != ST_CHAIN1)
+				continue;
+			const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);
+			enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx, st, sh.x, sh.y, undo[idx]);
+		}
+	}
 }
 
 // ---- order validation of eviction chains that run late ------------------------------
@@ -1011,21 +1078,6 @@ struct Tv {
 	uint32_t *dbg;
 };
 constexpr uint32_t kTvViolation = 1u, kTvNeed = 2u;
-
-// The touched record: per bucket, the list of the commits of this pass that used it.
-//   head  touched[b] = (stamp << kNodeBits) | (node + 1)     (another stamp: empty)
-//   node  tnodes[n]  = {index of the commit (kNone: taken back since), next node + 1 (0: end)}
-// Node numbers are static: 2 idx for a commit's primary bucket, 2 idx + 1 for its alternate
-// bucket, node_base + 8 slot + i for the i-th further bucket of the chain logged in `slot`.
-constexpr int kNodeBits = 26;
-
-__device__ __forceinline__ void touched_enter(unsigned long long *touched, uint2 *tnodes, unsigned long long tstamp,
-		uint32_t b, uint32_t node, uint32_t idx)
-{
-	const unsigned long long old = atomicExch(&touched[b], (tstamp << kNodeBits) | (unsigned long long)(node + 1u));
-	const uint32_t next = (old >> kNodeBits) == tstamp ? (uint32_t)(old & ((1ull << kNodeBits) - 1ull)) : 0u;
-	tnodes[node] = make_uint2(idx, next);
-}
 
 // lowest... any commit later than idx on bucket b (its index), or kNone
 __device__ __forceinline__ uint32_t touched_later_who(const Tv &tv, uint32_t b, uint32_t idx)
@@ -1150,6 +1202,7 @@ __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 	ctl->g_dupw[0] = ctl->g_dupw[1] = 0;
 	ctl->tail_rounds_used = 0;
 	ctl->tflags = 0;
+	ctl->record_by_r2 = 0;
 	ctl->vlist_n = 0;
 	ctl->tstamp_cur = ctl->tstamp_next++;
 	for (int k = 0; k < kMaxRegions; k++) {
@@ -1912,11 +1965,6 @@ __device__ __forceinline__ bool tag_pending(uint32_t st)
 	return st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK;
 }
 
-__device__ __forceinline__ bool tag_logged(uint32_t st)
-{
-	return st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2;
-}
-
 // The touched record of this pass: every request the grid-wide rounds have committed (its
 // tag says so) enters its index, under the stamp `tstamp`, on each bucket it used -- the
 // primary bucket always (examined even when full), the alternate bucket when the commit went
@@ -1936,25 +1984,7 @@ __device__ __forceinline__ void build_touched(const DevGeom &g, const uint8_t *s
 		if (!tag_logged(st))
 			continue;
 		const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);   // {sig, hash}
-		const Undo u = undo[idx];
-		const uint32_t P = sh.y & g.hash_mask;
-		const uint32_t A = alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask);
-		touched_enter(touched, tnodes, tstamp, P, 2u * idx, idx);
-		if (st == ST_CHAIN1 || st == ST_CHAIN2) {
-			if (A != P)
-				touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
-			const ChainLog *L = &chain_logs[u.word0];
-			const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-			uint32_t last = A, k = 0;
-			for (uint32_t i = 0; i < n; i++) {
-				const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
-				if (b != last && b != P && b != A && k < 8u)
-					touched_enter(touched, tnodes, tstamp, b, node_base + 8u * u.word0 + k++, idx);
-				last = b;
-			}
-		} else if ((u.word0 >> 4) != P) {
-			touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
-		}
+		enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx, st, sh.x, sh.y, undo[idx]);
 	}
 }
 
@@ -2181,7 +2211,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
 	const uint32_t pending_est = span > s_done12 ? span - s_done12 : 0u;
 	const bool use_helpers = nwg > 1u && (pending_est > (uint32_t)kTailAloneMax || span > (uint32_t)kTailAloneSpan ||
-			(any_hard && span > 8192u));          // (a long tag range is worth sharing even if little is left in it)
+			(any_hard && ctl->record_by_r2 == 0u && span > 8192u));   // (a long tag range is worth sharing even
+			                                                              // if little is left in it; so is the record)
 	if (wg != 0 && (!work_left || !use_helpers))
 		return;
 	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
@@ -2189,7 +2220,9 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	bool grid_mode = false;
 	if (work_left) {
 		// hard requests were left to the tail: their chains will be checked against the touched record
-		if (any_hard) {
+		if (OP == OP_CUCKOO && ctl->record_by_r2 != 0u) {
+			tstamp = ctl->tstamp_cur;           // round 2 has kept it
+		} else if (any_hard) {
 			tstamp = ctl->tstamp_cur;
 			build_touched(g, state, reqc, undo, chain_logs, touched, tnodes, node_base, tstamp, lo_idx, total, wg,
 					nwg_eff);
@@ -2492,7 +2525,8 @@ struct Workspace {
 	volatile uint32_t *host_flag = nullptr;
 	uint32_t *host_flag_dev = nullptr;
 	Chunking cycle_ck = {1, 65536, 0};    // chunking chosen by the first half of an mkv_cycle insert
-	int barrier_score = 0;             // > 0: region barriers were seen within the last few calls
+	int barrier_score = 0;             // > 0: eviction chains ran late within the last few calls
+	int record_hint = 0;               // ... so round 2 keeps the touched record as a matter of course
 	int stamp_resets = 0;              // times the reservation tables were cleared because the stamps ran low
 };
 
@@ -2640,49 +2674,55 @@ template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
 		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1);
 
-// Canonical-index chunks of one call.  With a size hint from the caller the
-// pipeline runs chunk after chunk (stream order = canonical order), so a region
-// barrier only ever redoes part of one chunk.  No hint (the plain ABI, whose
-// callers stay below 32 K requests): one pass over everything.
-// Passes of one call: data chunks, plus -- when there are several -- a trailing
-// flush pass over an empty range that only takes what the last data chunk carried.
-// Two-choice insert and delete never raise barriers: always one pass.
-static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
+// Canonical-index passes of one call.  With a size hint from the caller a large batch runs
+// pass after pass (stream order = canonical order), Tuning::insert_chunk requests each; no
+// hint (the plain ABI, whose callers stay below 32 K requests): one pass over everything.
+// Every pass finishes its own requests.  Two-choice insert and delete: always one pass.
+//
+// The tail kernel leaves a word in pinned host memory (bit 0: eviction chains had to run
+// late in that call).  It is read here without synchronising -- possibly a call late, which
+// is fine: it only steers where the touched record is kept (round 2 keeps it as a matter of
+// course while chains have been running late within the last Tuning::barrier_sticky calls;
+// otherwise the tail builds it if it turns out to be needed) and, with calm_factor > 1, the
+// pass size -- never the result.
+// work-groups of the mark pass inside a fused search launch: Tuning::mark_blocks for the usual
+// few per cent of SETs, more when the caller announces many (one per 512 requests, up to 1024)
+static uint32_t mark_blocks_for(long long hint)
 {
-	Chunking k;
-	k.passes = 1;
-	k.flush = 0;
-	k.step = (uint32_t)tuning().insert_chunk;
-	if (!cuckoo || hint <= 0)
-		return k;
-	long long c = tuning().insert_chunk;
-	// the flag is the previous call's; keep the fine-chunk mode for 16 calls after the last
-	// barrier so an occasional barrier does not meet a huge single pass
+	long long b = tuning().mark_blocks;
+	if (hint / 512 > b)
+		b = hint / 512;
+	return (uint32_t)(b > 1024 ? 1024 : b);
+}
+
+static bool chains_lately(Workspace *w)
+{
 	if (w && w->host_flag) {
 		if (*w->host_flag & 1u)
 			w->barrier_score = tuning().barrier_sticky;
 		else if (w->barrier_score > 0)
 			w->barrier_score--;
 	}
-	const bool barriers_lately = w && w->barrier_score > 0;
-	// no barrier for a while: chunks `calm_factor` times the size (fewer passes); the first
-	// barrier switches back (its own redo still rides the following passes)
-	if (!barriers_lately && tuning().calm_factor > 1)
+	return w && w->barrier_score > 0;
+}
+
+static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
+{
+	Chunking k;
+	k.passes = 1;
+	k.flush = 0;
+	k.step = (uint32_t)tuning().insert_chunk;
+	const bool lately = cuckoo && chains_lately(w);
+	if (w)
+		w->record_hint = lately ? 1 : 0;
+	if (!cuckoo || hint <= 0)
+		return k;
+	long long c = tuning().insert_chunk;
+	if (!lately && tuning().calm_factor > 1)
 		c *= tuning().calm_factor;
-	const int split = tuning().barrier_split;
-	if (barriers_lately && split > 1 && hint <= c && hint >= 8192) {
-		// barriers lately and a batch that would be one chunk: cut it up, so a barrier's redo
-		// rides through grid-wide passes.  Off by default since the tail scans and runs long
-		// lists on all its work-groups: the extra passes cost more than they save.
-		c = ((hint + split - 1) / split + 15) & ~15ll;
-		if (c < 2048)
-			c = 2048;
-	}
 	if (hint <= c)
 		return k;
 	const long long n = (hint + c - 1) / c;
-	// (every pass finishes its own requests: no trailing flush passes)
-	k.flush = 0;
 	k.passes = n > 250 ? 250 : (int)n;
 	k.step = (uint32_t)c;
 	return k;
@@ -2743,9 +2783,11 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
-	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridList), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi);
+			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
+			(uint32_t)(2 * w->req_cap), 0);
+	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
+			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
+			(uint32_t)(2 * w->req_cap), w->record_hint);
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
@@ -2851,7 +2893,7 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	if (rc != MKV_OK)
 		return rc;
 	const int64_t search_blocks = (num_search + 255) / 256;      // U = 4: 256 requests per block
-	const uint32_t mark_blocks = (uint32_t)mkv::tuning().mark_blocks;
+	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint);
 	if (search_blocks + mark_blocks > 0x7fffffffLL)
 		return MKV_ETOOBIG;
 	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
@@ -2964,7 +3006,7 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	const int nchunks = ck.passes;
 	uint32_t lo, hi;
 	mkv::chunk_range(0, ck, &lo, &hi);
-	const uint32_t mark_blocks = (uint32_t)mkv::tuning().mark_blocks;
+	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint);
 	const dim3 grid(search_blocks + mark_blocks), block(256);
 	if (tm)
 		(void)hipEventRecord(tm->ev[2 * slot], s);
