@@ -754,8 +754,11 @@ extern "C" int mkv_derive_requests(const void *keys, int64_t num_keys, int key_l
 //     loc == 0  =>  miss                                 (src/mega_send.c:464-466)
 // for a whole batch: one resolved location per request plus hit / miss totals
 // (the counters the reference aggregates per sender thread, src/mega_scheduler.c:97-116).
-// Turning a location into an item pointer and KEY_MATCH verification need the host
-// slab store and stay out of scope.
+// With KEY_MATCH the sender also compares the key stored in the item the location names
+// with the request's (src/mega_send.c:543-553: nkey equal and the bytes equal -> hit, else
+// miss): a 32-bit signature has false positives.  k_resolve_verify does that on the device
+// against a flat item arena standing in for the slab store (item `loc` at loc * item_stride;
+// the slab arithmetic of src/slabs.c:132-146 is the host allocator's business).
 // ===========================================================================
 namespace mkv {
 
@@ -774,6 +777,44 @@ __global__ __launch_bounds__(256) void k_resolve(const uint2 *__restrict__ pairs
 		hits += __shfl_down(hits, off);
 	if ((threadIdx.x & 63u) == 0u && hits)
 		atomicAdd(&counters[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], (unsigned long long)hits);
+}
+
+// KEY_MATCH: one lane per request.  Only the location the sender would pick is looked at --
+// the primary bucket's if it is non-zero, else the alternate's (:408-414); a false positive
+// in the primary bucket therefore hides a true entry in the alternate one, as in the reference.
+__global__ __launch_bounds__(256) void k_resolve_verify(const uint2 *__restrict__ pairs, int64_t n,
+		const uint8_t *__restrict__ keys, int64_t key_stride, uint32_t key_len, const uint8_t *__restrict__ arena,
+		int64_t item_stride, uint64_t arena_items, uint32_t nkey_off, uint32_t key_off,
+		uint32_t *__restrict__ loc, unsigned long long *__restrict__ counters)
+{
+	uint32_t hits = 0, fps = 0;
+	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
+			i += (int64_t)gridDim.x * blockDim.x) {
+		const uint2 p = pairs[i];
+		const uint32_t l = p.x ? p.x : p.y;
+		bool ok = false;
+		if (l != 0u && (uint64_t)l < arena_items) {
+			const uint8_t *it = arena + (uint64_t)l * (uint64_t)item_stride;
+			const uint32_t nkey = (uint32_t)it[nkey_off] | ((uint32_t)it[nkey_off + 1u] << 8);   // uint16_t nkey
+			ok = nkey == key_len;
+			const uint8_t *k = keys + i * key_stride;
+			for (uint32_t b = 0; ok && b < key_len; b++)
+				ok = it[key_off + b] == k[b];
+		}
+		loc[i] = ok ? l : 0u;
+		hits += ok ? 1u : 0u;
+		fps += (l != 0u && !ok) ? 1u : 0u;
+	}
+	for (int off = 32; off > 0; off >>= 1) {
+		hits += __shfl_down(hits, off);
+		fps += __shfl_down(fps, off);
+	}
+	if ((threadIdx.x & 63u) == 0u) {
+		if (hits)
+			atomicAdd(&counters[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], (unsigned long long)hits);
+		if (fps)
+			atomicAdd(&counters[66], (unsigned long long)fps);
+	}
 }
 
 // folds the 64 sharded partial sums: counters[64] = hits, counters[65] = misses
@@ -805,6 +846,31 @@ extern "C" int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *
 		hipLaunchKernelGGL(mkv::k_resolve, dim3((unsigned)blocks), dim3(256), 0, s,
 				reinterpret_cast<const uint2 *>(pairs), num_elem, loc,
 				reinterpret_cast<unsigned long long *>(counters));
+	}
+	hipLaunchKernelGGL(mkv::k_resolve_fold, dim3(1), dim3(64), 0, s,
+			reinterpret_cast<unsigned long long *>(counters), (long long)num_elem);
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+extern "C" int mkv_resolve_verify(const loc_t *pairs, int64_t num_elem, const void *keys, int64_t key_stride,
+		int key_len, const void *arena, int64_t item_stride, int64_t arena_items, int nkey_off, int key_off,
+		loc_t *loc, uint64_t *counters, void *stream)
+{
+	if (num_elem < 0 || !counters || key_len < 0 || key_len > 65535 || item_stride <= 0 || arena_items < 0 ||
+			nkey_off < 0 || key_off < 0 || (int64_t)nkey_off + 2 > item_stride || (int64_t)key_off + key_len > item_stride ||
+			key_stride < key_len || (num_elem && (!pairs || !loc || !keys || !arena)))
+		return MKV_EINVAL;
+	hipStream_t s = (hipStream_t)stream;
+	if (hipMemsetAsync(counters, 0, 68 * sizeof(uint64_t), s) != hipSuccess)
+		return MKV_EHIP;
+	if (num_elem) {
+		int64_t blocks = (num_elem + 255) / 256;
+		if (blocks > 4096)
+			blocks = 4096;
+		hipLaunchKernelGGL(mkv::k_resolve_verify, dim3((unsigned)blocks), dim3(256), 0, s,
+				reinterpret_cast<const uint2 *>(pairs), num_elem, reinterpret_cast<const uint8_t *>(keys), key_stride,
+				(uint32_t)key_len, reinterpret_cast<const uint8_t *>(arena), item_stride, (uint64_t)arena_items,
+				(uint32_t)nkey_off, (uint32_t)key_off, loc, reinterpret_cast<unsigned long long *>(counters));
 	}
 	hipLaunchKernelGGL(mkv::k_resolve_fold, dim3(1), dim3(64), 0, s,
 			reinterpret_cast<unsigned long long *>(counters), (long long)num_elem);

@@ -30,7 +30,7 @@ ABI_SYMBOLS = [
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
     "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
-    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
@@ -125,6 +125,8 @@ def load_library():
     L.mkv_derive_requests.argtypes = [P, I64, INT, I64, INT, P, P, INT, P]
     L.mkv_resolve_results.restype = INT
     L.mkv_resolve_results.argtypes = [P, I64, P, P, P]
+    L.mkv_resolve_verify.restype = INT
+    L.mkv_resolve_verify.argtypes = [P, I64, P, I64, INT, P, I64, I64, INT, INT, P, P, P]
     L.mkv_unpack_results.restype = INT
     L.mkv_unpack_results.argtypes = [P, P, I64, P, P]
     L.mkv_unroute_results.restype = INT

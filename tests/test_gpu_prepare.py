@@ -151,3 +151,62 @@ def test_resolve_results_like_the_sender(n):
     assert np.array_equal(host(loc)[:n], exp)
     c = ctr.cpu().numpy()
     assert int(c[64]) == int((exp != 0).sum()) and int(c[65]) == n - int((exp != 0).sum())
+
+
+@pytest.mark.parametrize("n,key_len", [(0, 8), (1, 8), (5000, 8), (200003, 16), (3001, 33)])
+def test_resolve_with_key_match_like_the_sender(n, key_len):
+    """src/mega_send.c:408-414 + 543-553 (KEY_MATCH): the location picked from the pair must
+    name an item whose key length and key bytes equal the request's; else it is a miss.  The
+    slab store is a flat arena here (reference item header: nkey at byte 10, key at byte 24,
+    src/include/items.h:37-50).  Host restatement vs the device, incl. false positives (a
+    location whose item holds another key), a wrong nkey, out-of-range locations and the
+    reference's blind spot (a false positive in the primary bucket hides the alternate)."""
+    L = load_library()
+    rng = np.random.default_rng(n + key_len)
+    items, stride, nkey_off, key_off = 4096, 64, 10, 24
+    arena = rng.integers(0, 256, size=(items, stride), dtype=np.uint8)
+    item_keys = rng.integers(0, 256, size=(items, key_len), dtype=np.uint8)
+    arena[:, key_off:key_off + key_len] = item_keys
+    arena[:, nkey_off] = key_len & 0xff
+    arena[:, nkey_off + 1] = key_len >> 8
+    wrong_len = rng.random(items) < 0.05
+    arena[wrong_len, nkey_off] = (key_len + 1) & 0xff                  # same bytes, another length
+    true_loc = rng.integers(1, items, size=n).astype(np.uint32)
+    keys = np.zeros((n, key_len + 3), np.uint8)                        # (a stride wider than the key)
+    keys[:, :key_len] = item_keys[true_loc] if n else 0
+    pairs = np.zeros((n, 2), np.uint32)
+    kind = rng.integers(0, 6, size=n)
+    other = rng.integers(1, items, size=n).astype(np.uint32)
+    pairs[kind == 0, 0] = true_loc[kind == 0]                           # hit in the primary bucket
+    pairs[kind == 1, 1] = true_loc[kind == 1]                           # hit in the alternate bucket
+    pairs[kind == 2, 0] = other[kind == 2]                              # false positive hiding ...
+    pairs[kind == 2, 1] = true_loc[kind == 2]                           # ... the true entry (reference: a miss)
+    pairs[kind == 3, 1] = other[kind == 3]                              # false positive (unless other == true)
+    pairs[kind == 5, 0] = items + 77                                    # a location outside the arena
+    # host restatement
+    pick = np.where(pairs[:, 0] != 0, pairs[:, 0], pairs[:, 1])
+    exp = np.zeros(n, np.uint32)
+    fp = 0
+    for i in range(n):
+        l = int(pick[i])
+        if l == 0:
+            continue
+        ok = l < items and (int(arena[l, nkey_off]) | int(arena[l, nkey_off + 1]) << 8) == key_len \
+            and bytes(arena[l, key_off:key_off + key_len]) == bytes(keys[i, :key_len])
+        if ok:
+            exp[i] = l
+        else:
+            fp += 1
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_pairs = dev(pairs) if n else torch.zeros((1, 2), dtype=torch.int32, device="cuda")
+    d_keys, d_arena = d(keys if n else np.zeros((1, key_len + 3), np.uint8)), d(arena)
+    loc = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
+    ctr = torch.zeros(68, dtype=torch.int64, device="cuda")
+    assert L.mkv_resolve_verify(_dev_ptr(d_pairs), n, _dev_ptr(d_keys), key_len + 3, key_len, _dev_ptr(d_arena), stride,
+                                items, nkey_off, key_off, _dev_ptr(loc), _dev_ptr(ctr), _stream_ptr(None)) == 0
+    torch.cuda.synchronize()
+    assert np.array_equal(host(loc)[:n], exp)
+    c = ctr.cpu().numpy()
+    assert (int(c[64]), int(c[65]), int(c[66])) == (int((exp != 0).sum()), n - int((exp != 0).sum()), fp)
+    if n > 1000:
+        assert fp > 0 and int(c[64]) > 0
