@@ -2649,6 +2649,45 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	return MKV_OK;
 }
 
+// ---- one table, several streams ---------------------------------------------------------
+// The reference's scheduler issues the deletes and inserts of all its workers on ONE table,
+// a stream per worker (src/mega_scheduler.c:393-500); its kernels then race benignly.  Here an
+// update keeps reservation state per stream, and a roll-back restores words -- two updates of
+// one table running side by side would not be anybody's serialisation.  So updates of a table
+// are put in the order the host issued them: the call that finds the table's last update on
+// ANOTHER stream makes its stream wait for that one (an event recorded there now).  A host
+// that keeps to one stream per table never records or waits.  Searches are not ordered
+// against updates of other streams (neither are the reference's).
+struct TableOrder {
+	hipStream_t last = nullptr;
+	bool any = false;
+	hipEvent_t ev = nullptr;
+};
+static std::unordered_map<uint64_t, TableOrder> g_table_order;   // key: device<<56 ^ table address
+
+static int order_table_updates(const void *table, hipStream_t stream)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return MKV_EHIP;
+	std::lock_guard<std::mutex> lock(g_ws_mutex);
+	TableOrder &o = g_table_order[((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)table];
+	if (o.any && o.last != stream) {
+		if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess)
+			return MKV_EHIP;
+		// (a stream that has been destroyed since has finished its work: nothing to wait for)
+		if (hipEventRecord(o.ev, o.last) == hipSuccess) {
+			if (hipStreamWaitEvent(stream, o.ev, 0) != hipSuccess)
+				return MKV_EHIP;
+		} else {
+			(void)hipGetLastError();
+		}
+	}
+	o.last = stream;
+	o.any = true;
+	return MKV_OK;
+}
+
 static int64_t ws_need(const ReqSrc &src, long long hint = 0)
 {
 	int64_t need = (int64_t)tuning().req_cap;
@@ -2756,7 +2795,10 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		return MKV_ETOOBIG;
 	if (hint > kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src, hint), stream);
+	int rc = order_table_updates(table, stream);
+	if (rc != MKV_OK)
+		return rc;
+	rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src, hint), stream);
 	if (rc != MKV_OK)
 		return rc;
 	if (src.single_n > 0 && hint <= 0)
@@ -2851,7 +2893,10 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *ta
 	hipStream_t s = (hipStream_t)stream;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
+	int rc = mkv::order_table_updates(table, s);
+	if (rc != MKV_OK)
+		return rc;
+	rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	if (hipEventRecord(w->ev_fork, s) != hipSuccess || hipStreamWaitEvent(w->aux, w->ev_fork, 0) != hipSuccess)
@@ -2889,7 +2934,10 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	hipStream_t s = (hipStream_t)stream;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
+	int rc = mkv::order_table_updates(table, s);
+	if (rc != MKV_OK)
+		return rc;
+	rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	const int64_t search_blocks = (num_search + 255) / 256;      // U = 4: 256 requests per block
@@ -2998,7 +3046,10 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	mkv::Workspace *w = nullptr;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
+	int rc = mkv::order_table_updates(table, s);
+	if (rc != MKV_OK)
+		return rc;
+	rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	const bool cuckoo = d.scheme == MKV_SCHEME_CUCKOO;
@@ -3084,6 +3135,10 @@ extern "C" void mkv_release_all(void)
 		delete kv.second;
 	}
 	mkv::g_ws.clear();
+	for (auto &kv : mkv::g_table_order)
+		if (kv.second.ev)
+			(void)hipEventDestroy(kv.second.ev);
+	mkv::g_table_order.clear();
 }
 
 extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);

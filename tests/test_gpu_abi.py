@@ -105,3 +105,43 @@ def test_plain_c_driver_with_other_baked_in_macros():
     r = subprocess.run([exe, "10", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "errors 0" in r.stdout
+
+
+def test_updates_of_one_table_from_several_streams_keep_issue_order():
+    """The reference's scheduler updates ONE table from a stream per worker
+    (src/mega_scheduler.c:393-500).  Here the updates of a table are put in the order the host
+    issued them, whatever streams they are on: inserts and deletes alternating over three
+    streams with no synchronisation in between, many keys shared between consecutive calls --
+    the table equals the oracle's after the calls in issue order."""
+    import torch
+    import megakv_amd as M
+    from oracle import oracle as O
+    g = M.Geometry(mem_p=20)
+    og = O.geom(mem_p=20)
+    idx = M.HashIndex(g)
+    exp = O.new_table(og)
+    rng = np.random.default_rng(12)
+    streams = [torch.cuda.Stream() for _ in range(3)]
+    pool = rng.integers(1, 2**32, size=(30000, 3), dtype=np.uint64).astype(np.uint32)
+    keep = []
+    for call in range(12):
+        e = pool[rng.integers(0, len(pool), size=20000)].copy()
+        e[:, 2] = rng.integers(1, 2**32, size=len(e), dtype=np.uint64)        # new locations for old keys
+        s = streams[call % 3]
+        if call % 4 == 3:
+            occ = np.argwhere(exp[:, :8] != 0)[::7]                           # delete what is stored: (sig, hash, loc)
+            d = np.stack([exp[occ[:, 0], occ[:, 1]], occ[:, 0].astype(np.uint32), exp[occ[:, 0], 8 + occ[:, 1]]], axis=1)
+            d = np.ascontiguousarray(d.astype(np.uint32))
+            O.delete(og, exp, d)
+            t = torch.from_numpy(d.view(np.int32)).cuda()
+            keep.append(t)
+            idx.delete(t, stream=s)
+        else:
+            O.insert(og, exp, [e])
+            t = torch.from_numpy(e.view(np.int32)).cuda()
+            keep.append(t)
+            ptrs, cnts, kk = idx.stage_blocks([t])
+            keep.append((ptrs, cnts, kk))
+            idx.insert_staged(ptrs, cnts, 1, stream=s, hint=len(e))
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.table_numpy(), exp)
