@@ -248,7 +248,9 @@ void mkv_shard_destroy(mkv_shard_t *e);
 
 /* Tuning knobs (all but the debug ones also environment variables MKV_<NAME>, read once at start-up):
  *   search:  "search_u" (1/2/4/8 requests in flight per lane group), "search_nt" (non-temporal
- *            table loads), "search_wide" (8 lanes per request, one 64-byte access per bucket);
+ *            table loads), "search_wide" (8 lanes per request, one 64-byte access per bucket),
+ *            "search_lds" (signature rows staged in LDS and probed with a wave ballot, the location
+ *            fetched by a second load: the reference's structure, kept for the measurement);
  *   update:  "tail_rounds" (0..48 reservation rounds of the tail), "tail_groups" (work-groups of
  *            the tail launch, 1..64), "grid_min" (a final tail list longer than this runs its
  *            rounds on all of them), "insert_chunk" (requests per pass of a hinted insert),

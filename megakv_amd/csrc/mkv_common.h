@@ -84,6 +84,7 @@ struct Tuning {
 	int search_u;        // requests in flight per 4-lane group: 1, 2, 4 or 8
 	int search_nt;       // non-temporal table loads in search
 	int search_wide;     // 8 lanes per request, one 64-byte access per bucket (search_body_wide)
+	int search_lds;      // signature rows staged in LDS, ballot/ffs probe, dependent location load (search_body_lds)
 	int tail_rounds;     // reservation rounds inside the tail work-group (0..48)
 	long long req_cap;   // default request capacity of an update workspace
 	long long insert_chunk; // requests per canonical-index chunk when the caller hints the batch size

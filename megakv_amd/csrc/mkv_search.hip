@@ -44,6 +44,14 @@ __global__ __launch_bounds__(256) void k_search_wide(const uint2 *__restrict__ i
 	search_body_wide<2 * U, ZERO_MISS, NT>(blockIdx.x, in, out, table, n, hash_mask, blk_mask);
 }
 
+template <bool ZERO_MISS>
+__global__ __launch_bounds__(256) void k_search_lds(const uint2 *__restrict__ in,
+		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n,
+		uint32_t hash_mask, uint32_t blk_mask)
+{
+	search_body_lds<ZERO_MISS>(blockIdx.x, in, out, table, n, hash_mask, blk_mask);
+}
+
 template <int U>
 static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int64_t n,
 		uint32_t hash_mask, uint32_t blk_mask, uint32_t flags, bool nt, hipStream_t stream)
@@ -54,6 +62,17 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 		return MKV_ETOOBIG;
 	dim3 grid((unsigned)blocks), block(256);
 	const bool zero = (flags & MKV_SEARCH_ZERO_MISS) != 0;
+	if (tuning().search_lds) {
+		// 64 requests per block of 4 waves
+		const int64_t lblocks = (n + 63) / 64;
+		if (lblocks > 0x7fffffffLL)
+			return MKV_ETOOBIG;
+		if (zero)
+			hipLaunchKernelGGL((k_search_lds<true>), dim3((unsigned)lblocks), block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+		else
+			hipLaunchKernelGGL((k_search_lds<false>), dim3((unsigned)lblocks), block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+	}
 	if (tuning().search_wide) {
 		// (same requests per block: 4 waves x 8 x 2U)
 		if (zero)
@@ -88,6 +107,8 @@ Tuning &tuning()
 		v.search_nt = s ? atoi(s) != 0 : 0;
 		s = getenv("MKV_SEARCH_WIDE");
 		v.search_wide = s ? atoi(s) != 0 : 0;
+		s = getenv("MKV_SEARCH_LDS");
+		v.search_lds = s ? atoi(s) != 0 : 0;
 		s = getenv("MKV_TAIL_ROUNDS");
 		v.tail_rounds = s ? atoi(s) : 48;
 		if (v.tail_rounds < 0) v.tail_rounds = 0;
@@ -168,6 +189,8 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.search_nt = value != 0;
 	} else if (!strcmp(name, "search_wide")) {
 		t.search_wide = value != 0;
+	} else if (!strcmp(name, "search_lds")) {
+		t.search_lds = value != 0;
 	} else if (!strcmp(name, "tail_rounds")) {
 		if (value < 0 || value > 48)
 			return MKV_EINVAL;
@@ -220,7 +243,7 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 extern "C" int mkv_tuning_is_default_search(void)
 {
 	const mkv::Tuning &t = mkv::tuning();
-	return t.search_u == 4 && t.search_nt == 0 && t.search_wide == 0;
+	return t.search_u == 4 && t.search_nt == 0 && t.search_wide == 0 && t.search_lds == 0;
 }
 
 // ---- diagnostics: what the memory system gives for random reads ---------------------

@@ -161,6 +161,68 @@ __device__ __forceinline__ void search_body_wide(uint32_t block, const uint2 *__
 	}
 }
 
+// The search in the shape the task's north star sketches, kept for the record (tuning
+// "search_lds"; DESIGN.md 5.1 has the measurement): the signature rows of a wave's 16 requests
+// are loaded coalesced (4 lanes x 16 bytes = both 32-byte rows of a request) and staged in
+// LDS; then a lane per signature compares, a wave ballot gives every request its 16-bit match
+// mask, ffs/clz picks the slot (the highest one, as everywhere here), and the lane that owns
+// the request fetches the location with a second, dependent load -- the reference's
+// structure (libgpuhash/gpu_hash.cu:41-72) on 64 lanes.  Bit-identical results; one request
+// per 4 lanes and step, two round trips per hit.
+template <bool ZERO_MISS>
+__device__ __forceinline__ void search_body_lds(uint32_t block, const uint2 *__restrict__ in,
+		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n,
+		uint32_t hash_mask, uint32_t blk_mask)
+{
+	__shared__ uint32_t srow[4][16][16];    // [wave][request][8 primary + 8 alternate signatures]
+	__shared__ uint2 sreq[4][16];
+	const uint32_t lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+	const int64_t base = ((int64_t)block * 4 + wave) * 16;
+	{
+		const uint32_t r = lane >> 2, part = lane & 3u;
+		const int64_t e = base + r;
+		const bool live = e < n;
+		const uint2 req = live ? in[e] : make_uint2(0u, 0u);
+		const uint32_t pri = req.y & hash_mask;
+		const uint32_t alt = alt_bucket(req.y, req.x, hash_mask, blk_mask);
+		const uint32_t b = (part & 2u) ? alt : pri;
+		const uint4 v = live ? table[((uint64_t)b << 2) + (part & 1u)] : make_uint4(0u, 0u, 0u, 0u);
+		*reinterpret_cast<uint4 *>(&srow[wave][r][part * 4u]) = v;
+		if (part == 0u)
+			sreq[wave][r] = req;
+	}
+	__syncthreads();
+#pragma unroll
+	for (uint32_t q = 0; q < 4; q++) {
+		const uint32_t rr = 4u * q + (lane >> 4), s = lane & 15u;
+		const int64_t e = base + rr;
+		const bool live = e < n;
+		const uint2 req = sreq[wave][rr];
+		const bool match = live && srow[wave][rr][s] == req.x;
+		const unsigned long long m = __ballot(match);
+		const uint32_t mine = (uint32_t)(m >> ((lane >> 4) * 16u)) & 0xffffu;
+		if (s == 0u && live) {
+			const uint32_t mp = mine & 0xffu, ma = mine >> 8;
+			const uint32_t pri = req.y & hash_mask;
+			const uint32_t alt = alt_bucket(req.y, req.x, hash_mask, blk_mask);
+			const uint32_t *tw = reinterpret_cast<const uint32_t *>(table);
+			uint32_t lp = 0u, la = 0u;
+			if (mp)
+				lp = tw[(uint64_t)pri * 16u + 8u + (31u - (uint32_t)__clz((int)mp))];
+			if (ma)
+				la = tw[(uint64_t)alt * 16u + 8u + (31u - (uint32_t)__clz((int)ma))];
+			if (ZERO_MISS) {
+				*reinterpret_cast<uint2 *>(out + 2 * e) = make_uint2(mp ? lp : 0u, ma ? la : 0u);
+			} else {
+				if (mp)
+					out[2 * e] = lp;
+				if (ma)
+					out[2 * e + 1] = la;
+			}
+		}
+	}
+}
+
 // Search of the slots a shard received (padded exchange format, mkv_route.hip):
 // linear block index -> (slot, 256-request chunk); the slot's request count is read
 // from its header on the device.

@@ -27,6 +27,7 @@ def _defaults():
     set_tuning("search_u", 4)
     set_tuning("search_nt", 0)
     set_tuning("search_wide", 0)
+    set_tuning("search_lds", 0)
 
 
 # ---------------------------------------------------------------- search ----
@@ -76,6 +77,28 @@ def test_search_wide_layout_agrees(u, zero_miss, n):
     rng = np.random.default_rng(78 + n)
     img = random_table(g, rng, 0.6, sig_space=60)          # few signatures: in-bucket duplicates
     q = random_requests(g, rng, n, 60)[:, :2].copy()
+    idx = HashIndex(g)
+    idx.load_table(img)
+    exp = np.zeros((n, 2), np.uint32) if zero_miss else np.full((n, 2), 0xABCD1234, np.uint32)
+    O.search(ogeom(g), img, q, out=exp)
+    out = dev(np.full((n, 2), 0xABCD1234, np.uint32))
+    idx.search(dev(q), out=out, zero_miss=zero_miss)
+    torch.cuda.synchronize()
+    assert np.array_equal(host(out), exp)
+
+
+@pytest.mark.parametrize("zero_miss", [True, False])
+@pytest.mark.parametrize("n", [1, 9, 64, 65, 30011])
+def test_search_lds_ballot_layout_agrees(zero_miss, n):
+    """The reference's structure on 64 lanes -- signature rows staged in LDS, a wave ballot per
+    request, ffs/clz for the slot, a dependent load for the location (the search the task's
+    north star sketches; measured and kept as an alternative: DESIGN 5.1) -- gives the same
+    results, in-bucket duplicates and ragged tails included."""
+    set_tuning("search_lds", 1)
+    g = Geometry(mem_p=18)
+    rng = np.random.default_rng(178 + n)
+    img = random_table(g, rng, 0.6, sig_space=60)
+    q = random_requests(g, rng, n, 60, zero_low=0.1)[:, :2].copy()
     idx = HashIndex(g)
     idx.load_table(img)
     exp = np.zeros((n, 2), np.uint32) if zero_miss else np.full((n, 2), 0xABCD1234, np.uint32)

@@ -60,6 +60,29 @@ def main():
                          "p10": round(float(np.percentile(us, 10)), 2), "GBps_algo": round(144 * n / us.mean() / 1e3, 1)}
                     res.append(r)
                     print(json.dumps(r), flush=True)
+        # the alternative layouts at their best setting: 8 lanes per request, and the LDS-staged
+        # ballot probe of the reference's structure
+        L.mkv_set_tuning(b"search_u", 4)
+        L.mkv_set_tuning(b"search_nt", 0)
+        for name in (b"search_wide", b"search_lds"):
+            L.mkv_set_tuning(name, 1)
+            for q in qs[:4]:
+                idx.search(q, out=out, zero_miss=True)
+            torch.cuda.synchronize()
+            evs = []
+            for rep in range(2):
+                for q in qs:
+                    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                    a.record()
+                    idx.search(q, out=out, zero_miss=True)
+                    b.record()
+                    evs.append((a, b))
+            torch.cuda.synchronize()
+            us = np.array([a.elapsed_time(b) for a, b in evs]) * 1e3
+            print(json.dumps({"theta": theta, "layout": name.decode(), "avg_us": round(float(us.mean()), 2),
+                              "p10": round(float(np.percentile(us, 10)), 2),
+                              "GBps_algo": round(144 * n / us.mean() / 1e3, 1)}), flush=True)
+            L.mkv_set_tuning(name, 0)
 
 
 if __name__ == "__main__":
