@@ -381,8 +381,11 @@ def main():
 
     # ---- the dominant kernel, timed launch by launch in a pass of its own -------------------
     # The same cycles over the timed region's batches once more (their SETs are then updates
-    # with the same value: the table does not change), HIP events on the run stream around the
-    # search launch of EVERY step.  Not part of `value`.
+    # with the same value: the table does not change); the search launch of EVERY step delivers
+    # its start and end time into a pair of HIP events (hipExtLaunchKernelGGL on the run stream:
+    # the dispatch's own timestamps, what rocprofv3 reports as the kernel's duration -- a pair of
+    # hipEventRecord calls around the launch reads 2-3 us more, the launch latency).  Not part
+    # of `value`.
     roofline = None
     inside = np.array(timer.elapsed_ms()) if timer else None
     if use_events and not args.graph and args.steps:
@@ -409,7 +412,9 @@ def main():
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
                     "algorithmic_bytes_per_launch": algo_bytes,
-                    "launch_us": round(med_s * 1e6, 2), "launch_us_is": "median of launches_timed HIP-event pairs",
+                    "launch_us": round(med_s * 1e6, 2),
+                    "launch_us_is": "median over launches_timed launches of the kernel's own duration: HIP events that "
+                                    "receive the dispatch's start and end time (hipExtLaunchKernelGGL on the run stream)",
                     "launches_timed": int(len(ms)), "avg_launch_us": round(float(ms.mean()) * 1e3, 2),
                     "p10_us": round(float(np.percentile(ms, 10)) * 1e3, 2),
                     "p90_us": round(float(np.percentile(ms, 90)) * 1e3, 2),

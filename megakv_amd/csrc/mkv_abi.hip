@@ -73,8 +73,8 @@ extern "C" void gpu_delete_insert(bucket_t *hash_table, delem_t *delete_in, uint
 				(void *)stream), "gpu_delete_insert/insert");
 }
 
-// HIP event pairs recorded on the caller's stream around the search launch of
-// mkv_cycle: how bench.py times the dominant kernel inside the timed region.
+// HIP event pairs that receive the start and end time of the search dispatch of mkv_cycle
+// (hipExtLaunchKernelGGL on the caller's stream): how bench.py times the dominant kernel.
 extern "C" void *mkv_timer_create(int slots)
 {
 	if (slots <= 0)
@@ -120,7 +120,9 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 		int *blk_elem_num, int num_blks, long long size_hint, void *stream, int joined);
 extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 		const bucket_t *table, int64_t num_search, ielem_t **blk_input, int *blk_elem_num, int num_blks,
-		long long size_hint, void *stream);
+		long long size_hint, void *stream, void *ev_start, void *ev_stop);
+extern "C" int mkv_search_timed(const mkv_geom_t *geom, const selem_t *in, loc_t *out, const bucket_t *table,
+		int64_t num_elem, uint32_t flags, void *stream, void *ev_start, void *ev_stop);
 extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
 
@@ -152,12 +154,8 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 			return rc;
 	}
 	if (fused) {
-		if (tm)
-			(void)hipEventRecord(tm->ev[2 * slot], (hipStream_t)stream);
 		rc = mkv_cycle_search_mark(geom, search_in, search_out, table, num_search, blk_input, blk_elem_num,
-				num_blks, insert_hint, stream);
-		if (tm)
-			(void)hipEventRecord(tm->ev[2 * slot + 1], (hipStream_t)stream);
+				num_blks, insert_hint, stream, tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr);
 		if (rc != MKV_OK)
 			return rc;
 	} else if (num_search > 0) {
@@ -166,13 +164,10 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 						(hipStream_t)stream) != hipSuccess)
 				return MKV_EHIP;
 		}
-		if (tm)
-			(void)hipEventRecord(tm->ev[2 * slot], (hipStream_t)stream);
 		// memset + write-on-hit and write-always give the same buffer: fused unless asked
-		rc = mkv_search(geom, search_in, search_out, table, num_search,
-				(search_flags & MKV_CYCLE_MEMSET) ? MKV_SEARCH_KEEP_MISS : MKV_SEARCH_ZERO_MISS, stream);
-		if (tm)
-			(void)hipEventRecord(tm->ev[2 * slot + 1], (hipStream_t)stream);
+		rc = mkv_search_timed(geom, search_in, search_out, table, num_search,
+				(search_flags & MKV_CYCLE_MEMSET) ? MKV_SEARCH_KEEP_MISS : MKV_SEARCH_ZERO_MISS, stream,
+				tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr);
 		if (rc != MKV_OK)
 			return rc;
 	}

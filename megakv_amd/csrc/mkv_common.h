@@ -3,6 +3,7 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+#include <hip/hip_ext.h>
 #include <stdint.h>
 
 #include "megakv_hip.h"
@@ -101,6 +102,16 @@ struct Tuning {
 	                     // region-suffix fall-back
 };
 Tuning &tuning();
+
+// A launch whose start and end time are delivered into HIP events when given (the dispatch's
+// own timestamps, hipExtLaunchKernelGGL); a plain launch otherwise.
+#define MKV_LAUNCH_TIMED(kernel, grid, block, stream, e0, e1, ...)                                  \
+	do {                                                                                            \
+		if ((e0) || (e1))                                                                           \
+			hipExtLaunchKernelGGL(kernel, grid, block, 0, stream, e0, e1, 0, __VA_ARGS__);           \
+		else                                                                                        \
+			hipLaunchKernelGGL(kernel, grid, block, 0, stream, __VA_ARGS__);                         \
+	} while (0)
 
 #define MKV_HIP_TRY(expr)                                   \
 	do {                                                    \

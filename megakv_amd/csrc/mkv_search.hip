@@ -23,6 +23,8 @@
 //     CUDA kernel races there (gpu_hash.cu:56-58).
 #include <string.h>
 
+#include <hip/hip_ext.h>
+
 #include "mkv_common.h"
 #include "mkv_search_body.h"
 
@@ -54,7 +56,8 @@ __global__ __launch_bounds__(256) void k_search_lds(const uint2 *__restrict__ in
 
 template <int U>
 static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int64_t n,
-		uint32_t hash_mask, uint32_t blk_mask, uint32_t flags, bool nt, hipStream_t stream)
+		uint32_t hash_mask, uint32_t blk_mask, uint32_t flags, bool nt, hipStream_t stream, hipEvent_t e0 = nullptr,
+		hipEvent_t e1 = nullptr)
 {
 	const int64_t per_block = 4 * 16 * U;
 	const int64_t blocks = (n + per_block - 1) / per_block;
@@ -68,29 +71,29 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 		if (lblocks > 0x7fffffffLL)
 			return MKV_ETOOBIG;
 		if (zero)
-			hipLaunchKernelGGL((k_search_lds<true>), dim3((unsigned)lblocks), block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search_lds<true>), dim3((unsigned)lblocks), block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		else
-			hipLaunchKernelGGL((k_search_lds<false>), dim3((unsigned)lblocks), block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search_lds<false>), dim3((unsigned)lblocks), block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
 	if (tuning().search_wide) {
 		// (same requests per block: 4 waves x 8 x 2U)
 		if (zero)
-			hipLaunchKernelGGL((k_search_wide<U, true, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search_wide<U, true, false>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		else
-			hipLaunchKernelGGL((k_search_wide<U, false, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search_wide<U, false, false>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
 	if (zero) {
 		if (nt)
-			hipLaunchKernelGGL((k_search<U, true, true>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search<U, true, true>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		else
-			hipLaunchKernelGGL((k_search<U, true, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search<U, true, false>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 	} else {
 		if (nt)
-			hipLaunchKernelGGL((k_search<U, false, true>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search<U, false, true>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		else
-			hipLaunchKernelGGL((k_search<U, false, false>), grid, block, 0, stream, in, out, table, n, hash_mask, blk_mask);
+			MKV_LAUNCH_TIMED((k_search<U, false, false>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 	}
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
@@ -153,8 +156,18 @@ Tuning &tuning()
 
 }  // namespace mkv
 
+extern "C" int mkv_search_timed(const mkv_geom_t *geom, const selem_t *in, loc_t *out, const bucket_t *table,
+		int64_t num_elem, uint32_t flags, void *stream, void *ev_start, void *ev_stop);
+
 extern "C" int mkv_search(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 		const bucket_t *table, int64_t num_elem, uint32_t flags, void *stream)
+{
+	return mkv_search_timed(geom, in, out, table, num_elem, flags, stream, nullptr, nullptr);
+}
+
+// the same; ev_start / ev_stop (HIP events, or NULL) receive the dispatch's start and end time
+extern "C" int mkv_search_timed(const mkv_geom_t *geom, const selem_t *in, loc_t *out, const bucket_t *table,
+		int64_t num_elem, uint32_t flags, void *stream, void *ev_start, void *ev_stop)
 {
 	const mkv::Tuning &tune = mkv::tuning();
 	mkv::DevGeom d;
@@ -168,11 +181,12 @@ extern "C" int mkv_search(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
 	hipStream_t s = (hipStream_t)stream;
 	const bool nt = tune.search_nt != 0;
+	hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
 	switch (tune.search_u) {
-	case 1: return mkv::launch_search<1>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
-	case 2: return mkv::launch_search<2>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
-	case 8: return mkv::launch_search<8>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
-	default: return mkv::launch_search<4>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s);
+	case 1: return mkv::launch_search<1>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s, e0, e1);
+	case 2: return mkv::launch_search<2>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s, e0, e1);
+	case 8: return mkv::launch_search<8>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s, e0, e1);
+	default: return mkv::launch_search<4>(in2, out, t4, num_elem, d.hash_mask, d.blk_mask, flags, nt, s, e0, e1);
 	}
 }
 

@@ -66,6 +66,8 @@
 #include <mutex>
 #include <unordered_map>
 
+#include <hip/hip_ext.h>
+
 #include "mkv_common.h"
 #include "mkv_search_body.h"
 
@@ -2917,7 +2919,7 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *ta
 // with mkv_cycle_insert_end(..., joined = 0).
 extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 		const bucket_t *table, int64_t num_search, ielem_t **blk_input, int *blk_elem_num, int num_blks,
-		long long size_hint, void *stream)
+		long long size_hint, void *stream, void *ev_start, void *ev_stop)
 {
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || num_blks <= 0 || num_blks > mkv::kMaxBlocks || !blk_input ||
@@ -2951,11 +2953,15 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	uint32_t lo, hi;
 	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
 	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
+	// (ev_start / ev_stop: HIP events that receive the START and END time of this very dispatch --
+	// hipExtLaunchKernelGGL -- i.e. the kernel's duration as a profiler sees it, without the
+	// launch latency a pair of hipEventRecord calls around the launch includes)
+	hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
 	if (d.scheme == MKV_SCHEME_2CHOICE)
-		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, 0, s, in2, out, t4, num_search,
+		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
 	else
-		hipLaunchKernelGGL((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, 0, s, in2, out, t4, num_search,
+		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
@@ -3026,14 +3032,10 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	if (cap_set == 0 || !set_ptrs) {
 		// nothing to insert: plain slot search (mark_blocks = 0)
 		mkv::ReqSrc none = {};
-		if (tm)
-			(void)hipEventRecord(tm->ev[2 * slot], s);
-		hipLaunchKernelGGL((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), 0, s,
+		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), s, tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr,
 				recvbuf, slot_words, (uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks,
 				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (uint4 *)nullptr,
 				(uint8_t *)nullptr, 0u, 0u);
-		if (tm)
-			(void)hipEventRecord(tm->ev[2 * slot + 1], s);
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
 	mkv::ReqSrc src;
@@ -3059,18 +3061,15 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	mkv::chunk_range(0, ck, &lo, &hi);
 	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint);
 	const dim3 grid(search_blocks + mark_blocks), block(256);
-	if (tm)
-		(void)hipEventRecord(tm->ev[2 * slot], s);
+	hipEvent_t e0 = tm ? tm->ev[2 * slot] : nullptr, e1 = tm ? tm->ev[2 * slot + 1] : nullptr;
 	if (cuckoo)
-		hipLaunchKernelGGL((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, 0, s, recvbuf, slot_words,
+		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
 				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
 	else
-		hipLaunchKernelGGL((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, 0, s, recvbuf, slot_words,
+		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
 				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
-	if (tm)
-		(void)hipEventRecord(tm->ev[2 * slot + 1], s);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
 		mkv::chunk_range(c, ck, &lo, &hi);

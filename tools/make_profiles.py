@@ -1,11 +1,17 @@
 #!/usr/bin/env python3
-"""Turns gpurun_out/profiles_raw/<tag>/ (tools/collect_profiles.sh) into the
-committed evidence under profiles/:
-  profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --stats summary (our kernels + top others)
-  profiles/<round>_<tag>_pmc.json           per-kernel PMC averages per launch
-  profiles/search_traffic.json              HBM bytes per search launch, read by bench.py
-usage: make_profiles.py <round> <tag> <workload-key>      e.g.  r01 zipf95_mix zipf95-mix
-"""
+"""Turns gpurun_out/profiles_raw/<tag>/ (tools/collect_profiles.sh) into the committed
+evidence under profiles/:
+  profiles/<round>_<tag>_kernel_stats.csv   rocprofv3 --stats summary of the bench command as run
+  profiles/<round>_<tag>_timed_region.json  per-kernel durations of the TIMED REGION's dispatches only
+                                            (and of the launch-timing pass behind it), plus the PMC
+                                            averages per launch over the timed region's dispatches
+  profiles/search_traffic.json              HBM bytes per launch of the dominant kernel, read by bench.py
+usage: make_profiles.py <round> <tag> <workload-key> <warmup> <steps> <head>
+       e.g.  r02 default zipf95-mix 20 100 $(git rev-parse --short HEAD)
+
+A bench.py run launches the step's kernels in this order: W warm-up steps, K timed steps, then
+(after the checks) the launch-timing pass.  One step = one dispatch of the dominant kernel
+(k_search_mark), so its dispatches number W .. W+K-1 are the timed region's."""
 import collections
 import csv
 import glob
@@ -21,65 +27,106 @@ def find(raw, name, suffix):
     return max(f, key=os.path.getmtime) if f else None
 
 
+def short(n):
+    return n.split("(")[0].replace("void ", "")
+
+
+def steps_of(rows, key="k_search_mark"):
+    """indices of the rows that start a step (the dominant kernel's dispatches)"""
+    return [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
+
+
 def main():
-    rnd, tag, key = sys.argv[1], sys.argv[2], sys.argv[3]
+    rnd, tag, key, W, K, head = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
     raw = os.path.join(ROOT, "gpurun_out", "profiles_raw", tag)
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    # --- kernel stats summary
+    dom = "k_search_mark" if "get100" not in key else "k_search<"
+    # --- kernel stats summary of the command as run
     f = find(raw, "stats", "kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
     with open(os.path.join(out, f"{rnd}_{tag}_kernel_stats.csv"), "w", newline="") as fo:
         w = csv.writer(fo)
         w.writerow(["Name", "Calls", "TotalDurationNs", "AverageNs", "Percentage", "MinNs", "MaxNs", "StdDev"])
         for r in rows[:14]:
-            name = r["Name"].split("(")[0].replace("void ", "")
-            w.writerow([name, r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
+            w.writerow([short(r["Name"]), r["Calls"], r["TotalDurationNs"], r["AverageNs"], r["Percentage"], r["MinNs"],
                         r["MaxNs"], r["StdDev"]])
-    # steady-state average of the timed steps only (the stats file also holds the pre-load launches)
+    # --- the timed region's dispatches
     tr = find(raw, "stats", "kernel_trace.csv")
     trows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Start_Timestamp"]))
-    marks = [i for i, r in enumerate(trows) if "k_search" in r["Kernel_Name"]]
-    steady = collections.defaultdict(list)
-    for r in trows[marks[-100] if len(marks) >= 100 else marks[0]:]:
-        steady[r["Kernel_Name"].split("(")[0].replace("void ", "")].append(
-            (int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
-    # --- PMC per launch
-    pmc = collections.defaultdict(lambda: collections.defaultdict(list))
+    marks = steps_of(trows, dom)
+    marks_set = set(marks)
+    summary = {"round": rnd, "tag": tag, "head": head, "warmup": W, "steps": K,
+               "command": open(os.path.join(raw, "stats.err")).read()[:0] or "python3 bench.py " + " ".join(sys.argv[7:])}
+
+    cycle = ("k_search_mark", "k_search<", "k_round", "k_tail", "k_mark", "k_search_slots")
+
+    def region(lo, hi):
+        """the kernels of steps lo .. hi-1: each step = its dominant kernel's dispatch and the
+        cycle's kernels that follow it directly"""
+        agg = collections.defaultdict(list)
+        if hi > len(marks) or hi <= lo:
+            return {}
+        last_end = 0
+        for s_ in range(lo, hi):
+            i = marks[s_]
+            while i < len(trows) and (i == marks[s_] or (i not in marks_set and any(c in trows[i]["Kernel_Name"] for c in cycle))):
+                r = trows[i]
+                agg[short(r["Kernel_Name"])].append((int(r["End_Timestamp"]) - int(r["Start_Timestamp"])) / 1000.0)
+                last_end = int(r["End_Timestamp"])
+                i += 1
+        span = (last_end - int(trows[marks[lo]]["Start_Timestamp"])) / 1000.0 / (hi - lo)
+        d = {k: {"launches": len(v), "avg_us": round(sum(v) / len(v), 2), "min_us": round(min(v), 2),
+                 "max_us": round(max(v), 2)} for k, v in agg.items()}
+        d["_step_span_us"] = round(span, 2)
+        return d
+
+    summary["timed_region"] = region(W, W + K)
+    if len(marks) > W + K + 8:
+        summary["launch_timing_pass"] = region(W + K + 4, len(marks))
+    # --- PMC per launch, timed region's dispatches only
+    pmc = collections.defaultdict(dict)
     for name in ("pmc_fetch", "pmc_write", "pmc_l2"):
         f = find(raw, name, "counter_collection.csv")
         if not f:
             continue
         crow = list(csv.DictReader(open(f)))
-        # keep the steady-state launches: drop the first third of each kernel's dispatches
+        order = sorted({(int(r["Dispatch_Id"]), r["Kernel_Name"]) for r in crow})
+        ids = [d for d, k in order]
+        names = {d: k for d, k in order}
+        dmarks = [d for d in ids if dom in names[d]]
+        if len(dmarks) <= W + K:
+            continue
+        lo, hi = dmarks[W], dmarks[W + K]
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in crow:
-            if "mkv::" in r["Kernel_Name"]:
-                per[r["Kernel_Name"].split("(")[0].replace("void ", "")][r["Counter_Name"]].append(
-                    float(r["Counter_Value"]))
+            d = int(r["Dispatch_Id"])
+            if lo <= d < hi and "mkv::" in r["Kernel_Name"]:
+                per[short(r["Kernel_Name"])][r["Counter_Name"]].append(float(r["Counter_Value"]))
         for k, cs in per.items():
             for c, v in cs.items():
-                v = v[len(v) // 3:]
-                pmc[k][c] = sum(v) / max(len(v), 1)
-    summary = {"round": rnd, "tag": tag, "steady_state_avg_us": {k: round(sum(v) / len(v), 2) for k, v in steady.items()
-                                                                 if "mkv::" in k or "fill" in k.lower()},
-               "pmc_per_launch": {k: dict(v) for k, v in pmc.items()}}
-    json.dump(summary, open(os.path.join(out, f"{rnd}_{tag}_pmc.json"), "w"), indent=1)
-    # --- traffic of the dominant (search) kernel, for bench.py
-    dom = [k for k in pmc if "k_search" in k]
-    if dom:
-        k = max(dom, key=lambda x: pmc[x].get("FETCH_SIZE", 0))
+                pmc[k][c] = round(sum(v) / max(len(v), 1), 2)
+                pmc[k]["_launches"] = len(v)
+    summary["pmc_per_launch_timed_region"] = {k: dict(v) for k, v in pmc.items()}
+    name = f"{rnd}_{tag}_timed_region.json"
+    json.dump(summary, open(os.path.join(out, name), "w"), indent=1)
+    # --- traffic of the dominant kernel, for bench.py (labelled with where it came from)
+    domk = [k for k in pmc if dom.rstrip("<") in k]
+    if domk:
+        k = max(domk, key=lambda x: pmc[x].get("FETCH_SIZE", 0))
         fetch_kb, write_kb = pmc[k].get("FETCH_SIZE", 0.0), pmc[k].get("WRITE_SIZE", 0.0)
         tp = os.path.join(out, "search_traffic.json")
         d = json.load(open(tp)) if os.path.exists(tp) else {}
-        d[key] = {"kernel": k, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
-                  "hbm_bytes_per_launch": int((fetch_kb + write_kb) * 1024),
-                  "note": "FETCH_SIZE + WRITE_SIZE (KB x 1024), separate PMC passes; calibrated on uniform GETs: "
-                          "random 64-B bucket reads are tallied exactly, the coalesced request stream at one "
-                          "half (gfx950 FETCH_SIZE rule) -- see DESIGN.md 'measurement'",
-                  "l2": {c: pmc[k][c] for c in pmc[k] if c.startswith("TCC_")}, "source": f"profiles/{rnd}_{tag}_pmc.json"}
+        kern = "k_search_mark" if "k_search_mark" in k else ("k_search_slots_mark" if "slots" in k else "k_search")
+        d[f"{key}-{kern}"] = {
+            "kernel": k, "FETCH_SIZE_KB": fetch_kb, "WRITE_SIZE_KB": write_kb,
+            "hbm_bytes_per_launch": int((fetch_kb + write_kb) * 1024), "launches_averaged": pmc[k].get("_launches"),
+            "note": "FETCH_SIZE + WRITE_SIZE (KB x 1024) per launch, separate --pmc passes, the timed region's "
+                    "dispatches only; calibrated on uniform GETs: random 64-B bucket reads are tallied exactly, "
+                    "the coalesced request stream at one half (gfx950 FETCH_SIZE rule) -- DESIGN.md 'measurement'",
+            "l2": {c: pmc[k][c] for c in pmc[k] if c.startswith("TCC_")}, "source": name, "head": head}
         json.dump(d, open(tp, "w"), indent=1)
-    print(json.dumps(summary, indent=1)[:1500])
+    print(json.dumps(summary, indent=1)[:2500])
 
 
 if __name__ == "__main__":
