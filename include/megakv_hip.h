@@ -95,6 +95,12 @@ int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *stream);
 /* Frees every workspace of the calling process (device must be idle). */
 void mkv_release_all(void);
 
+/* Updates of one table issued on different streams are put in issue order (an update that
+ * finds the table's last update on another stream waits for an event recorded there).  A host
+ * that DESTROYS a stream it has updated a table on calls this first: the stream is synchronised
+ * and no longer referred to. */
+void mkv_forget_stream(void *stream);
+
 /* Diagnostics of the most recent insert/delete on `stream` (synchronises the
  * stream).  Not part of the hot path. */
 typedef struct mkv_update_info_s {
@@ -245,6 +251,30 @@ int mkv_shard_run(mkv_shard_t *e, int nbatches, const selem_t *const *gets, cons
 int mkv_shard_overflowed(mkv_shard_t *e, int *flag);   /* synchronises the device */
 const char *mkv_shard_error(const mkv_shard_t *e);
 void mkv_shard_destroy(mkv_shard_t *e);
+
+/* ---- the worker cycle as a three-stage pipeline over HOST buffers ----
+ * What the reference's scheduler does per worker and batch on one stream -- requests host ->
+ * device, search / insert, results device -> host (src/mega_scheduler.c:393-504, buffers
+ * src/mega_recv.c:120-213, src/include/mega_batch.h:74-97) -- with the three stages on three
+ * streams and `depth` sets of device buffers: the copy-in of batch i+1 and the copy-out of
+ * batch i-1 run beside the kernels of batch i (PCIe is full duplex; pinned hipMemcpyAsync runs
+ * on the DMA engines).  Results are those of the cycles run one after the other.
+ * mkv_pipe_run: gets[i] / sets[i] / outs[i] are HOST pointers (pinned: cudaHostAlloc /
+ * mkv_host_alloc), sets[i] holds the insert requests block after block with
+ * blk_counts[i][0 .. num_blks) per block; outs[i] receives n_get[i] x 2 loc_t (resolve = 0)
+ * or n_get[i] x loc_t (resolve = 1: loc = pair[0] ? pair[0] : pair[1], src/mega_send.c:408-414
+ * done on the device, which halves the copy-out).  The host separates the pipeline's steps (one
+ * synchronisation per step, as the reference's scheduler has one per cycle): the call waits for
+ * what is queued on `stream`, and RETURNS WHEN THE LAST RESULT IS IN HOST MEMORY. */
+typedef struct mkv_pipe mkv_pipe_t;
+int mkv_pipe_create(mkv_pipe_t **out, const mkv_geom_t *geom, bucket_t *table, int64_t max_get, int64_t max_set,
+		int num_blks, int depth);
+int mkv_pipe_run(mkv_pipe_t *p, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int *const *blk_counts, loc_t *const *outs, int resolve, void *stream);
+const char *mkv_pipe_error(const mkv_pipe_t *p);
+void mkv_pipe_destroy(mkv_pipe_t *p);
+void *mkv_host_alloc(int64_t bytes);    /* pinned host memory (hipHostMalloc) */
+void mkv_host_free(void *ptr);
 
 /* Tuning knobs (all but the debug ones also environment variables MKV_<NAME>, read once at start-up):
  *   search:  "search_u" (1/2/4/8 requests in flight per lane group), "search_nt" (non-temporal

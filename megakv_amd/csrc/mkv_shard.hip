@@ -212,7 +212,10 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 			if (ev) (void)hipEventDestroy(ev);
 		if (l.ev_aux_done) (void)hipEventDestroy(l.ev_aux_done);
 		if (l.aux) (void)hipStreamDestroy(l.aux);
-		if (l.stream) (void)hipStreamDestroy(l.stream);
+		if (l.stream) {
+			mkv_forget_stream(l.stream);
+			(void)hipStreamDestroy(l.stream);
+		}
 	}
 	if (e->overflow) (void)hipFree(e->overflow);
 	if (e->ev_start) (void)hipEventDestroy(e->ev_start);

@@ -3109,6 +3109,19 @@ extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 			(hipStream_t)stream);
 }
 
+// A stream is about to be destroyed (the library's own: pipeline, shard engine): it must not be
+// named as "where this table was last updated" any more -- its work is waited for here instead.
+// A host that destroys streams of its own while the library remembers them should call this
+// first (declared in megakv_hip.h).
+extern "C" void mkv_forget_stream(void *stream)
+{
+	(void)hipStreamSynchronize((hipStream_t)stream);
+	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+	for (auto &kv : mkv::g_table_order)
+		if (kv.second.any && kv.second.last == (hipStream_t)stream)
+			kv.second.any = false;
+}
+
 extern "C" int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *stream)
 {
 	mkv::DevGeom d;

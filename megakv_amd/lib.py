@@ -33,6 +33,7 @@ ABI_SYMBOLS = [
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
+    "mkv_forget_stream", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -119,6 +120,18 @@ def load_library():
     L.mkv_shard_error.argtypes = [P]
     L.mkv_shard_destroy.restype = None
     L.mkv_shard_destroy.argtypes = [P]
+    L.mkv_pipe_create.restype = INT
+    L.mkv_pipe_create.argtypes = [ctypes.POINTER(P), G, P, I64, I64, INT, INT]
+    L.mkv_pipe_run.restype = INT
+    L.mkv_pipe_run.argtypes = [P, INT, P, P, P, P, P, INT, P]
+    L.mkv_pipe_error.restype = ctypes.c_char_p
+    L.mkv_pipe_error.argtypes = [P]
+    L.mkv_pipe_destroy.restype = None
+    L.mkv_pipe_destroy.argtypes = [P]
+    L.mkv_host_alloc.restype = P
+    L.mkv_host_alloc.argtypes = [I64]
+    L.mkv_host_free.restype = None
+    L.mkv_host_free.argtypes = [P]
     L.mkv_slots_cycle.restype = INT
     L.mkv_slots_cycle.argtypes = [G, P, INT, I64, I64, P, P, P, ctypes.c_longlong, P, P, INT]
     L.mkv_derive_requests.restype = INT
