@@ -3048,10 +3048,9 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	mkv::Workspace *w = nullptr;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = mkv::order_table_updates(table, s);
-	if (rc != MKV_OK)
-		return rc;
-	rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
+	// (no ordering against other streams here: the callers of this entry point -- the sharded
+	// engines -- run the local phases of their lanes' streams in batch order with events of their own)
+	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
 	const bool cuckoo = d.scheme == MKV_SCHEME_CUCKOO;
