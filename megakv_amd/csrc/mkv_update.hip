@@ -13,50 +13,49 @@
 // touches its primary bucket P and at most its alternate bucket A, both known
 // from the request alone; only a request that finds P and A full with no
 // duplicate ("hard") walks on to data-dependent buckets of its region.
-// Requests commute unless they share P/A, so the work is done in reservation
-// rounds over a per-bucket owner table in HBM (64-bit atomicMin of
+// Requests commute unless they share a bucket, so per bucket they must run in
+// index order and nothing else has to be ordered.  The work is done in
+// reservation rounds over a per-bucket owner table in HBM (64-bit atomicMin of
 // {round stamp, canonical index}; stamps make stale entries lose, the table is
-// never cleared):
+// never cleared), committed optimistically:
 //
 //   K1 mark     every request registers on P and A (two atomics) and is copied
-//               into a 16-byte request cache so later passes do not chase the
-//               caller's block pointers again.
-//   K2 round 1  a request that owns all its buckets (no earlier pending request
-//               touches them) executes with plain loads/stores -- it has
-//               exclusive use of those buckets -- and logs what it overwrote;
-//               losers re-register for round 2 and bump a registrant count on
-//               the buckets they lost.
-//   K3 round 2  the same over the losers (without eviction chains: see below).  It also
-//               classifies them: a loser might turn hard before its turn unless it
-//               holds a duplicate or the empty slots of P and A outnumber the other
-//               registrants.
-//   barrier     hard requests, and losers that might turn hard, publish their
-//               index into a per-region minimum B: an eviction chain may reach
-//               any bucket of the region, so nothing at or beyond B may run
-//               before it.  Commits are optimistic: K4 first rolls back (from
-//               the log) every commit at or beyond the final B.
-//   K4 tail     one launch of 32 work-groups of 1024 lanes.  With something to roll
-//               back or much left, all of them share the scans over the request
-//               tags (roll-back, gather; grid-wide meetings on counters the kernel
-//               before resets); otherwise the helpers leave at once.  Work-group 0
-//               then runs further rounds over what is left (same rule, decide-then-
-//               commit with work-group barriers) -- all 32 groups when a final pass
-//               is left with a long list -- until a round would resolve less than
-//               the in-order replay does in its time; the remainder is sorted by
-//               canonical index and replayed in order per closed region, eviction
-//               chains included.
+//               into a 16-byte request cache.  A cuckoo request that looks hard
+//               in the table as it stands also registers on the buckets its chain
+//               would go on to (read-only walk): later requests of the batch on
+//               those buckets then line up behind it.
+//   K2 round 1  a request that is the lowest registrant of the buckets it needs
+//               executes with plain loads/stores and logs what it overwrote; a hard
+//               request runs its chain if every further bucket is its own or
+//               nobody's.  Losers re-register for round 2.  A hard request whose
+//               chain meets somebody else is left to the tail -- nobody waits for it.
+//   K3 round 2  the same over the losers.  Its idle lanes keep the "touched record"
+//               (per bucket: the commits of this pass that used it) when chains
+//               are running late.
+//   K4 tail     one launch of 32 work-groups of 1024 lanes (the helpers leave at
+//               once unless there is much to scan).  Reservation rounds over what
+//               is left (register / decide / commit with work-group barriers; the
+//               lowest request of a region that is hard, or might turn hard, is the
+//               round's barrier for that region: the tail never commits ahead of
+//               it, so its commits are final), then the in-order replay per region.
 //
-// "Holds a duplicate" only counts while nothing can evict that duplicate before the
-// request's turn: never for signature 0 (which matches empty slots anybody may fill);
-// in K3 because no chain runs beside the classification; in the tail's rounds only if
-// the request owns the bucket or no registrant has it as its alternate bucket (a chain
-// starts at the alternate bucket and goes on through unregistered ones).
+// Rounds 1 and 2 commit without asking whether an EARLIER pending request will
+// turn hard and walk its chain into the same bucket.  That is checked when the
+// chain walks (tail): a bucket with a later commit on its list is an order
+// violation, and exactly the commits involved -- those later ones on that
+// bucket, and what ran after them on their buckets -- are taken back from their
+// logs and run again behind the chain (select_from / take_back).
 //
-// Why this equals the canonical order: DESIGN.md, "insert: why the result is
-// the canonical one".  No host synchronisation anywhere: request counts are
-// read on the device (the reference passes them as a device array,
-// gpu_hash.cu:236-237), grids are fixed and stride over them, and the round
-// stamps live on the device so a captured hipGraph can be replayed.
+// "Holds a duplicate" only counts as "cannot turn hard" while nothing can evict
+// that duplicate before the request's turn: never for signature 0 (which matches
+// empty slots anybody may fill); only if the request owns the bucket or no
+// registrant has it as its alternate bucket; and a chain that takes a bucket
+// over from a later pending request bars that request from the round.
+//
+// Why this equals the canonical order: DESIGN.md 5.2.  No host synchronisation
+// anywhere: request counts are read on the device (the reference passes them as
+// a device array, gpu_hash.cu:236-237), grids are fixed and stride over them,
+// and the round stamps live on the device so a captured hipGraph can be replayed.
 //
 // The per-lane atomicCAS the north star suggests for slot claims is not needed:
 // exclusivity comes from the reservation, so a commit is two plain stores.
