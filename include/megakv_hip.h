@@ -289,7 +289,8 @@ void mkv_host_free(void *ptr);
  *            capacity of an update workspace);
  *   sharded: "pack_three_pass";
  *   tests:   "debug_first_stamp", "debug_skip" (1 / 2: the tail takes the general way / the
- *            region-suffix fall-back for every order violation of an eviction chain).
+ *            region-suffix fall-back for every order violation of an eviction chain; + 4: the
+ *            grid-wide rounds leave every eviction chain to the tail).
  * Results never depend on them; they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);
 

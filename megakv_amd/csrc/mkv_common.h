@@ -95,11 +95,13 @@ struct Tuning {
 	int barrier_split;      // barriers lately: cut a hinted single-chunk batch into this many chunks (1: off)
 	int grid_min;           // a final tail list longer than this runs its rounds on all work-groups of the launch
 	int calm_factor;        // chunk size multiplier while no region barrier was met lately
+	int round_blocks;       // work-groups of the round-1 / round-2 launches of an insert or delete
+	int mark_alone_blocks;  // work-groups of the stand-alone mark launch
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)
 	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)
 	int debug_skip;      // tests only (results unchanged): how the tail deals with an order violation --
 	                     // 0 as designed, 1 always the general way (resolve_violations), 2 always the
-	                     // region-suffix fall-back
+	                     // region-suffix fall-back; +4: rounds 1 and 2 leave every eviction chain to the tail
 };
 Tuning &tuning();
 

@@ -121,6 +121,8 @@ Tuning &tuning()
 		if (v.req_cap < 1024) v.req_cap = 1024;
 		v.debug_skip = 0;
 		v.debug_first_stamp = 0;
+		v.round_blocks = 512;
+		v.mark_alone_blocks = 1024;
 		s = getenv("MKV_MARK_BLOCKS");
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
@@ -239,6 +241,14 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 64)
 			return MKV_EINVAL;
 		t.tail_groups = (int)value;
+	} else if (!strcmp(name, "round_blocks")) {
+		if (value < 1 || value > 65536)
+			return MKV_EINVAL;
+		t.round_blocks = (int)value;
+	} else if (!strcmp(name, "mark_alone_blocks")) {
+		if (value < 1 || value > 65536)
+			return MKV_EINVAL;
+		t.mark_alone_blocks = (int)value;
 	} else if (!strcmp(name, "debug_first_stamp")) {
 		t.debug_first_stamp = value;
 	} else if (!strcmp(name, "debug_skip")) {

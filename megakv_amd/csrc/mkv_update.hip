@@ -87,7 +87,7 @@ constexpr int kViolCap = 128;       // order violations recorded per turn of the
 constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
 constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
                                     // launch stays free of scratch memory and calls)
-constexpr uint32_t kGridAll = 1024;
+constexpr int kDeferCap = 768;           // k_round: requests a work-group may hold back for its second phase
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 
@@ -937,7 +937,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	// many idle lanes enter round 1's commits (final by now), its losers their own as they
 	// commit -- the tail, with far fewer lanes, then need not build it.
 	// (record_hint: chains have been running late in recent calls -- one may only turn up in this round)
-	const bool record = ROUND == 2 && OP == OP_CUCKOO && (ctl->any_hard != 0u || record_hint != 0);
+	const bool record = ROUND == 2 && OP == OP_CUCKOO && (ctl->any_hard != 0u || (record_hint & 1) != 0);
+	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
 	if (ROUND == 2 && ctl->any_loser == 0u && !record)
 		return;
 	const unsigned long long tstamp = record ? ctl->tstamp_cur : 0ull;
@@ -954,50 +955,113 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
 	const uint32_t carry = ctl->carry_lo;
 	const uint32_t start = carry < lo_idx ? carry : lo_idx;
+	// Two phases per work-group.  Phase 1, every request: the reservation of P and the primary
+	// bucket; a request P can take is finished there (19 of 20 at load factor 0.5, nearly all below
+	// 0.3).  One that needs its alternate bucket -- three more dependent round trips, an eviction
+	// chain many more -- is put on a queue in LDS instead of holding up the 63 other lanes of its
+	// wave for that long in every turn of the loop; phase 2 runs the queue on adjacent lanes, once
+	// per work-group (or whenever the queue could overflow).  Nothing else changes: a queued
+	// request owns P all along, and nobody may touch A unless he owns it.
+	__shared__ uint4 s_q[kDeferCap];
+	__shared__ uint32_t s_qn;
+	if (threadIdx.x == 0)
+		s_qn = 0u;
+	__syncthreads();
 	// whole waves go round together (the re-registration folds the atomics of lanes on one
 	// bucket): the loop variable is the work-group's first index
-	for (uint32_t base = start + blockIdx.x * blockDim.x; base < count && base >= start; base += span) {
-		const uint32_t idx = base + threadIdx.x;
-		const bool in_range = idx < count;
-		// first round trip: request and its state -- independent loads
-		const uint8_t st = in_range ? state[idx] : ST_DONE;
-		const bool pending = st == (ROUND == 1 ? ST_PENDING : ST_LOSER);
-		const uint4 rc = (in_range && (ROUND == 1 || pending)) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
-		const Req r = req_of(rc);
-		const uint32_t P = r.hash & g.hash_mask;
-		const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-		const unsigned long long key = owner_key(stamp, idx);
-		// second round trip: reservation of P and the primary bucket -- independent.  The
-		// reservation of A is only read if P cannot take the request: a request needs
-		// exclusive use of exactly the buckets it touches.
-		unsigned long long oP = 0;
-		Bkt kP;
-		kP.s0 = kP.s1 = kP.l0 = kP.l1 = make_uint4(0u, 0u, 0u, 0u);
-		if (pending) {
-			oP = owner[P];
-			kP = load_bucket(table, P);
+	uint32_t base = start + blockIdx.x * blockDim.x;
+	for (bool more = base < count && base >= start; ; ) {
+		if (more) {
+			const uint32_t idx = base + threadIdx.x;
+			const bool in_range = idx < count;
+			// first round trip: request and its state -- independent loads
+			const uint8_t st = in_range ? state[idx] : ST_DONE;
+			const bool pending = st == (ROUND == 1 ? ST_PENDING : ST_LOSER);
+			const uint4 rc = (in_range && (ROUND == 1 || pending)) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
+			const Req r = req_of(rc);
+			const uint32_t P = r.hash & g.hash_mask;
+			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+			const unsigned long long key = owner_key(stamp, idx);
+			// second round trip: reservation of P and the primary bucket -- independent.  The
+			// reservation of A is only read if P cannot take the request: a request needs
+			// exclusive use of exactly the buckets it touches.
+			bool lose = false;
+			if (pending) {
+				const unsigned long long oP = owner[P];
+				const Bkt kP = load_bucket(table, P);
+				if (oP == key) {
+					Undo u;
+					u.word0 = kNoWord;
+					u.word1 = kNoWord;
+					u.old0 = 0u;
+					u.old1 = 0u;
+					if (apply_primary<OP, OP == OP_CUCKOO>(table, r, P, kP, &u)) {
+						state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
+						if (OP == OP_CUCKOO)
+							undo[idx] = u;
+						if (record)
+							enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx, ST_ROUND2, r.sig, r.hash, u);
+						ndone++;
+					} else {
+						s_q[atomicAdd(&s_qn, 1u)] = make_uint4(r.sig, r.hash, r.loc, idx);
+					}
+				} else {
+					lose = true;
+				}
+			}
+			if (ROUND == 1) {
+				// Losers register for round 2.  (Every lane comes by here.  Many in one wave mean
+				// duplicates of a hot key: their atomics on one bucket are folded; the usual two or
+				// three go one atomic each.)
+				if (__popcll(__ballot(lose)) >= 8)
+					reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
+				else if (lose)
+					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+			}
+			if (lose) {
+				state[idx] = ROUND == 1 ? ST_LOSER : ST_TAIL;
+				if (ROUND == 1)
+					ctl->any_loser = 1u;
+				else
+					ctl->any_tail = 1u;
+			}
+			base += span;
+			more = base < count && base >= start;
 		}
-		bool done = false, lose = false, to_tail = false, hard = false;
-		if (pending) {
-			if (oP == key) {
+		__syncthreads();
+		const uint32_t qn = s_qn;
+		if (more && qn + blockDim.x <= (uint32_t)kDeferCap)
+			continue;                                   // room for another turn's worth
+		// phase 2: the queued requests, one per lane
+		for (uint32_t q0 = 0; q0 < qn; q0 += blockDim.x) {
+			const uint32_t q = q0 + threadIdx.x;
+			const bool live = q < qn;
+			const uint4 e = live ? s_q[q] : make_uint4(0u, 0u, 0u, 0u);
+			Req r;
+			r.sig = e.x;
+			r.hash = e.y;
+			r.loc = e.z;
+			const uint32_t idx = e.w;
+			const uint32_t P = r.hash & g.hash_mask;
+			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+			const unsigned long long key = owner_key(stamp, idx);
+			bool done = false, hard = false;
+			if (live && (A == P || owner[A] == key)) {
 				Undo u;
 				u.word0 = kNoWord;
 				u.word1 = kNoWord;
 				u.old0 = 0u;
 				u.old1 = 0u;
 				bool chained = false;
-				done = apply_primary<OP, OP == OP_CUCKOO>(table, r, P, kP, &u);
-				if (!done && (A == P || owner[A] == key)) {
-					// P cannot take it: the alternate bucket is needed, and owned too
-					done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
-					if (OP == OP_CUCKOO && !done) {
-						// hard: P and A full without duplicate -> eviction chain
-						atomicMin(&ctl->first_hard, idx);
-						uint32_t log_slot = 0;
-						chained = try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1);
-						hard = !chained;
-						u.word0 = log_slot;
-					}
+				done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
+				if (OP == OP_CUCKOO && !done) {
+					// hard: P and A full without duplicate -> eviction chain
+					atomicMin(&ctl->first_hard, idx);
+					uint32_t log_slot = 0;
+					chained = chains_here &&
+						try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1);
+					hard = !chained;
+					u.word0 = log_slot;
 				}
 				if (done || chained) {
 					state[idx] = chained ? (ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2) : (ROUND == 1 ? ST_ROUND1 : ST_ROUND2);
@@ -1012,36 +1076,36 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					done = true;
 				}
 			}
-			if (!done) {
-				if (ROUND == 1 && !hard)
-					lose = true;
-				else
-					to_tail = true;
+			const bool lose = live && !done && ROUND == 1 && !hard;
+			const bool to_tail = live && !done && !lose;
+			if (ROUND == 1) {
+				// the hard requests left to the tail register for round 2 like the losers: they stay the
+				// lowest registrant of their buckets, nothing later passes them there in round 2
+				const bool reg = lose || (hard && to_tail);
+				if (__popcll(__ballot(reg)) >= 8)
+					reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), reg);
+				else if (reg)
+					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+			}
+			if (lose) {
+				state[idx] = ST_LOSER;
+				ctl->any_loser = 1u;
+			}
+			if (to_tail) {
+				state[idx] = ST_TAIL;
+				ctl->any_tail = 1u;
+				if (hard) {
+					ctl->any_hard = 1u;
+					atomicAdd(&ctl->hard_tail, 1u);
+				}
 			}
 		}
-		if (ROUND == 1) {
-			// Losers register for round 2 -- and so do the hard requests left to the tail: they stay
-			// the lowest registrant of their buckets, nothing later passes them there in round 2.
-			// (Every lane comes by here.  Many in one wave mean duplicates of a hot key: their
-			// atomics on one bucket are folded; the usual two or three go one atomic each.)
-			const bool reg = lose || (hard && to_tail);
-			if (__popcll(__ballot(reg)) >= 8)
-				reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), reg);
-			else if (reg)
-				reserve(owner_next, P, A, owner_key(stamp + 1, idx));
-		}
-		if (lose) {
-			state[idx] = ST_LOSER;
-			ctl->any_loser = 1u;
-		}
-		if (to_tail) {
-			state[idx] = ST_TAIL;
-			ctl->any_tail = 1u;
-			if (hard) {
-				ctl->any_hard = 1u;
-				atomicAdd(&ctl->hard_tail, 1u);
-			}
-		}
+		if (!more)
+			break;
+		__syncthreads();
+		if (threadIdx.x == 0)
+			s_qn = 0u;
+		__syncthreads();
 	}
 	count_add(ctl->committed[ROUND - 1], ndone);
 	if (record) {
@@ -2706,7 +2770,7 @@ template <Op OP>
 static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream,
 		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
-	hipLaunchKernelGGL((k_mark<OP>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, src, g,
+	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)tuning().mark_alone_blocks), dim3(256), 0, stream, w->ctl, src, g,
 			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table);
 }
 
@@ -2825,16 +2889,16 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	int tail_rounds = tuning().tail_rounds;
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
-	hipLaunchKernelGGL((k_round<OP, 1>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
+	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
-			(uint32_t)(2 * w->req_cap), 0);
-	hipLaunchKernelGGL((k_round<OP, 2>), dim3(kGridAll), dim3(256), 0, stream, w->ctl, g, table,
+			(uint32_t)(2 * w->req_cap), tuning().debug_skip & 4);
+	hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
-			(uint32_t)(2 * w->req_cap), w->record_hint);
+			(uint32_t)(2 * w->req_cap), (w->record_hint ? 1 : 0) | (tuning().debug_skip & 4));
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, tuning().debug_skip);
+			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, tuning().debug_skip & 3);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Per-call diagnostics of the insert path: pre-load to a load factor, then time
 insert batches of a given size and print the library's update info.
-usage: insert_probe.py <lf> <batch> <nbatches> [new|upd] [cuckoo|2choice]"""
+usage: insert_probe.py <lf> <batch> <nbatches> [new|upd] [cuckoo|2choice] [tuning=value ...]"""
 import os
 import sys
 import time
@@ -24,6 +24,10 @@ def main():
     sets = sys.argv[4] if len(sys.argv) > 4 else "new"
     scheme = M.SCHEME_2CHOICE if (len(sys.argv) > 5 and sys.argv[5] == "2choice") else M.SCHEME_CUCKOO
     g = M.Geometry(mem_p=30, scheme=scheme)
+    for a in sys.argv[4:]:
+        if "=" in a:
+            name, value = a.split("=")
+            assert M.lib.load_library().mkv_set_tuning(name.encode(), int(value)) == 0, a
     idx = M.HashIndex(g)
     idx.reserve(max(batch, 1 << 20) + 8)
     P = W.preload_count(30, lf)
