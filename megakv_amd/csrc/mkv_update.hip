@@ -87,6 +87,7 @@ constexpr int kViolCap = 128;       // order violations recorded per turn of the
 constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
 constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
                                     // launch stays free of scratch memory and calls)
+constexpr uint32_t kLateSticky = 16; // calls for which round 2 keeps the touched record after a call whose chains ran late
 constexpr int kDeferCap = 768;           // k_round: requests a work-group may hold back for its second phase
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
@@ -162,6 +163,7 @@ struct Ctl {
 	uint32_t tflags;                 // tail: bit 0 = a violation was recorded, bit 1 = the touched record is needed
 	uint32_t violations;             // order violations handled this call (each rolls back a region's later commits)
 	uint32_t hard_tail;              // hard requests the grid-wide rounds left to the tail this call
+	uint32_t late_score;             // > 0: chains ran late in one of the last kLateSticky calls (persists across calls)
 	unsigned long long tstamp_next;  // next stamp of the touched record (persists across calls)
 	unsigned long long tstamp_cur;   // stamp a tail launch builds its touched record with (set by round 1)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
@@ -936,8 +938,10 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	// Round 2 also keeps the touched record when round 1 has left hard requests to the tail: its
 	// many idle lanes enter round 1's commits (final by now), its losers their own as they
 	// commit -- the tail, with far fewer lanes, then need not build it.
-	// (record_hint: chains have been running late in recent calls -- one may only turn up in this round)
-	const bool record = ROUND == 2 && OP == OP_CUCKOO && (ctl->any_hard != 0u || (record_hint & 1) != 0);
+	// (chains have been running late in recent calls -- one may only turn up in this round: the tail's
+	// note in the control block, or the host's hint, which lags behind by the calls in flight)
+	const bool record = ROUND == 2 && OP == OP_CUCKOO &&
+			(ctl->any_hard != 0u || (record_hint & 1) != 0 || ctl->late_score != 0u);
 	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
 	if (ROUND == 2 && ctl->any_loser == 0u && !record)
 		return;
@@ -2062,8 +2066,7 @@ __device__ __forceinline__ void build_touched(const DevGeom &g, const uint8_t *s
 // Commits that keep their place ran on their buckets before everything taken back there -- or
 // on other buckets -- so they stand.  One lane per violation walks the lists (they are short),
 // with a stack of {bucket, index} in LDS; a commit is selected by flagging its tag ST_SELECT
-// (a plain byte store: two lanes selecting the same commit do no harm) and noting it in the
-// list `sel`.  Returns false if its stack or the list overflowed (the caller then takes back
+// and noting it in the list `sel`.  Returns false if its stack or the list overflowed (the caller then takes back
 // the whole region suffix).  Nothing is written to the table here.
 constexpr uint32_t kSelCap = 2048, kLaneStack = 24;
 
@@ -2089,7 +2092,11 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 			const uint32_t st = state[u];
 			if (!tag_logged(st))
 				continue;                           // selected already (by this lane or another), or no commit
-			state[u] = (uint8_t)(st | ST_SELECT);
+			// (the flag is set with an atomic on the tags' word: exactly one lane selects a commit,
+			// the list holds it once)
+			const uint32_t sh = (u & 3u) * 8u;
+			if ((atomicOr(reinterpret_cast<uint32_t *>(state) + (u >> 2), (uint32_t)ST_SELECT << sh) >> sh) & ST_SELECT)
+				continue;
 			const uint32_t at = atomicAdd(nsel, 1u);
 			if (at < kSelCap)
 				sel[at] = u;
@@ -2393,9 +2400,25 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			break;                                 // everything is done
 		// -- a chain met an order violation, or needs the touched record ------------------------
 		bool rebuild = (flags & kTvNeed) != 0u;
+		uint32_t relisted = kNone;                 // entries of the next work list already in glist (kNone: gather anew)
 		if (OP == OP_CUCKOO && (flags & kTvViolation)) {
 			uint32_t nseeds = ld_agent32(&ctl->vlist_n);
 			nseeds = nseeds < (uint32_t)kViolCap ? nseeds : (uint32_t)kViolCap;
+			if (in_lds) {
+				// The next work list is what this one has left plus what is taken back below -- no
+				// need to scan the tags of the whole pass for it.  The first part goes to the global
+				// list now: the LDS of the work list is about to hold the stacks.
+				if (t == 0)
+					s_left = 0;
+				__syncthreads();
+				for (uint32_t i = t; i < n2; i += blockDim.x) {
+					const uint32_t k = lkeys[i];
+					if (k != kNone && tag_pending(state[k]))
+						glist[atomicAdd(&s_left, 1u)] = k;
+				}
+				__syncthreads();
+				relisted = s_left;
+			}
 			// one lane per violation selects what has to go (select_from); the work list's LDS holds
 			// the lanes' stacks and the list of what they selected (it is gathered anew afterwards)
 			static_assert((uint32_t)kViolCap * kLaneStack * 2u + kSelCap <= (uint32_t)kSortCap, "LDS of the work list");
@@ -2431,7 +2454,15 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 					}
 					wg_sync();
 				}
+				if (relisted != kNone && !rebuild) {
+					for (uint32_t i = t; i < nsel; i += blockDim.x)
+						glist[relisted + i] = sel[i];
+					relisted += nsel;
+				} else {
+					relisted = kNone;
+				}
 			} else {
+				relisted = kNone;
 				// a stack or the list overflowed: the whole suffix of the regions concerned, and the
 				// record anew (roll_back_from also takes back what is flagged already)
 				if (t < kMaxRegions)
@@ -2466,7 +2497,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		tv.tstamp = tstamp;
 		if (rebuild)
 			build_touched(g, state, reqc, undo, chain_logs, touched, tnodes, node_base, tstamp, lo_idx, total, 0u, 1u);
-		gather_pending(state, glist, &s_n, lo_idx, total, 0u, 1u);
+		if (relisted == kNone)
+			gather_pending(state, glist, &s_n, lo_idx, total, 0u, 1u);
+		else if (t == 0)
+			s_n = relisted;
 		wg_sync();
 		MKV_PHASE(3);
 	}
@@ -2508,6 +2542,9 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		// an order violation grows with the square of the pass size); bit 1: the 40-bit round stamps
 		// are nearly used up -- the host clears the reservation tables before a later call
 		// (ensure_ws); bit 2 (sticky): a batch exceeded the workspace and was dropped
+		if (last_chunk)
+			ctl->late_score = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? kLateSticky :
+					(ctl->late_score ? ctl->late_score - 1u : 0u);
 		if (last_chunk && host_flag)
 			*host_flag = ((ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u) |
 					(ctl->stamp_base > kStampMax - kStampReserve ? 2u : 0u) |
@@ -2548,6 +2585,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
 		ctl->any_hard = 0;
 		ctl->violations = 0;
 		ctl->hard_tail = 0;
+		ctl->late_score = 0;
 		ctl->tstamp_next = 1;
 		for (int k = 0; k < 8; k++)
 			ctl->dbg[k] = 0;

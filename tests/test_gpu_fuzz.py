@@ -24,6 +24,7 @@ def _defaults():
     L.mkv_set_tuning(b"grid_min", 2048)
     L.mkv_set_tuning(b"calm_factor", 4)
     L.mkv_set_tuning(b"debug_skip", 0)
+    L.mkv_set_tuning(b"round_blocks", 512)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
@@ -99,8 +100,12 @@ def _run(seed, forced):
     L.mkv_set_tuning(b"calm_factor", int(rng2.choice([1, 4])))
     # how the tail deals with an order violation of a late eviction chain: as designed (a sole later
     # commit is taken back alone), always the general way, always the region-suffix fall-back
-    L.mkv_set_tuning(b"debug_skip", int(np.random.default_rng(11000 + seed).choice([0, 0, 1, 2])))
-    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"debug_skip"):   # bisecting aid
+    # (+ 4: rounds 1 and 2 leave every eviction chain to the tail)
+    rng3 = np.random.default_rng(11000 + seed)
+    L.mkv_set_tuning(b"debug_skip", int(rng3.choice([0, 0, 1, 2])) + int(rng3.choice([0, 0, 0, 4])))
+    # work-groups of rounds 1 and 2: few make a work-group's queue of held-back requests run over
+    L.mkv_set_tuning(b"round_blocks", int(rng3.choice([1, 3, 64, 512, 512])))
+    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"debug_skip", b"round_blocks"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
             L.mkv_set_tuning(name, int(v))

@@ -13,3 +13,6 @@ run MKV_FUZZ_TAIL_GROUPS=2 MKV_FUZZ_TAIL_ROUNDS=0 MKV_FUZZ_INSERT_CHUNK=65536
 # how order violations of late chains are taken back: always the general way / the region suffix
 run MKV_FUZZ_DEBUG_SKIP=1 MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=48
 run MKV_FUZZ_DEBUG_SKIP=2 MKV_FUZZ_TAIL_GROUPS=5 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_INSERT_CHUNK=8192
+# rounds 1 and 2 on few work-groups (their queues of held-back requests run over), every chain left to the tail
+run MKV_FUZZ_ROUND_BLOCKS=2 MKV_FUZZ_DEBUG_SKIP=4 MKV_FUZZ_TAIL_GROUPS=32
+run MKV_FUZZ_ROUND_BLOCKS=1 MKV_FUZZ_DEBUG_SKIP=0

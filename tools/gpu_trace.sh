@@ -8,8 +8,10 @@ f=$(ls $out/*/*kernel_trace.csv | head -1)
 python3 - "$f" <<'PY'
 import csv, sys
 rows = sorted(csv.DictReader(open(sys.argv[1])), key=lambda r: int(r["Start_Timestamp"]))
-marks = [i for i, r in enumerate(rows) if "k_search" in r["Kernel_Name"] or "fillBuffer" in r["Kernel_Name"]]
-# three steps from the middle of the run
+marks = [i for i, r in enumerate(rows) if "k_search_mark" in r["Kernel_Name"] or "k_search_slots_mark" in r["Kernel_Name"]]
+if not marks:       # three-call sequence: a step starts with the memset of the results (or the search)
+    marks = [i for i, r in enumerate(rows) if "fillBuffer" in r["Kernel_Name"]] or [i for i, r in enumerate(rows) if "k_search" in r["Kernel_Name"]]
+# steps from the middle of the run (the timed region, if it is longer than warm-up + the launch-timing pass)
 lo = marks[len(marks) // 2]
 prev = None
 for r in rows[lo:lo + 22]:
