@@ -257,6 +257,14 @@ __device__ __forceinline__ uint32_t loc_at(const Bkt &k, uint32_t slot)
 	return (slot & 2u) ? b : a;
 }
 
+// signature in slot `slot` of a signature row held in registers
+__device__ __forceinline__ uint32_t sig_at(const uint4 &lo, const uint4 &hi, uint32_t slot)
+{
+	const uint4 v = (slot & 4u) ? hi : lo;
+	const uint32_t a = (slot & 1u) ? v.y : v.x, b = (slot & 1u) ? v.w : v.z;
+	return (slot & 2u) ? b : a;
+}
+
 // What a commit overwrote, so it can be rolled back: up to two words
 // (word indices fit 32 bits: mem_p <= 33).
 struct Undo {
@@ -417,32 +425,6 @@ __device__ __forceinline__ bool apply_static(uint32_t *table, const Req &r, uint
 		return true;
 	}
 	return false;
-}
-
-// One request run to completion, eviction chain included (tail only).
-template <Op OP>
-__device__ void apply_serial(uint32_t *table, const DevGeom &g, const Req &r)
-{
-	const uint32_t P = r.hash & g.hash_mask;
-	const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-	if (apply_static<OP, true, false>(table, r, P, A, nullptr))
-		return;
-	// cuckoo, P and A full without duplicate (ref :357-423)
-	uint32_t sig = r.sig, loc = r.loc, b = A;
-	const uint32_t v = r.sig & 7u;          // victim slot: ORIGINAL signature (:360)
-	for (uint32_t k = 0;; k++) {
-		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
-		const uint32_t vloc = ld_agent32(table + loc_word(b, v));
-		table[sig_word(b, v)] = sig;
-		table[loc_word(b, v)] = loc;
-		if (k >= g.max_cuckoo)
-			return;                         // victim dropped (:414-423)
-		sig = vsig;
-		loc = vloc;
-		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
-		if (try_place<true, false>(table, b, sig, loc, r.sig, nullptr))
-			return;
-	}
 }
 
 __device__ __forceinline__ Req req_of(const uint4 &rc)
@@ -1171,6 +1153,22 @@ __device__ __forceinline__ bool touched_later(const Tv &tv, uint32_t b, uint32_t
 	return touched_later_who(tv, b, idx) != kNone;
 }
 
+// the same, from the head of the bucket's list (loaded by the caller beside its other accesses to the bucket)
+__device__ __forceinline__ bool touched_later_from(const Tv &tv, unsigned long long head, uint32_t idx)
+{
+	if ((head >> kNodeBits) != tv.tstamp)
+		return false;
+	uint32_t n = (uint32_t)(head & ((1ull << kNodeBits) - 1ull));
+	for (int guard = 0; n != 0u && guard < 64; guard++) {
+		const uint32_t *nw = reinterpret_cast<const uint32_t *>(tv.tnodes + (n - 1u));
+		const uint32_t who = ld_agent32(nw);
+		if (who != kNone && who > idx)
+			return true;
+		n = ld_agent32(nw + 1);
+	}
+	return false;
+}
+
 __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g, uint32_t P, uint32_t idx,
 		uint32_t bucket)
 {
@@ -1471,11 +1469,14 @@ __device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const D
 // through, the chain never returns to a bucket it already used (so the walk saw what the real
 // run will see), and no later request of this pass was COMMITTED on one of the buckets by the
 // grid-wide rounds (touched record; else: order violation, reported) -- the request may run
-// its chain in this round's commit phase if it still owns everything then (chain_still_owned:
+// its chain in this round's commit phase if it still owns everything then (run_owned_chain:
 // an earlier chain may come by after it).
 __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
-		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv, uint32_t *rbar)
+		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv, uint32_t *rbar, uint32_t vsig)
 {
+	// vsig: the signature in the victim slot of A (the caller holds A's signature row).  Every
+	// further bucket costs ONE round trip: its claim, the head of its touched list and its
+	// signature row -- which also holds the next victim -- go out together.
 	if (tv.tstamp == 0ull) {
 		atomicOr(tv.flags, kTvNeed);        // (the caller treats the request as this round's barrier)
 		return false;
@@ -1485,11 +1486,9 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 	const uint32_t v = r.sig & 7u;
 	uint32_t seen[8];
 	uint32_t nseen = 0;
-	uint32_t b = A;
 	for (uint32_t k = 0;; k++) {
 		if (k >= g.max_cuckoo)
 			return true;                            // last eviction drops its victim: no further bucket
-		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
 		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);
 		if (nb == P || nb == A) {
 			atomicAdd(tv.dbg + 7, 1u);
@@ -1501,6 +1500,9 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 				return false;
 			}
 		const unsigned long long old = atomicMin(&owner[nb], mykey);
+		const unsigned long long head = ld_agent(&tv.touched[nb]);
+		uint4 lo, hi;
+		load_sig_row<true>(table, nb, lo, hi);
 		if ((old >> kIdxBits) == stamp_field && old != mykey) {
 			if (old < mykey) {
 				atomicAdd(tv.dbg + 3, 1u);
@@ -1514,43 +1516,75 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 			atomicMin(&rbar[P >> g.region_shift], (uint32_t)(old & ((1ull << kIdxBits) - 1ull)));
 		}
 		// a later request of this pass was committed on nb by the grid-wide rounds: order violation
-		if (touched_later(tv, nb, idx)) {
+		if (touched_later_from(tv, head, idx)) {
 			report_violation(tv, g, P, idx, nb);
 			return false;
 		}
 		seen[nseen++] = nb;
-		uint4 lo, hi;
-		load_sig_row<true>(table, nb, lo, hi);
 		if (eq_mask(lo, hi, vsig) || eq_mask(lo, hi, 0u))
 			return true;                            // the victim finds a duplicate or room here
-		b = nb;
+		vsig = sig_at(lo, hi, v);
 	}
 }
 
-// Commit phase: does the request tagged CHAIN_OK still own P, A and every bucket of the walk?
-// (An earlier chain that came by after this request's claim has taken the bucket over.)
-// Buckets it owns are written by nobody else in this phase, so the walk reads what the decide
-// phase read.
-__device__ __forceinline__ bool chain_still_owned(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
-		uint32_t idx, const unsigned long long *owner, unsigned long long stamp)
+// Commit phase: the chain of a request tagged CHAIN_OK runs while it is checked that the
+// request still owns P, A and every bucket of the walk (an earlier chain that came by after
+// this request's claim has taken the bucket over) -- one round trip per bucket (its reservation, its signature row and the location of the next
+// victim go out together) instead of a read-only walk followed by the run.  A bucket is only
+// written once it is known to be the request's own, and such a bucket is written by nobody
+// else in this phase; if a later one turns out to be taken over, what was written is put
+// back from the lane's log.  The chain never returns to a bucket (walk_and_claim saw to
+// that), so each bucket reads as the walk read it.  False: nothing is changed.
+__device__ __forceinline__ bool run_owned_chain(uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
+		uint32_t idx, const unsigned long long *owner, unsigned long long stamp, const Tv &tv)
 {
 	const unsigned long long mykey = owner_key(stamp, idx);
-	if (ld_agent(&owner[P]) != mykey || (A != P && ld_agent(&owner[A]) != mykey))
+	const uint32_t v = r.sig & 7u;          // victim slot: ORIGINAL signature (ref :360)
+	const unsigned long long oP = ld_agent(&owner[P]);
+	const unsigned long long oA = A != P ? ld_agent(&owner[A]) : mykey;
+	uint32_t vsig = ld_agent32(table + sig_word(A, v));
+	uint32_t vloc = ld_agent32(table + loc_word(A, v));
+	if (oP != mykey || oA != mykey)
 		return false;
-	const uint32_t v = r.sig & 7u;
-	uint32_t b = A;
+	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
+	uint32_t n = 0;
+	uint32_t sig = r.sig, loc = r.loc, b = A;
 	for (uint32_t k = 0;; k++) {
+		const uint64_t ws = sig_word(b, v), wl = loc_word(b, v);
+		L->word[n] = (uint32_t)ws;
+		L->old[n++] = vsig;
+		L->word[n] = (uint32_t)wl;
+		L->old[n++] = vloc;
+		table[ws] = sig;
+		table[wl] = loc;
 		if (k >= g.max_cuckoo)
-			return true;
-		const uint32_t vsig = ld_agent32(table + sig_word(b, v));
-		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);
-		if (ld_agent(&owner[nb]) != mykey)
-			return false;
+			return true;                    // victim dropped (ref :414-423)
+		sig = vsig;
+		loc = vloc;
+		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (ref :334)
+		const unsigned long long ob = ld_agent(&owner[b]);
 		uint4 lo, hi;
-		load_sig_row<true>(table, nb, lo, hi);
-		if (eq_mask(lo, hi, vsig) || eq_mask(lo, hi, 0u))
+		load_sig_row<true>(table, b, lo, hi);
+		const uint32_t nloc = ld_agent32(table + loc_word(b, v));
+		if (ob != mykey) {
+			for (uint32_t i = n; i-- > 0;)
+				table[L->word[i]] = L->old[i];
+			return false;
+		}
+		const uint32_t m = eq_mask(lo, hi, sig);
+		if (m) {
+			table[loc_word(b, (uint32_t)__ffs((int)m) - 1u)] = loc;
 			return true;
-		b = nb;
+		}
+		const uint32_t e = eq_mask(lo, hi, 0u);
+		if (e) {
+			const uint32_t s2 = preferred_slot(e, r.sig);
+			table[sig_word(b, s2)] = sig;
+			table[loc_word(b, s2)] = loc;
+			return true;
+		}
+		vsig = sig_at(lo, hi, v);
+		vloc = nloc;
 	}
 }
 
@@ -1699,7 +1733,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					atomicAdd(&ctl->dbg[2], 1u);
 				if (bad && clean) {
 					// hard right now: it may still run this round if its chain is all its own
-					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar)) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar, sig_at(lo, hi, rc.x & 7u))) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
 					} else {
@@ -1750,13 +1784,12 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					atomicAdd(s_left, 1u);
 					continue;
 				} else if (st == ST_CHAIN_OK) {
-					if (!chain_still_owned(table, g, r, P, A, idx, owner, stamp)) {
+					if (!run_owned_chain(table, g, r, P, A, idx, owner, stamp, tv)) {
 						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
 						atomicAdd(s_left, 1u);
 						continue;
 					}
-					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
-					done = true;
+					done = true;                        // chain over buckets only it holds
 				} else if (st == ST_DUPW_OK) {
 					if (!commit_last_writer(table, g, emax, reqc, r, P, idx)) {
 						state[idx] = ST_TAIL;
@@ -1903,7 +1936,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 				}
 				bool bad = clean ? room == 0u : room < 1u + others;
 				if (bad && clean) {
-					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar)) {
+					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar, sig_at(lo, hi, rc.x & 7u))) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
 					}
@@ -1974,13 +2007,12 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 					my_left++;
 					continue;
 				} else if (st == ST_CHAIN_OK) {
-					if (!chain_still_owned(table, g, r, P, A, idx, owner, stamp)) {
+					if (!run_owned_chain(table, g, r, P, A, idx, owner, stamp, tv)) {
 						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
 						my_left++;
 						continue;
 					}
-					apply_serial<OP>(table, g, r);      // chain over buckets only it holds
-					done = true;
+					done = true;                        // chain over buckets only it holds
 				} else if (st == ST_DUPW_OK) {
 					if (!commit_last_writer(table, g, emax, reqc, r, P, idx)) {
 						state[idx] = ST_TAIL;
