@@ -922,6 +922,14 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	// commit -- the tail, with far fewer lanes, then need not build it.
 	// (chains have been running late in recent calls -- one may only turn up in this round: the tail's
 	// note in the control block, or the host's hint, which lags behind by the calls in flight)
+	// The first turn's request and tag are fetched before anything is known from the control block
+	// (one round trip less on the critical path of a launch that is all latency); used if the
+	// work-group's first index turns out to be what was guessed (no carried requests).
+	const uint32_t pre_base = lo_idx + blockIdx.x * blockDim.x;
+	const uint32_t pre_idx = pre_base + threadIdx.x;
+	const bool pre_ok = pre_idx < (node_base >> 1) && pre_idx >= lo_idx;      // (node_base: twice the request capacity)
+	const uint8_t pre_st = pre_ok ? state[pre_idx] : (uint8_t)ST_DONE;
+	const uint4 pre_rc = pre_ok ? reqc[pre_idx] : make_uint4(0u, 0u, 0u, 0u);
 	const bool record = ROUND == 2 && OP == OP_CUCKOO &&
 			(ctl->any_hard != 0u || (record_hint & 1) != 0 || ctl->late_score != 0u);
 	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
@@ -961,9 +969,10 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			const uint32_t idx = base + threadIdx.x;
 			const bool in_range = idx < count;
 			// first round trip: request and its state -- independent loads
-			const uint8_t st = in_range ? state[idx] : ST_DONE;
+			const bool pre = base == pre_base && pre_ok;
+			const uint8_t st = !in_range ? (uint8_t)ST_DONE : pre ? pre_st : state[idx];
 			const bool pending = st == (ROUND == 1 ? ST_PENDING : ST_LOSER);
-			const uint4 rc = (in_range && (ROUND == 1 || pending)) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
+			const uint4 rc = pre ? pre_rc : (in_range && (ROUND == 1 || pending)) ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
 			const Req r = req_of(rc);
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
