@@ -1,6 +1,8 @@
 #!/bin/bash
-# Runs on the GPU box: the bench lines behind DESIGN.md's results table -> gpurun_out/table/*.json
+# Runs on the GPU box: the bench lines behind DESIGN.md's results table -> gpurun_out/table/*.json,
+# the table itself -> gpurun_out/table/table.txt (copied to profiles/<round>_results_table.txt)
 mkdir -p gpurun_out/table
+exec > >(tee gpurun_out/table/table.txt) 2>&1
 run() { name=$1; shift; timeout 900 python3 bench.py "$@" > gpurun_out/table/$name.json 2> gpurun_out/table/$name.err; python3 - "$name" <<'PY'
 import json, sys
 n = sys.argv[1]
@@ -35,3 +37,7 @@ run supd_2c --sets upd --scheme 2choice --steps 20 --warmup 5 --no-cpu --no-pcie
 run sharded1 --force-sharded --no-cpu
 echo "-- insert only (tools/insert_probe.py: 2^19 new keys per call)"
 for lf in 0.2 0.35 0.5 0.6; do echo "LF $lf"; timeout 300 python3 tools/insert_probe.py $lf 524288 4 2>&1 | grep batch | cut -c1-230; done
+echo "-- probes (tools/probes): host-buffer copies, two-stream cycle"
+make -s -C tools/probes pcie_probe overlap_probe > /dev/null 2>&1
+timeout 300 ./tools/probes/pcie_probe 2>&1 | tee gpurun_out/table/pcie_probe.txt
+timeout 120 ./tools/probes/overlap_probe 2>&1 | tee gpurun_out/table/overlap_probe.txt
