@@ -579,6 +579,119 @@ __device__ __forceinline__ void atomic_max_dedup(unsigned long long *words, uint
 		atomicMax(&words[b], key);
 }
 
+// Work-group-wide folding of reservation atomics (grid-wide tail rounds): thousands of pending
+// SETs of a few hot keys would otherwise queue on the words of those keys' buckets -- a wave
+// folds the lanes of its first two buckets only.  The work-group gathers {bucket, smallest or
+// largest key, registrant count, alternate flag} in a small hash table in LDS (two probes; an
+// entry that finds no slot acts alone on the global word) and sends ONE set of atomics per
+// bucket and turn.  The table lives in the LDS of the work list, which grid-wide rounds keep
+// in global memory.
+constexpr int kFoldLog2 = 11;           // grid-wide tail rounds: 2048 slots for 1024 lanes x 2 buckets
+constexpr uint32_t kFoldSlots = 1u << kFoldLog2;
+constexpr int kMarkFoldLog2 = 9;        // mark pass: 512 slots for 256 lanes x 2 buckets
+constexpr int kMarkFoldBlocks = 256;    // ... for calls with at most this many insert blocks
+struct Fold {
+	uint32_t *tb;               // bucket of the slot (kNone: free)
+	uint32_t *tc;               // registrants entered (bit 31: one of them has the bucket as its alternate); may be null
+	unsigned long long *tk;     // smallest (largest) key entered
+};
+
+template <bool MAX, int LOG2>
+__device__ __forceinline__ void fold_clear(const Fold &f)
+{
+	for (uint32_t s = threadIdx.x; s < (1u << LOG2); s += blockDim.x) {
+		f.tb[s] = kNone;
+		if (f.tc)
+			f.tc[s] = 0u;
+		f.tk[s] = MAX ? 0ull : ~0ull;
+	}
+	__syncthreads();
+}
+
+// true: entered in the table; false: no slot -- the caller acts on the global words itself
+template <bool MAX, int LOG2>
+__device__ __forceinline__ bool fold_enter(const Fold &f, uint32_t b, unsigned long long key, bool count, bool alt)
+{
+	uint32_t slot = (b * 2654435761u) >> (32 - LOG2);
+	for (int probe = 0; probe < 2; probe++) {
+		const uint32_t old = atomicCAS(&f.tb[slot], kNone, b);
+		if (old == kNone || old == b) {
+			if (MAX)
+				atomicMax(&f.tk[slot], key);
+			else
+				atomicMin(&f.tk[slot], key);
+			if (count)
+				atomicAdd(&f.tc[slot], 1u);
+			if (alt)
+				atomicOr(&f.tc[slot], 0x80000000u);
+			return true;
+		}
+		slot = (slot + 1u) & ((1u << LOG2) - 1u);
+	}
+	return false;
+}
+
+// one set of atomics per occupied slot; the table is left clear (NEXT_MAX says for which use)
+template <bool MAX, bool NEXT_MAX, int LOG2>
+__device__ __forceinline__ void fold_flush(const Fold &f, unsigned long long *words, unsigned long long *cnt,
+		unsigned long long stamp)
+{
+	__syncthreads();
+	for (uint32_t s = threadIdx.x; s < (1u << LOG2); s += blockDim.x) {
+		const uint32_t b = f.tb[s];
+		if (b != kNone) {
+			if (MAX)
+				atomicMax(&words[b], f.tk[s]);
+			else
+				atomicMin(&words[b], f.tk[s]);
+			const uint32_t c = f.tc ? f.tc[s] : 0u;
+			if (c & 0x7fffffffu) {
+				atomicMax(&cnt[b], stamp << kIdxBits);   // a stale entry restarts at (stamp, 0)
+				atomicAdd(&cnt[b], (unsigned long long)(c & 0x7fffffffu));
+				if (c >> 31)
+					atomicOr(&cnt[b], kAltFlag);
+			}
+			f.tb[s] = kNone;
+			if (f.tc)
+				f.tc[s] = 0u;
+		}
+		f.tk[s] = NEXT_MAX ? 0ull : ~0ull;
+	}
+	__syncthreads();
+}
+
+// atomic_min_dedup with the fold table behind it: the lanes of a wave on the bucket of the wave's
+// first pending lane go as one entry (two peeling steps: a whole wave on one bucket -- the
+// reference's LOCAL_TEST keying -- must not queue on one LDS word either), the rest one each.
+// (Batches of distinct keys pay nothing measurable for the detour through LDS: A/B on one box,
+// tools/gpu_ab_bench.sh.)
+template <int LOG2>
+__device__ __forceinline__ void fold_min_dedup(const Fold &f, unsigned long long *owner, uint32_t b,
+		unsigned long long key, bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		unsigned long long k = same ? key : ~0ull;
+		if (__popcll(__ballot(same)) > 1) {
+			for (int off = 32; off > 0; off >>= 1) {
+				const unsigned long long o = __shfl_xor(k, off);
+				k = o < k ? o : k;
+			}
+		}
+		if ((int)(threadIdx.x & 63u) == first && !fold_enter<false, LOG2>(f, fb, k, false, false))
+			atomicMin(&owner[fb], k);
+		active = active && !same;
+	}
+	if (active && !fold_enter<false, LOG2>(f, b, key, false, false))
+		atomicMin(&owner[b], key);
+}
+
 // statistics: one atomic per wave, spread over kShards words
 __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 {
@@ -629,6 +742,19 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
 	__shared__ uint32_t s_total;
+	// Registrations of one turn of the work-group are folded per bucket (Zipf SET keys: the hot
+	// keys' buckets; the reference's LOCAL_TEST keying: one alternate bucket per region).  The
+	// table lies in the unused end of the block pointers' LDS -- the launch this rides in
+	// (k_search_mark) should not cost the search work-groups more LDS -- so a call with more
+	// than kMarkFoldBlocks insert blocks (the reference uses 8) goes without it.
+	static_assert((kMaxBlocks - kMarkFoldBlocks) * sizeof(uint32_t *) >= (12u << kMarkFoldLog2), "fold table in s_ptr");
+	const bool use_fold = src.single || src.nblk <= (uint32_t)kMarkFoldBlocks;
+	Fold fold;
+	fold.tk = reinterpret_cast<unsigned long long *>(s_ptr + kMarkFoldBlocks);
+	fold.tb = reinterpret_cast<uint32_t *>(fold.tk + (1u << kMarkFoldLog2));
+	fold.tc = nullptr;
+	if (use_fold)
+		fold_clear<false, kMarkFoldLog2>(fold);
 	const uint32_t t = threadIdx.x;
 	const uint32_t nblk = src.nblk;
 	const unsigned long long stamp = ctl->stamp_base;
@@ -726,9 +852,16 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 				A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			}
 		}
-		reserve_wave(owner, P, A, owner_key(stamp, idx), live);
+		const unsigned long long key = owner_key(stamp, idx);
+		if (use_fold) {
+			fold_min_dedup<kMarkFoldLog2>(fold, owner, P, key, live);
+			fold_min_dedup<kMarkFoldLog2>(fold, owner, A, key, live && A != P);
+			fold_flush<false, false, kMarkFoldLog2>(fold, owner, nullptr, stamp);
+		} else {
+			reserve_wave(owner, P, A, key, live);
+		}
 		if (OP == OP_CUCKOO && live && table)
-			prewalk_register(table, g, rq, P, A, owner, owner_key(stamp, idx));
+			prewalk_register(table, g, rq, P, A, owner, key);
 	}
 }
 
@@ -1848,10 +1981,12 @@ template <Op OP>
 __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
-		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip)
+		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip,
+		const Fold &fold)
 {
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
+	fold_clear<false, kFoldLog2>(fold);
 	unsigned long long tick = wall_clock64();
 	// ticks[0..7]: register, its meeting, decide, its meeting, election + meeting, commit, its meeting
 #define MKV_GTICK(k) do { const unsigned long long now_ = wall_clock64(); ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
@@ -1881,13 +2016,25 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			const bool reg = live && state[idx] != ST_DEFER;      // (a deferred request sits this round out)
-			reserve_wave(owner, P, A, owner_key(stamp, live ? idx : 0u), reg);
-			if (OP != OP_DELETE) {
-				bump_wave(cnt, P, stamp, A == P, reg);
-				bump_wave(cnt, A, stamp, true, reg && A != P);
-				if (live)
-					atomicMin(&s_rmin[P >> g.region_shift], idx);
+			// (folded per work-group: fold_enter; an entry without a slot goes alone)
+			const unsigned long long key = owner_key(stamp, live ? idx : 0u);
+			if (reg && !fold_enter<false, kFoldLog2>(fold, P, key, OP != OP_DELETE, A == P)) {
+				atomicMin(&owner[P], key);
+				if (OP != OP_DELETE) {
+					if (A == P)
+						bump_alt(cnt, P, stamp);
+					else
+						bump(cnt, P, stamp);
+				}
 			}
+			if (reg && A != P && !fold_enter<false, kFoldLog2>(fold, A, key, OP != OP_DELETE, true)) {
+				atomicMin(&owner[A], key);
+				if (OP != OP_DELETE)
+					bump_alt(cnt, A, stamp);
+			}
+			if (OP != OP_DELETE && live)
+				atomicMin(&s_rmin[P >> g.region_shift], idx);
+			fold_flush<false, false, kFoldLog2>(fold, owner, cnt, stamp);
 		}
 		__syncthreads();
 		if (OP == OP_CUCKOO && t < g.nregions && s_rmin[t] != kNone)
@@ -1969,14 +2116,27 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 			// the duplicate writers below the round's barrier elect the last one per bucket
 			// (all work-groups read the same flag: they take or skip the meeting together)
 			if (ld_agent32(&ctl->g_dupw[set])) {
+				fold_clear<true, kFoldLog2>(fold);
 				for (uint32_t base = wg * blockDim.x; base < m; base += span) {
 					const uint32_t i = base + t;
 					const uint32_t idx = i < m ? keys[i] : kNone;
 					const bool live = idx != kNone;
 					const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
-					elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift],
-							stamp, live);
+					// (elect_last_writer, its atomicMax folded per work-group)
+					bool take = live && state[idx] == ST_DUPW && idx < s_rbar[P >> g.region_shift];
+					if (take) {
+						const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
+						const uint8_t so = state[o];
+						take = so == ST_DUPW || so == ST_DUPW_OK;
+					}
+					const unsigned long long ekey = (stamp << kIdxBits) | idx;
+					if (take && !fold_enter<true, kFoldLog2>(fold, P, ekey, false, false))
+						atomicMax(&emax[P], ekey);
+					if (take)
+						state[idx] = ST_DUPW_OK;
+					fold_flush<true, true, kFoldLog2>(fold, emax, cnt, stamp);
 				}
+				fold_clear<false, kFoldLog2>(fold);
 				grid_sync_nth(&ctl->g_sync, nwg, &nth);
 				MKV_GTICK(4);
 			}
@@ -2283,7 +2443,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min,
 		int dbg_path)
 {
-	__shared__ uint32_t lkeys[kSortCap];
+	__shared__ __align__(16) uint32_t lkeys[kSortCap];
 	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
 	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
 	__shared__ uint32_t s_dflag, s_nsel;
@@ -2375,8 +2535,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		uint32_t n2 = 1;
 		if (grid_mode) {
 			uint32_t par = 0;
+			Fold fold;                             // (the work list of grid-wide rounds is the global one: its LDS is free)
+			fold.tb = lkeys;
+			fold.tc = lkeys + kFoldSlots;
+			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
+			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
 			left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin, &s_progress,
-					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total);
+					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total, fold);
 			if (wg != 0)
 				return;
 			grid_mode = false;                     // (later turns of this loop are work-group 0's alone)
