@@ -94,6 +94,7 @@ struct Tuning {
 	int barrier_sticky;     // calls for which a call that met a barrier counts as "barriers lately"
 	int barrier_split;      // barriers lately: cut a hinted single-chunk batch into this many chunks (1: off)
 	int grid_min;           // a final tail list longer than this runs its rounds on all work-groups of the launch
+	int grid_progress;      // grid-wide tail rounds go on while they resolve at least this many requests (else: in-order replay)
 	int calm_factor;        // chunk size multiplier while no region barrier was met lately
 	int round_blocks;       // work-groups of the round-1 / round-2 launches of an insert or delete
 	int mark_alone_blocks;  // work-groups of the stand-alone mark launch

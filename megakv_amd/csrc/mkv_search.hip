@@ -122,6 +122,7 @@ Tuning &tuning()
 		v.debug_skip = 0;
 		v.debug_first_stamp = 0;
 		v.round_blocks = 512;
+		v.grid_progress = 96;
 		v.mark_alone_blocks = 1024;
 		s = getenv("MKV_MARK_BLOCKS");
 		v.mark_blocks = s ? atoi(s) : 128;
@@ -233,6 +234,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 0 || value > (1ll << 30))
 			return MKV_EINVAL;
 		t.grid_min = (int)value;
+	} else if (!strcmp(name, "grid_progress")) {
+		if (value < 0 || value > (1ll << 30))
+			return MKV_EINVAL;
+		t.grid_progress = (int)value;
 	} else if (!strcmp(name, "calm_factor")) {
 		if (value < 1 || value > 64)
 			return MKV_EINVAL;

@@ -76,7 +76,7 @@ constexpr int kMaxBlocks = 1024;    // insert blocks per call
 constexpr int kMaxRegions = 32;
 constexpr int kMaxTailRounds = 48;  // in-work-group rounds of the tail
 constexpr uint32_t kMinRoundProgress = 24;   // in-work-group round: ~4 us against ~75 ns per replayed request / 8 regions
-constexpr uint32_t kMinGridProgress = 96;    // grid-wide round: ~15 us against ~200 ns per replayed request
+constexpr uint32_t kGridHandover = 1024;  // grid-wide rounds hand a list this short over to work-group 0's in-group rounds
 constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with a long list
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
 constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished requests in order without trying rounds
@@ -1982,7 +1982,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
 		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip,
-		const Fold &fold)
+		const Fold &fold, uint32_t min_progress)
 {
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
@@ -2222,7 +2222,10 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 		// time, judged over the last few (the round after a chain is often a thin one)
 		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
 		// (the flags were last written before the meeting above: every work-group reads the same)
-		if (progress == 0 || (round >= 3 && recent < kMinGridProgress) || ld_agent32(tv.flags) != 0u)
+		// (so few are left that one work-group takes them in one go: it continues alone, with barriers
+		// in place of the grid-wide meetings)
+		if (progress == 0 || (round >= 3 && recent < min_progress) || ld_agent32(tv.flags) != 0u ||
+				left <= kGridHandover)
 			break;
 	}
 	*rounds_used = used;
@@ -2440,7 +2443,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		unsigned long long *owner, unsigned long long *cnt, unsigned long long *touched, uint2 *tnodes,
 		uint32_t node_base, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
 		uint32_t *glist, int max_rounds,
-		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min,
+		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
 		int dbg_path)
 {
 	__shared__ __align__(16) uint32_t lkeys[kSortCap];
@@ -2541,13 +2544,36 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
 			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
 			left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin, &s_progress,
-					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total, fold);
+					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total, fold, grid_progress);
 			if (wg != 0)
 				return;
 			grid_mode = false;                     // (later turns of this loop are work-group 0's alone)
 			if (t == 0)
 				s_par += par;
 			__syncthreads();
+			if (left != 0 && left <= kGridHandover && max_rounds > 0 && ld_agent32(&ctl->tflags) == 0u) {
+				// handed over: what is left goes into the LDS list and through the in-group rounds
+				if (t == 0)
+					s_left = 0;
+				__syncthreads();
+				for (uint32_t i = t; i < m; i += blockDim.x) {
+					const uint32_t k = glist[i];
+					if (k != kNone)
+						lkeys[atomicAdd(&s_left, 1u)] = k;
+				}
+				__syncthreads();
+				const uint32_t m2 = s_left;
+				while (n2 < m2)
+					n2 <<= 1;
+				for (uint32_t i = m2 + t; i < n2; i += blockDim.x)
+					lkeys[i] = kNone;
+				in_lds = true;
+				rounds_total += used;
+				used = 0;
+				wg_sync();
+				left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, lkeys, m2, s_rbar, s_rmin, &s_progress,
+						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total);
+			}
 		} else {
 			// work list: LDS when it fits, else the global list it was gathered into
 			in_lds = m <= (uint32_t)kSortCap;
@@ -3142,7 +3168,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
 			w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, tuning().debug_skip & 3);
+			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

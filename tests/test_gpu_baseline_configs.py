@@ -7,7 +7,7 @@ image bit for bit.
 
   configs[1]  100 % GET, uniform keys                      (test_config1_*)
   configs[2]  95/5 GET/SET, Zipf-0.99, S-new and S-upd     (test_config2_*), K-mix and K-ref
-  configs[3]  50/50 GET/SET, Zipf-0.99, cuckoo AND 2-choice (test_config3_*)
+  configs[3]  50/50 GET/SET, Zipf-0.99, cuckoo AND 2-choice, S-new and S-upd (test_config3_*)
   + load factor 0.5 (eviction chains and their conflict handling at full size)
   configs[4]  8 shards, Zipf 95/5: 8 ranks sharing the one GPU against ONE aggregate oracle
               table (tests/sharded_check.py)
@@ -139,6 +139,15 @@ def test_config3_zipf50_both_schemes(loaded):
     """configs[3]: 50/50 GET/SET, 524 288 inserts per batch, cuckoo and two-choice."""
     st = loaded.run("zipf50", "new", 3, seed_shift=2)
     assert st["sets"] == 3 << (BATCH_LOG2 - 1)
+
+
+@pytest.mark.parametrize("loaded", [MIX, TWO], indirect=True)
+def test_config3_zipf50_updates(loaded):
+    """configs[3] with Zipf SET keys (S-upd): 524 288 SETs of 224 K distinct keys per batch --
+    300 K duplicates go through the tail's grid-wide rounds (registrations folded per
+    work-group, last-writer elections, hand-over to the in-group rounds)."""
+    st = loaded.run("zipf50", "upd", 2, seed_shift=5)
+    assert st["sets"] == 2 << (BATCH_LOG2 - 1)
 
 
 @pytest.mark.parametrize("loaded", [HALF], indirect=True)
