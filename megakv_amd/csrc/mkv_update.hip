@@ -153,6 +153,7 @@ struct Ctl {
 	uint32_t g_sync;                 // arrivals at the sync points of the tail's grid-wide rounds (monotone)
 	uint32_t g_rbar[2][kMaxRegions]; // grid-wide rounds: round barrier / lowest pending index per region,
 	uint32_t g_rmin[2][kMaxRegions]; //   two sets used alternately (the idle one is reset meanwhile)
+	uint32_t g_below[2][kMaxRegions];//   requests before the round's barrier that the round has left pending
 	uint32_t g_progress[2], g_left[2];
 	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
 	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
@@ -1417,6 +1418,7 @@ __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 	for (int k = 0; k < kMaxRegions; k++) {
 		ctl->g_rbar[0][k] = ctl->g_rbar[1][k] = kNone;
 		ctl->g_rmin[0][k] = ctl->g_rmin[1][k] = kNone;
+		ctl->g_below[0][k] = ctl->g_below[1][k] = 0u;
 		ctl->viol[k] = kNone;
 	}
 }
@@ -1783,7 +1785,7 @@ __device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom
 template <Op OP>
 __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
-		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
+		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_below, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
 		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used, const Tv &tv, uint32_t stamp_skip)
 {
 	const uint32_t t = threadIdx.x;
@@ -1796,6 +1798,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 		if (t < kMaxRegions) {
 			s_rbar[t] = kNone;
 			s_rmin[t] = kNone;
+			s_below[t] = 0u;
 		}
 		if (t == 0) {
 			*s_progress = 0;
@@ -1900,6 +1903,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			}
 		}
 		// commit
+		uint32_t my_bar = kNone;                    // list position of a round barrier this lane holds back (see below)
 		for (uint32_t i = t; i < m; i += blockDim.x) {
 			const uint32_t idx = keys[i];
 			if (idx == kNone)
@@ -1908,40 +1912,39 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
-			bool done = false;
+			const uint32_t region = P >> g.region_shift;
+			const uint32_t bar = OP != OP_DELETE ? s_rbar[region] : kNone;
+			bool done = false, settled = false;         // settled: nothing more to try this round
 			if (OP != OP_DELETE) {
-				const uint32_t region = P >> g.region_shift;
-				const uint32_t bar = s_rbar[region];
 				const uint8_t st = state[idx];
-				if (idx == bar && idx == s_rmin[region]) {
-					// first of its region: exact, alone (its chain checked against the touched record)
-					if (apply_serial_checked<OP>(table, g, r, idx, tv) != 0) {
-						atomicAdd(s_left, 1u);
-						continue;
-					}
-					done = true;
-				} else if (idx >= bar || st == ST_DUPW) {
+				if (idx == bar) {
 					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
-					atomicAdd(s_left, 1u);
-					continue;
-				} else if (st == ST_CHAIN_OK) {
-					if (!run_owned_chain(table, g, r, P, A, idx, owner, stamp, tv)) {
-						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
-						atomicAdd(s_left, 1u);
+					if (idx == s_rmin[region]) {
+						// first of its region: exact, alone (its chain checked against the touched record)
+						done = apply_serial_checked<OP>(table, g, r, idx, tv) == 0;
+					} else if (my_bar == kNone) {
+						my_bar = i;                         // its turn may come at the end of this round
 						continue;
 					}
-					done = true;                        // chain over buckets only it holds
-				} else if (st == ST_DUPW_OK) {
-					if (!commit_last_writer(table, g, emax, reqc, r, P, idx)) {
+					settled = true;
+				} else if (idx > bar || st == ST_DUPW) {
+					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
-						atomicAdd(s_left, 1u);
-						continue;
-					}
-					done = true;
+					settled = true;
+				} else if (st == ST_CHAIN_OK) {
+					done = run_owned_chain(table, g, r, P, A, idx, owner, stamp, tv);   // chain over buckets only it holds
+					if (!done)
+						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
+					settled = true;
+				} else if (st == ST_DUPW_OK) {
+					done = commit_last_writer(table, g, emax, reqc, r, P, idx) != 0;
+					if (!done)
+						state[idx] = ST_TAIL;
+					settled = true;
 				}
 			}
-			if (!done && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
+			if (!settled && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
 				done = apply_static<OP, true, false>(table, r, P, A, nullptr);
 			if (done) {
 				state[idx] = ST_DONE;
@@ -1949,6 +1952,26 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				atomicAdd(s_progress, 1u);
 			} else {
 				atomicAdd(s_left, 1u);
+				if (idx < bar)
+					atomicAdd(&s_below[region], 1u);
+			}
+		}
+		if (OP != OP_DELETE) {
+			// The round's barrier of a region -- hard, or not provably harmless -- has had to wait for
+			// the requests before it.  If they are all through now, it is the first pending request of
+			// its region: it runs exactly, alone, at the end of this round instead of the next.
+			wg_sync();
+			if (my_bar != kNone) {
+				const uint32_t idx = keys[my_bar];
+				const Req r = req_of(reqc[idx]);
+				const uint32_t region = (r.hash & g.hash_mask) >> g.region_shift;
+				if (s_below[region] == 0u && apply_serial_checked<OP>(table, g, r, idx, tv) == 0) {
+					state[idx] = ST_DONE;
+					keys[my_bar] = kNone;
+					atomicAdd(s_progress, 1u);
+				} else {
+					atomicAdd(s_left, 1u);
+				}
 			}
 		}
 		wg_sync();
@@ -1980,7 +2003,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 template <Op OP>
 __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
-		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
+		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_below, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
 		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip,
 		const Fold &fold, uint32_t min_progress)
 {
@@ -2000,6 +2023,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 		if (t < kMaxRegions) {
 			s_rbar[t] = kNone;
 			s_rmin[t] = kNone;
+			s_below[t] = 0u;
 		}
 		if (t == 0) {
 			*s_progress = 0;
@@ -2145,11 +2169,13 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 		if (wg == 0 && t < kMaxRegions) {
 			ctl->g_rbar[set ^ 1u][t] = kNone;
 			ctl->g_rmin[set ^ 1u][t] = kNone;
+			ctl->g_below[set ^ 1u][t] = 0u;
 			if (t == 0)
 				ctl->g_progress[set ^ 1u] = ctl->g_left[set ^ 1u] = ctl->g_dupw[set ^ 1u] = 0;
 		}
 		// commit
 		uint32_t my_done = 0, my_left = 0;
+		uint32_t my_bar = kNone;                    // list position of a round barrier this lane holds back (see below)
 		for (uint32_t i = first; i < m; i += span) {
 			const uint32_t idx = keys[i];
 			if (idx == kNone)
@@ -2158,46 +2184,76 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
-			bool done = false;
+			const uint32_t region = P >> g.region_shift;
+			const uint32_t bar = OP != OP_DELETE ? s_rbar[region] : kNone;
+			bool done = false, settled = false;         // settled: nothing more to try this round
 			if (OP != OP_DELETE) {
-				const uint32_t region = P >> g.region_shift;
-				const uint32_t bar = s_rbar[region];
 				const uint8_t st = state[idx];
-				if (idx == bar && idx == s_rmin[region]) {
-					// first of its region: exact, alone (its chain checked against the touched record)
-					if (apply_serial_checked<OP>(table, g, r, idx, tv) != 0) {
-						my_left++;
-						continue;
-					}
-					done = true;
-				} else if (idx >= bar || st == ST_DUPW) {
+				if (idx == bar) {
 					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
-					my_left++;
-					continue;
-				} else if (st == ST_CHAIN_OK) {
-					if (!run_owned_chain(table, g, r, P, A, idx, owner, stamp, tv)) {
-						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
-						my_left++;
+					if (idx == s_rmin[region]) {
+						// first of its region: exact, alone (its chain checked against the touched record)
+						done = apply_serial_checked<OP>(table, g, r, idx, tv) == 0;
+					} else if (my_bar == kNone) {
+						my_bar = i;                         // its turn may come at the end of this round
 						continue;
 					}
-					done = true;                        // chain over buckets only it holds
-				} else if (st == ST_DUPW_OK) {
-					if (!commit_last_writer(table, g, emax, reqc, r, P, idx)) {
+					settled = true;
+				} else if (idx > bar || st == ST_DUPW) {
+					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
-						my_left++;
-						continue;
-					}
-					done = true;
+					settled = true;
+				} else if (st == ST_CHAIN_OK) {
+					done = run_owned_chain(table, g, r, P, A, idx, owner, stamp, tv);   // chain over buckets only it holds
+					if (!done)
+						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
+					settled = true;
+				} else if (st == ST_DUPW_OK) {
+					done = commit_last_writer(table, g, emax, reqc, r, P, idx) != 0;
+					if (!done)
+						state[idx] = ST_TAIL;
+					settled = true;
 				}
 			}
-			if (!done && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
+			if (!settled && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
 				done = apply_static<OP, true, false>(table, r, P, A, nullptr);
 			if (done) {
 				state[idx] = ST_DONE;
 				keys[i] = kNone;
 				my_done++;
 			} else {
+				my_left++;
+				if (idx < bar)
+					atomicAdd(&s_below[region], 1u);
+			}
+		}
+		if (OP != OP_DELETE) {
+			// The round's barrier of a region has had to wait for the requests before it; if they
+			// are all through now it is the first pending request of its region and runs exactly,
+			// alone, at the end of this round instead of the next.  (One more meeting -- taken by
+			// all work-groups or none: they hold the same barriers and minima.)
+			bool late_bar = false;
+			for (uint32_t k = 0; k < g.nregions; k++)
+				late_bar = late_bar || (s_rbar[k] != kNone && s_rbar[k] != s_rmin[k]);
+			if (late_bar) {
+				__syncthreads();
+				if (t < g.nregions && s_below[t])
+					atomicAdd(&ctl->g_below[set][t], s_below[t]);
+				grid_sync_nth(&ctl->g_sync, nwg, &nth);
+				if (my_bar != kNone) {
+					const uint32_t idx = keys[my_bar];
+					const Req r = req_of(reqc[idx]);
+					const uint32_t region = (r.hash & g.hash_mask) >> g.region_shift;
+					if (ld_agent32(&ctl->g_below[set][region]) == 0u && apply_serial_checked<OP>(table, g, r, idx, tv) == 0) {
+						state[idx] = ST_DONE;
+						keys[my_bar] = kNone;
+						my_done++;
+					} else {
+						my_left++;
+					}
+				}
+			} else if (my_bar != kNone) {
 				my_left++;
 			}
 		}
@@ -2452,6 +2508,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ uint32_t s_dflag, s_nsel;
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
+	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
 	__shared__ unsigned long long s_tstamp;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
@@ -2543,7 +2600,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			fold.tc = lkeys + kFoldSlots;
 			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
 			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
-			left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin, &s_progress,
+			left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin, s_below, &s_progress,
 					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total, fold, grid_progress);
 			if (wg != 0)
 				return;
@@ -2571,7 +2628,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				rounds_total += used;
 				used = 0;
 				wg_sync();
-				left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, lkeys, m2, s_rbar, s_rmin, &s_progress,
+				left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, lkeys, m2, s_rbar, s_rmin, s_below, &s_progress,
 						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total);
 			}
 		} else {
@@ -2588,7 +2645,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			}
 			wg_sync();
 			// a handful of requests: the in-order replay is done before a round would be
-			left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin, &s_progress,
+			left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
 					&s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &used, tv, rounds_total);
 		}
 		rounds_total += used;
