@@ -285,8 +285,11 @@ void mkv_host_free(void *ptr);
  *            the tail launch, 1..64), "grid_min" (a final tail list longer than this runs its
  *            rounds on all of them), "insert_chunk" (requests per pass of a hinted insert),
  *            "calm_factor" (passes that many times larger while no barrier was met lately),
- *            "barrier_sticky", "barrier_split", "mark_blocks", "req_cap" (default request
- *            capacity of an update workspace);
+ *            "barrier_sticky", "barrier_split", "mark_blocks" (mark work-groups inside the fused
+ *            search launch), "mark_alone_blocks" (of a mark launch of its own), "round_blocks"
+ *            (work-groups of rounds 1 and 2; 512: more lanes in flight were slower),
+ *            "grid_progress" (grid-wide tail rounds go on while they resolve at least this many
+ *            requests), "req_cap" (default request capacity of an update workspace);
  *   sharded: "pack_three_pass";
  *   tests:   "debug_first_stamp", "debug_skip" (1 / 2: the tail takes the general way / the
  *            region-suffix fall-back for every order violation of an eviction chain; + 4: the

@@ -34,6 +34,8 @@ run lf05 --lf 0.5 --no-cpu --no-pcie
 run lf085 --lf 0.85 --steps 40 --no-cpu --no-pcie
 run supd --sets upd --steps 20 --warmup 5 --no-cpu --no-pcie
 run supd_2c --sets upd --scheme 2choice --steps 20 --warmup 5 --no-cpu --no-pcie
+run z50_upd --workload zipf50 --sets upd --steps 10 --warmup 3 --no-cpu --no-pcie
+run z50_upd_2c --workload zipf50 --sets upd --scheme 2choice --steps 10 --warmup 3 --no-cpu --no-pcie
 run sharded1 --force-sharded --no-cpu
 echo "-- insert only (tools/insert_probe.py: 2^19 new keys per call)"
 for lf in 0.2 0.35 0.5 0.6; do echo "LF $lf"; timeout 300 python3 tools/insert_probe.py $lf 524288 4 2>&1 | grep batch | cut -c1-230; done
