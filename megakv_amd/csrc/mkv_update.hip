@@ -466,6 +466,16 @@ __device__ __forceinline__ bool alt_of(unsigned long long v, unsigned long long 
 	return (v >> kIdxBits) == stamp && (v & kAltFlag) != 0ull;
 }
 
+// Tail rounds also keep, per bucket, the LOWEST index among the registrants that have it as their
+// alternate bucket (same keys as the reservations, in the table round 2 used): only a request
+// BEFORE idx can evict from the bucket before idx's turn.
+__device__ __forceinline__ bool alt_before(const unsigned long long *altmin, uint32_t b, unsigned long long stamp,
+		uint32_t idx)
+{
+	const unsigned long long v = __hip_atomic_load(&altmin[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+	return (v >> kIdxBits) == kStampMax - stamp && (uint32_t)(v & ((1ull << kIdxBits) - 1ull)) <= idx;
+}
+
 // owner key of request idx in the round stamped `stamp`: newer rounds compare lower
 __device__ __forceinline__ unsigned long long owner_key(unsigned long long stamp, uint32_t idx)
 {
@@ -1784,7 +1794,7 @@ __device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom
 // Returns the number of requests still pending.
 template <Op OP>
 __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
-		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
+		unsigned long long *cnt, unsigned long long *altmin, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_below, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
 		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used, const Tv &tv, uint32_t stamp_skip)
 {
@@ -1820,6 +1830,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			if (OP != OP_DELETE) {
 				bump_wave(cnt, P, stamp, A == P, reg);
 				bump_wave(cnt, A, stamp, true, reg && A != P);
+				atomic_min_dedup(altmin, A, owner_key(stamp, live ? idx : 0u), reg);
 				if (live)
 					atomicMin(&s_rmin[P >> g.region_shift], idx);
 			}
@@ -1853,8 +1864,9 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				// A duplicate only counts while nothing can evict it before this request's turn
 				// (and never for signature 0, which "matches" empty slots anybody may fill):
 				// the request owns the bucket (every other registrant comes later), or no
-				// registrant has the bucket as its alternate.
-				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp))) {
+				// registrant BEFORE it has the bucket as its alternate (a later one does not own
+				// the bucket while this request is registered on it).
+				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_before(altmin, P, stamp, idx))) {
 					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
 					*s_dupw = 1u;
 					continue;
@@ -2002,7 +2014,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 // same totals after the third and so leave the loop together.
 template <Op OP>
 __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
-		unsigned long long *cnt, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
+		unsigned long long *cnt, unsigned long long *altmin, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_below, uint32_t *s_progress, uint32_t *s_left, uint32_t *s_dupw,
 		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip,
 		const Fold &fold, uint32_t min_progress)
@@ -2059,6 +2071,12 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 			if (OP != OP_DELETE && live)
 				atomicMin(&s_rmin[P >> g.region_shift], idx);
 			fold_flush<false, false, kFoldLog2>(fold, owner, cnt, stamp);
+			if (OP != OP_DELETE) {
+				// the lowest registrant that has the bucket as its alternate (alt_before)
+				if (reg && !fold_enter<false, kFoldLog2>(fold, A, key, false, false))
+					atomicMin(&altmin[A], key);
+				fold_flush<false, false, kFoldLog2>(fold, altmin, cnt, stamp);
+			}
 		}
 		__syncthreads();
 		if (OP == OP_CUCKOO && t < g.nregions && s_rmin[t] != kNone)
@@ -2094,8 +2112,9 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 				// A duplicate only counts while nothing can evict it before this request's turn
 				// (and never for signature 0, which "matches" empty slots anybody may fill):
 				// the request owns the bucket (every other registrant comes later), or no
-				// registrant has the bucket as its alternate.
-				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_of(cP, stamp))) {
+				// registrant BEFORE it has the bucket as its alternate (a later one does not own
+				// the bucket while this request is registered on it).
+				if (rc.x != 0u && eq_mask(lo, hi, rc.x) && (ownP || !alt_before(altmin, P, stamp, idx))) {
 					state[idx] = ST_DUPW;                   // a pure loc write: see elect_last_writer
 					*s_dupw = 1u;
 					continue;
@@ -2496,8 +2515,8 @@ __device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *l
 // the launch roll back the later commits of that region and take them on as well.
 template <Op OP>
 __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
-		unsigned long long *owner, unsigned long long *cnt, unsigned long long *touched, uint2 *tnodes,
-		uint32_t node_base, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
+		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, unsigned long long *touched,
+		uint2 *tnodes, uint32_t node_base, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
 		uint32_t *glist, int max_rounds,
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
 		int dbg_path)
@@ -2600,7 +2619,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			fold.tc = lkeys + kFoldSlots;
 			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
 			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
-			left = grid_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, glist, m, s_rbar, s_rmin, s_below, &s_progress,
+			left = grid_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, glist, m, s_rbar, s_rmin, s_below, &s_progress,
 					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total, fold, grid_progress);
 			if (wg != 0)
 				return;
@@ -2628,7 +2647,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				rounds_total += used;
 				used = 0;
 				wg_sync();
-				left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, lkeys, m2, s_rbar, s_rmin, s_below, &s_progress,
+				left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, lkeys, m2, s_rbar, s_rmin, s_below, &s_progress,
 						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total);
 			}
 		} else {
@@ -2645,7 +2664,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			}
 			wg_sync();
 			// a handful of requests: the in-order replay is done before a round would be
-			left = tail_rounds<OP>(ctl, g, table, owner, cnt, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
+			left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
 					&s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &used, tv, rounds_total);
 		}
 		rounds_total += used;
@@ -3223,7 +3242,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
 			(uint32_t)(2 * w->req_cap), (w->record_hint ? 1 : 0) | (tuning().debug_skip & 4));
 	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
-			w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+			w->owner[1], w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
