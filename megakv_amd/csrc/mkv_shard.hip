@@ -50,6 +50,7 @@ struct Lane {
 	int32_t *perm2[2] = {nullptr, nullptr};
 	hipEvent_t ev_xchg[2] = {nullptr, nullptr};    // the exchange that carried the lane's requests is done
 	hipEvent_t ev_pack[2] = {nullptr, nullptr};    // the lane's next batch is packed
+	hipEvent_t ev_recv[2] = {nullptr, nullptr};    // the lane's requests have arrived (and its result slots are read)
 	hipEvent_t ev_aux_done = nullptr;
 };
 
@@ -68,6 +69,9 @@ struct mkv_shard {
 	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
 	Lane lane[4];
 	hipEvent_t ev_start = nullptr;
+	hipStream_t cstream = nullptr;  // fused schedule: every local phase, one after the other (no hand-over between streams)
+	hipEvent_t ev_cdone = nullptr;
+	int one_compute_stream = 0;     // MKV_SHARD_CSTREAM=1
 	Rccl api;
 	ncclComm_t comm = nullptr;
 	char err[256] = {0};
@@ -210,6 +214,8 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 			if (ev) (void)hipEventDestroy(ev);
 		for (hipEvent_t ev : l.ev_pack)
 			if (ev) (void)hipEventDestroy(ev);
+		for (hipEvent_t ev : l.ev_recv)
+			if (ev) (void)hipEventDestroy(ev);
 		if (l.ev_aux_done) (void)hipEventDestroy(l.ev_aux_done);
 		if (l.aux) (void)hipStreamDestroy(l.aux);
 		if (l.stream) {
@@ -219,6 +225,11 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 	}
 	if (e->overflow) (void)hipFree(e->overflow);
 	if (e->ev_start) (void)hipEventDestroy(e->ev_start);
+	if (e->ev_cdone) (void)hipEventDestroy(e->ev_cdone);
+	if (e->cstream) {
+		mkv_forget_stream(e->cstream);
+		(void)hipStreamDestroy(e->cstream);
+	}
 	// the RCCL handle stays open: the host framework usually holds the same library
 	delete e;
 }
@@ -259,6 +270,8 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	e->fused = world > 1;
 	if (const char *v = getenv("MKV_SHARD_FUSED"))
 		e->fused = atoi(v) != 0;
+	if (const char *v = getenv("MKV_SHARD_CSTREAM"))
+		e->one_compute_stream = atoi(v) != 0;
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
 	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
 
@@ -321,12 +334,21 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		for (hipEvent_t &ev : l.ev_pack)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+		for (hipEvent_t &ev : l.ev_recv)
+			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		SH_HIP(e, hipEventCreateWithFlags(&l.ev_aux_done, hipEventDisableTiming));
 		if (cap_set) {
 			const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, l.stream);
 			if (rc != MKV_OK)
 				return fail(e, rc, "mkv_reserve", nullptr);
 		}
+	}
+	SH_HIP(e, hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+	SH_HIP(e, hipEventCreateWithFlags(&e->ev_cdone, hipEventDisableTiming));
+	if (cap_set && e->one_compute_stream) {
+		const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, e->cstream);
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_reserve", nullptr);
 	}
 	SH_HIP(e, hipDeviceSynchronize());
 	return MKV_OK;
@@ -440,53 +462,68 @@ static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, hipStream_t main, void *timer,
 		int timer_every, int trace_from)
 {
+	const int L = e->nlanes;                          // batches in flight
 	SH_HIP(e, hipEventRecord(e->ev_start, main));
-	for (int li = 0; li < 2; li++) {
+	for (int li = 0; li < L; li++) {
 		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
 		SH_HIP(e, hipStreamWaitEvent(e->lane[li].aux, e->ev_start, 0));
 	}
+	// MKV_SHARD_CSTREAM=1: the local phases -- which update ONE table in batch order -- run on a
+	// stream of their own instead of the lanes' streams chained by events (a hand-over between
+	// streams costs 10 - 14 us here, once per batch, on the critical path); what a local phase
+	// then waits for is the exchange that brought its requests, L - 1 local phases earlier.
+	const bool cs = e->one_compute_stream != 0;
+	hipStream_t C = e->cstream;
+	if (cs)
+		SH_HIP(e, hipStreamWaitEvent(C, e->ev_start, 0));
 	auto pack = [&](Lane &l, int j, hipStream_t s, int lane, bool tr) -> int {
 		if (n_get[j] > e->n_get || n_set[j] > e->n_set)
 			return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
 		Span sp("pack", lane, j, s, tr);
 		const int rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world,
-				l.sendbuf, e->cap_get, e->cap_set, l.perm2[(j / 2) & 1], l.scratch, e->scratch_bytes, e->overflow, s);
+				l.sendbuf, e->cap_get, e->cap_set, l.perm2[(j / L) & 1], l.scratch, e->scratch_bytes, e->overflow, s);
 		return rc == MKV_OK ? MKV_OK : fail(e, rc, "mkv_pack_requests", nullptr);
 	};
 	int rc = MKV_OK;
-	for (int j = 0; j < 2 && j < nbatches; j++) {
+	for (int j = 0; j < L && j < nbatches; j++) {
 		Lane &l = e->lane[j];
 		if ((rc = pack(l, j, l.stream, j, false)) != MKV_OK)
 			return rc;
 		SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
 		SH_HIP(e, hipEventRecord(l.ev_xchg[0], l.stream));
+		SH_HIP(e, hipEventRecord(l.ev_recv[0], l.stream));
 	}
 	hipEvent_t prev_local = nullptr;
 	for (int i = 0; i < nbatches; i++) {
-		Lane &l = e->lane[i & 1];
-		const int lane = i & 1, k = (i / 2) & 1, k2 = k ^ 1;
+		Lane &l = e->lane[i % L];
+		const int lane = i % L, k = (i / L) & 1, k2 = k ^ 1;
 		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
-		const bool more = i + 2 < nbatches;
+		const bool more = i + L < nbatches;
 		if (more) {
 			// the lane's send buffers are free once the exchange that carried batch i is done
 			SH_HIP(e, hipStreamWaitEvent(l.aux, l.ev_xchg[k], 0));
-			if ((rc = pack(l, i + 2, l.aux, lane, tr)) != MKV_OK)
+			if ((rc = pack(l, i + L, l.aux, lane, tr)) != MKV_OK)
 				return rc;
 			SH_HIP(e, hipEventRecord(l.ev_pack[k2], l.aux));
 		}
-		if (prev_local)
+		hipStream_t ls = cs ? C : l.stream;           // where this batch's local phase runs
+		if (cs)
+			SH_HIP(e, hipStreamWaitEvent(C, l.ev_recv[k], 0));   // requests in recvbuf, result slots of batch i-L sent
+		else if (prev_local)
 			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
 		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
 		{
-			Span sp("local", lane, i, l.stream, tr);
+			Span sp("local", lane, i, ls, tr);
 			rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
-					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, l.stream, timed ? timer : nullptr,
+					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, ls, timed ? timer : nullptr,
 					timed ? i / timer_every : 0);
 		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_slots_cycle", nullptr);
 		prev_local = l.ev_local[k];
-		SH_HIP(e, hipEventRecord(prev_local, l.stream));
+		SH_HIP(e, hipEventRecord(prev_local, ls));
+		if (cs)
+			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
 		if (more)
 			SH_HIP(e, hipStreamWaitEvent(l.stream, l.ev_pack[k2], 0));
 		{
@@ -501,6 +538,7 @@ static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 			SH_NCCL(e, r2);
 			fake_xfer(l.stream);
 		}
+		SH_HIP(e, hipEventRecord(l.ev_recv[k2], l.stream));
 		{
 			Span sp("unpack", lane, i, l.stream, tr);
 			rc = mkv_unpack_results(l.back_slots, l.perm2[k], n_get[i], outs[i], l.stream);
@@ -512,12 +550,16 @@ static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 		// and the send buffer, which the exchange above has read.
 		SH_HIP(e, hipEventRecord(l.ev_xchg[k2], l.stream));
 	}
-	for (int li = 0; li < 2; li++) {
+	for (int li = 0; li < L; li++) {
 		Lane &l = e->lane[li];
 		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
 		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
 		SH_HIP(e, hipEventRecord(l.ev_aux_done, l.aux));
 		SH_HIP(e, hipStreamWaitEvent(main, l.ev_aux_done, 0));
+	}
+	if (cs) {
+		SH_HIP(e, hipEventRecord(e->ev_cdone, C));
+		SH_HIP(e, hipStreamWaitEvent(main, e->ev_cdone, 0));
 	}
 	return MKV_OK;
 }
@@ -544,7 +586,7 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	const int trace_from = g_trace.on > 0 && nbatches > g_trace.on + 16 ? nbatches - g_trace.on - 8 : nbatches + 1;
 	g_trace.n = 0;
 	int rc = MKV_OK;
-	if (e->fused && L == 2) {
+	if (e->fused) {
 		rc = run_fused(e, nbatches, gets, n_get, sets, n_set, outs, main, timer, timer_every, trace_from);
 		if (rc == MKV_OK)
 			print_trace();
