@@ -127,11 +127,13 @@ def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
         sh.native.close()
 
 
-@pytest.mark.parametrize("world,fused,scheme", [(4, 1, 0), (4, 0, 0), (8, 1, 0), (2, 1, 1)])
-def test_native_engine_schedule_with_several_slots(world, fused, scheme, monkeypatch):
+@pytest.mark.parametrize("world,fused,scheme,lanes,cstream", [(4, 1, 0, 2, 0), (4, 0, 0, 2, 0), (8, 1, 0, 2, 0), (2, 1, 1, 2, 0),
+                                                              (4, 1, 0, 3, 0), (4, 1, 0, 2, 1), (2, 1, 0, 4, 1), (4, 0, 0, 3, 0)])
+def test_native_engine_schedule_with_several_slots(world, fused, scheme, lanes, cstream, monkeypatch):
     """The C engine's W-rank schedules (run_fused: one grouped exchange per batch, packs on
     a stream of their own into alternating `where` arrays; and the plain two-lane one) with
-    every peer looped back to this process: W slots per batch, a different `where` array for
+    every peer looped back to this process (two to four batches in flight, local phases on the
+    lanes' streams or on one of their own): W slots per batch, a different `where` array for
     every batch, batches of different sizes, results of EVERY batch and the final table
     against the oracle (canonical order of the local table = slot, then batch index).  Wrong
     event placement between un-pack and the pack two batches on shows here."""
@@ -141,6 +143,8 @@ def test_native_engine_schedule_with_several_slots(world, fused, scheme, monkeyp
     from oracle import oracle as O
     late_imports()
     monkeypatch.setenv("MKV_SHARD_FUSED", str(fused))
+    monkeypatch.setenv("MKV_SHARD_LANES", str(lanes))          # batches in flight
+    monkeypatch.setenv("MKV_SHARD_CSTREAM", str(cstream))      # local phases on a stream of their own
     mem_p = 18
     k = world.bit_length() - 1
     rng = np.random.default_rng(500 + world + fused)
