@@ -7,6 +7,7 @@
 // Time per step over 300 steps on one stream.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <chrono>
 #define CK(x) do { hipError_t e_ = (x); if (e_ != hipSuccess) { printf("%s: %s\n", #x, hipGetErrorString(e_)); return 1; } } while (0)
 __device__ __forceinline__ unsigned mix(unsigned x) { x ^= x >> 16; x *= 0x7feb352du; x ^= x >> 15; x *= 0x846ca68bu; x ^= x >> 16; return x; }
@@ -57,7 +58,7 @@ __global__ __launch_bounds__(1024) void k_third(const unsigned *tab, unsigned ma
 static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 int main()
 {
-	const unsigned words = 1u << 26, n = 52428;
+	const unsigned words = (getenv("PROBE_WORDS_LOG2") ? 1u << atoi(getenv("PROBE_WORDS_LOG2")) : 1u << 26), n = 52428;
 	unsigned *tab, *out, *counter, *busy;
 	CK(hipMalloc(&tab, (size_t)words * 4)); CK(hipMemset(tab, 1, (size_t)words * 4));
 	CK(hipMalloc(&out, (n + 4096) * 4)); CK(hipMalloc(&counter, 4)); CK(hipMemset(counter, 0, 4));
