@@ -57,6 +57,9 @@ def parse(argv=None):
     ap.add_argument("--keying", default="mix", choices=["mix", "ref"])
     ap.add_argument("--sets", default="new", choices=["new", "upd"])
     ap.add_argument("--scheme", default="cuckoo", choices=["cuckoo", "2choice"])
+    ap.add_argument("--sorted-gets", action="store_true",
+                    help="experiment (DESIGN 5.1): the GETs of every batch pre-sorted by primary bucket on the host -- "
+                         "the upper bound of what bucket-ordered probing could gain; the kernels are unchanged")
     ap.add_argument("--lf", type=float, default=0.2)
     ap.add_argument("--batch-log2", type=int, default=20)
     ap.add_argument("--mem-p", type=int, default=30, help="per-GPU table size (log2 bytes)")
@@ -107,6 +110,7 @@ class Stream:
         self.args = args
         self.keying = W.KEYING_MIX if args.keying == "mix" else W.KEYING_REF
         self.P = W.preload_count(mem_p_agg, args.lf)            # keys 1 .. P-1 are pre-loaded
+        self.mem_p_agg = mem_p_agg
         theta = 0.0 if args.workload == "get100" else 0.99
         # reference: mehcached_zipf_init(n = P-2, theta, seed 21); ranks differ by seed only
         self.zipf = W.ZipfKeys(self.P - 2, theta, 21 + rank)
@@ -123,6 +127,10 @@ class Stream:
     def batch(self):
         self.last_get_keys = self.zipf.keys(self.n_get)        # (kept for the result check after the warm-up)
         gets = W.make_selem(self.last_get_keys, self.keying)
+        if getattr(self.args, "sorted_gets", False):
+            order = np.argsort(gets[:, 1] & np.uint32((1 << (self.mem_p_agg - 6)) - 1), kind="stable")
+            gets = np.ascontiguousarray(gets[order])
+            self.last_get_keys = self.last_get_keys[order]
         if self.n_set == 0:
             return gets, np.zeros((0, 3), np.uint32)
         if self.args.sets == "new":
