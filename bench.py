@@ -691,6 +691,7 @@ def pcie_inclusive(engine, batches, stream, args):
     L = idx.lib
     n = len(batches)
     keep = []
+    pipe = None
 
     def pinned(nbytes, dtype, shape):
         ptr = L.mkv_host_alloc(max(int(nbytes), 64))
@@ -771,6 +772,7 @@ def pcie_inclusive(engine, batches, stream, args):
             res[resolve] = {"value": round(steps * (1 << args.batch_log2) / best / 1e6, 1), "unit": "Mops",
                             "us_per_step": round(best / steps * 1e6, 1), "host_results_identical": ok}
         L.mkv_pipe_destroy(pipe)
+        pipe = None
         # the reference's own issue order: one stream, no overlap
         hq = [torch.from_numpy(h["q"]) for h in host]
         t_host = [{"q": b["q"].cpu().pin_memory(), "out": torch.empty_like(b["out"], device="cpu").pin_memory(),
@@ -805,6 +807,10 @@ def pcie_inclusive(engine, batches, stream, args):
             "note": "pinned host buffers; H2D requests + D2H results per step; best of three passes"})
         return out
     finally:
+        # the pipeline first (it drains the device): copies on the pinned buffers may be in flight
+        if pipe is not None and pipe.value:
+            L.mkv_pipe_destroy(pipe)
+        torch.cuda.synchronize()
         for ptr in keep:
             L.mkv_host_free(ptr)
 

@@ -106,6 +106,12 @@ int main(int argc, char **argv)
 		k->num_search = k->num_delete = k->num_gone = 0;
 	}
 
+	/* device memory the library takes for itself (update workspaces): free memory once the host's
+	 * own buffers are there, against free memory at the end */
+	size_t free_setup = 0, free_end = 0, total_mem = 0;
+	CUDA_SAFE_CALL(cudaDeviceSynchronize());
+	CUDA_SAFE_CALL(cudaMemGetInfo(&free_setup, &total_mem));
+
 	uint32_t next_key = 1;
 	uint64_t total_search = 0, total_insert = 0, total_delete = 0;
 	struct timespec t0, t1;
@@ -238,8 +244,10 @@ int main(int argc, char **argv)
 	}
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	double us = 1e6 * (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) / 1e3;
-	printf("cycles %d workers %d%s: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d\n",
+	CUDA_SAFE_CALL(cudaMemGetInfo(&free_end, &total_mem));
+	printf("cycles %d workers %d%s: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d, library memory %.0f MiB\n",
 			cycles, WORKERS, MAPPED ? " (host buffers mapped, no copies)" : "", (unsigned long long)total_search, (unsigned long long)total_insert,
-			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors);
+			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors,
+			free_setup > free_end ? (double)(free_setup - free_end) / 1048576.0 : 0.0);
 	return errors ? 1 : 0;
 }

@@ -57,6 +57,7 @@ cudaError_t cudaStreamDestroy(cudaStream_t stream);
 cudaError_t cudaStreamSynchronize(cudaStream_t stream);
 cudaError_t cudaDeviceSynchronize(void);
 cudaError_t cudaGetLastError(void);
+cudaError_t cudaMemGetInfo(size_t *free_bytes, size_t *total_bytes);	/* (examples/scheduler_cycle.c: the library's memory) */
 const char *cudaGetErrorString(cudaError_t error);
 
 #ifdef __cplusplus

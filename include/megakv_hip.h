@@ -85,20 +85,34 @@ void *mkv_timer_create(int slots);
 int mkv_timer_elapsed_ms(void *timer, int slot, float *ms);
 void mkv_timer_destroy(void *timer);
 
-/* Insert/delete keep a private device workspace per stream (conflict tables and
- * request state).  It is created on the first call that needs it; call this
- * beforehand to size it explicitly (and keep allocation out of a region being
- * captured into a hipGraph).  max_requests bounds the requests of one
- * insert/delete call on that stream. */
+/* Insert/delete keep their reservation state (conflict tables, request state) in a device
+ * workspace owned by the library: ONE pair per device, shared by every stream and table of
+ * the process (one for insert / delete calls, one for the insert half of mkv_cycle) -- about
+ * 0.9 GiB each at MEM_P = 30 with the default request capacity, whatever the number of worker
+ * streams (the reference's scheduler runs up to 16 over one table, src/mega_scheduler.c:273-280).
+ * They are created on the first call that needs them; call this beforehand to size them
+ * explicitly (and to keep allocation out of a region being captured into a hipGraph).
+ * max_requests bounds the requests of one insert/delete call.  `stream`: where the
+ * initialisation is enqueued (it is waited for). */
 int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *stream);
 
-/* Frees every workspace of the calling process (device must be idle). */
+/* Frees the workspaces of the calling process (synchronises the device). */
 void mkv_release_all(void);
 
-/* Updates of one table issued on different streams are put in issue order (an update that
- * finds the table's last update on another stream waits for an event recorded there).  A host
- * that DESTROYS a stream it has updated a table on calls this first: the stream is synchronised
- * and no longer referred to. */
+/* Device memory the workspaces of the current device hold, in bytes. */
+long long mkv_workspace_bytes(void);
+
+/* An insert/delete call WITHOUT a size hint whose device-side counts exceed the workspace is
+ * not applied (the library only learns of it after the fact): reported on stderr by the next
+ * insert/delete call, and counted here.  Nothing aborts. */
+unsigned long long mkv_dropped_batches(void);
+
+/* Updates issued on different streams are put in issue order (from the second stream on, every
+ * update call records an event of the library's own behind its last kernel and an update on
+ * another stream waits for it; the first time a second stream turns up, the device is
+ * synchronised once).  No stream handle is kept beyond the name of the last one used: a host
+ * that destroys a stream may call this first (the stream is synchronised and forgotten); it is
+ * not required. */
 void mkv_forget_stream(void *stream);
 
 /* Diagnostics of the most recent insert/delete on `stream` (synchronises the

@@ -47,6 +47,7 @@ cudaError_t cudaStreamSynchronize(cudaStream_t s)
 }
 cudaError_t cudaDeviceSynchronize(void) { return (cudaError_t)hipDeviceSynchronize(); }
 cudaError_t cudaGetLastError(void) { return (cudaError_t)hipGetLastError(); }
+cudaError_t cudaMemGetInfo(size_t *f, size_t *t) { return (cudaError_t)hipMemGetInfo(f, t); }
 const char *cudaGetErrorString(cudaError_t e) { return hipGetErrorString((hipError_t)e); }
 
 }

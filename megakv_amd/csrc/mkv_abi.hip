@@ -139,7 +139,8 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 	MkvTimer *tm = reinterpret_cast<MkvTimer *>(timer);
 	if (tm && (slot < 0 || slot >= tm->slots))
 		return MKV_EINVAL;
-	// The insert's mark pass does not touch the table.  Default: it rides in the
+	// The insert's mark pass never writes the table (its pre-walk reads it: a hint only, so a
+	// delete of the same cycle running beside it is harmless).  Default: it rides in the
 	// search launch (extra work-groups of one kernel).  MKV_CYCLE_SIDE_STREAM: it
 	// runs on a side stream beside the search kernel.  MKV_CYCLE_NO_OVERLAP: plain
 	// sequence of the three entry points.
@@ -186,5 +187,5 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 
 extern "C" const char *mkv_version(void)
 {
-	return "megakv_amd libgpuhash gfx950 r2";
+	return "megakv_amd libgpuhash gfx950 r3";
 }

@@ -141,7 +141,7 @@ extern "C" int mkv_pipe_create(mkv_pipe **out, const mkv_geom_t *geom, bucket_t 
 		PIPE_HIP(p, hipEventCreateWithFlags(&s.ev_comp, hipEventDisableTiming));
 		PIPE_HIP(p, hipEventCreateWithFlags(&s.ev_out, hipEventDisableTiming));
 	}
-	// the update workspace of the compute stream now, not inside the first cycle
+	// the device's update workspaces now, not inside the first cycle
 	if (max_set) {
 		const int rc = mkv_reserve(geom, max_set + 8, p->s_comp);
 		if (rc != MKV_OK)
@@ -189,7 +189,21 @@ static int stage_inserts(mkv_pipe *p, int i, const ielem_t *const *sets, const i
 	return MKV_OK;
 }
 
+static int pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int *const *blk_counts, loc_t *const *outs, int resolve, void *stream);
+
+// Every way out of a failed run drains the device first: copies on the caller's host buffers may
+// still be in flight on the pipeline's streams, and the caller is about to free those buffers.
 extern "C" int mkv_pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int *const *blk_counts, loc_t *const *outs, int resolve, void *stream)
+{
+	const int rc = pipe_run(p, nbatches, gets, n_get, sets, blk_counts, outs, resolve, stream);
+	if (rc != MKV_OK && p)
+		(void)hipDeviceSynchronize();
+	return rc;
+}
+
+static int pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *gets, const int64_t *n_get,
 		const ielem_t *const *sets, const int *const *blk_counts, loc_t *const *outs, int resolve, void *stream)
 {
 	if (!p || nbatches < 0 || (nbatches && (!gets || !n_get || !sets || !blk_counts || !outs)))
@@ -223,7 +237,7 @@ extern "C" int mkv_pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *get
 	// streams never wait for each other.
 	for (int i = 0; i < D - 1 && i < nbatches; i++)
 		if ((rc = copy_in(i)) != MKV_OK)
-			goto fail;
+			return rc;
 	for (int t = 0; t < nbatches; t++) {
 		Slot &s = p->slot[t % D];
 		// the cycle of batch t-1 is done: its results can leave, and the slot of batch t-1-(D-2) ...
@@ -239,7 +253,7 @@ extern "C" int mkv_pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *get
 		// batch t-1, just waited for) take the next copy-in
 		if (t + D - 1 < nbatches)
 			if ((rc = copy_in(t + D - 1)) != MKV_OK)
-				goto fail;
+				return rc;
 		// the cycle of batch t: its requests have arrived, and the result buffers of its slot have
 		// been copied out (batch t-D)
 		PIPE_HIP(p, hipEventSynchronize(s.ev_in));
@@ -253,10 +267,8 @@ extern "C" int mkv_pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *get
 					nset ? cnts : nullptr, nset ? p->nblk : 0, nset, 0u, p->s_comp, nullptr, 0);
 			if (rc == MKV_OK && resolve && n_get[t])
 				rc = mkv_resolve_results(s.out, n_get[t], s.loc, s.counters, p->s_comp);
-			if (rc != MKV_OK) {
-				pfail(p, rc, "mkv_cycle", hipSuccess);
-				goto fail;
-			}
+			if (rc != MKV_OK)
+				return pfail(p, rc, "mkv_cycle", hipSuccess);
 			PIPE_HIP(p, hipEventRecord(s.ev_comp, p->s_comp));
 		}
 	}
@@ -271,9 +283,6 @@ extern "C" int mkv_pipe_run(mkv_pipe *p, int nbatches, const selem_t *const *get
 	PIPE_HIP(p, hipStreamSynchronize(p->s_comp));
 	PIPE_HIP(p, hipStreamSynchronize(p->s_out));
 	return MKV_OK;
-fail:
-	(void)hipDeviceSynchronize();
-	return rc;
 }
 
 // pinned host memory for the pipeline's callers that have no allocator of their own for it

@@ -2846,17 +2846,20 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		// requests the grid-wide rounds left to the tail)
 		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + s_viols;
 		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->hard_tail;
-		// bit 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
-		// an order violation grows with the square of the pass size); bit 1: the 40-bit round stamps
+		// word 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
+		// an order violation grows with the square of the pass size); word 1: the 40-bit round stamps
 		// are nearly used up -- the host clears the reservation tables before a later call
-		// (ensure_ws); bit 2 (sticky): a batch exceeded the workspace and was dropped
+		// (ensure_ws); word 2: batches that exceeded the workspace and were dropped, so far.  Only
+		// this kernel writes the words; the host only reads them.
 		if (last_chunk)
 			ctl->late_score = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? kLateSticky :
 					(ctl->late_score ? ctl->late_score - 1u : 0u);
-		if (last_chunk && host_flag)
-			*host_flag = ((ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u) |
-					(ctl->stamp_base > kStampMax - kStampReserve ? 2u : 0u) |
-					(ctl->overflow ? 4u : (*host_flag & 4u));
+		if (last_chunk && host_flag) {
+			host_flag[0] = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u;
+			host_flag[1] = ctl->stamp_base > kStampMax - kStampReserve ? 1u : 0u;
+			if (ctl->overflow)
+				host_flag[2] = host_flag[2] + 1u;
+		}
 		ctl->hard_tail = 0;
 		ctl->chain_n = 0;
 		ctl->chain_ok = 0;
@@ -2929,12 +2932,16 @@ struct Workspace {
 	// insert overlaps the search kernel, and the fork/join events
 	hipStream_t aux = nullptr;
 	hipEvent_t ev_fork = nullptr, ev_join = nullptr;
-	// One word of pinned host memory the tail kernel writes (1 = the call met region
-	// barriers).  The host reads it without synchronising when the next call on this
-	// workspace is set up -- possibly a call late, which is fine: it only steers how
-	// finely the next hinted batch is chunked, never the result.
+	// Three words of pinned host memory that only the tail kernel writes (the host never does):
+	//   [0] 1 = eviction chains ran late in the call (read without synchronising when the next
+	//       call on this workspace is set up -- possibly a call late, which is fine: it only steers
+	//       how finely the next hinted batch is chunked, never the result);
+	//   [1] 1 = the 40-bit round stamps are nearly used up (ensure_ws clears the reservation tables);
+	//   [2] number of batches dropped so far because they exceeded the workspace (report_dropped).
 	volatile uint32_t *host_flag = nullptr;
 	uint32_t *host_flag_dev = nullptr;
+	uint32_t dropped_seen = 0;         // value of word [2] already reported
+	int reset_cooldown = 0;            // calls for which word [1] is ignored after a stamp reset was enqueued
 	Chunking cycle_ck = {1, 65536, 0};    // chunking chosen by the first half of an mkv_cycle insert
 	int barrier_score = 0;             // > 0: eviction chains ran late within the last few calls
 	int record_hint = 0;               // ... so round 2 keeps the touched record as a matter of course
@@ -2942,7 +2949,14 @@ struct Workspace {
 };
 
 static std::mutex g_ws_mutex;
-static std::unordered_map<uint64_t, Workspace *> g_ws;   // key: device<<56 ^ stream
+// ONE pair of workspaces per device, shared by every stream and every table of the process
+// (key: device << 1 | which): [0] serves insert / delete calls, [1] the insert half of a cycle
+// (mkv_cycle, mkv_slots_cycle), whose mark pass rides in the search launch while a delete of the
+// same cycle may still be using [0].  The reference's scheduler drives up to 16 worker streams
+// over one table (src/mega_scheduler.c:273-280): a workspace per stream would cost it 16 x 0.9
+// GiB for nothing, since updates are put in issue order across streams anyway (order_updates).
+static std::unordered_map<uint64_t, Workspace *> g_ws;
+static unsigned long long g_dropped_total = 0;   // batches dropped because they exceeded a workspace
 
 static void free_ws(Workspace *w)
 {
@@ -2964,7 +2978,28 @@ static void free_ws(Workspace *w)
 	*w = Workspace();
 }
 
-constexpr uint64_t kCycleSalt = 0x00a5a5a5a5a5a5a5ull;   // second workspace of a stream (mkv_cycle inserts)
+constexpr uint64_t kCycleSalt = 1ull;   // the device's second workspace (insert half of a cycle)
+
+// An earlier insert/delete on this workspace carried more requests than it holds: the counts are
+// device memory, so the library only learns this after the fact, and that batch was NOT applied.
+// Nothing can be returned through the reference's void ABI (and that call has long returned), and
+// killing a key-value server over it would be worse than the loss: it is reported on stderr, once
+// per dropped batch, counted (mkv_dropped_batches), and the current call goes on normally.
+static void report_dropped(Workspace *w)
+{
+	if (!w->host_flag)
+		return;
+	const uint32_t now = w->host_flag[2];
+	if (now == w->dropped_seen)
+		return;
+	g_dropped_total += (uint32_t)(now - w->dropped_seen);
+	w->dropped_seen = now;
+	fprintf(stderr, "libgpuhash (MI355X): an insert/delete call carried more requests than the update "
+			"workspace holds (%lld); that batch was dropped (%llu so far).  Size the workspace with "
+			"mkv_reserve(geom, max_requests, stream), pass the batch size to mkv_insert_hinted, or set "
+			"MKV_REQ_CAP (limit %lld requests per call).\n", (long long)w->req_cap, g_dropped_total,
+			(long long)kMaxReqCap);
+}
 
 static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStream_t stream,
 		uint64_t salt = 0)
@@ -2972,26 +3007,20 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess)
 		return MKV_EHIP;
-	const uint64_t key = ((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^ salt;
+	const uint64_t key = ((uint64_t)dev << 1) | (salt ? 1ull : 0ull);
 	std::lock_guard<std::mutex> lock(g_ws_mutex);
 	Workspace *&w = g_ws[key];
 	if (!w)
 		w = new Workspace();
-	if (w->host_flag && (*w->host_flag & 4u)) {
-		// An earlier insert/delete on this workspace carried more requests than it holds: the counts
-		// are device memory, so the library only learns this after the fact, and that batch was NOT
-		// applied.  Nothing can be returned through the void ABI (and the call has long returned):
-		// stop loudly rather than go on with a table that silently misses a batch.
-		fprintf(stderr, "libgpuhash (MI355X): an insert/delete call carried more requests than the update "
-				"workspace holds (%lld); that batch was dropped.  Size the workspace with "
-				"mkv_reserve(geom, max_requests, stream), pass the batch size to mkv_insert_hinted, or set "
-				"MKV_REQ_CAP (limit %lld requests per call).\n", (long long)w->req_cap, (long long)kMaxReqCap);
-		abort();
-	}
+	report_dropped(w);
 	if (w->device == dev && w->nbuckets >= nbuckets && w->req_cap >= req_cap) {
-		if (w->host_flag && (*w->host_flag & 2u)) {
+		if (w->reset_cooldown > 0) {
+			w->reset_cooldown--;
+		} else if (w->host_flag && w->host_flag[1]) {
 			// round stamps nearly used up (tail kernel's flag, read a call or two late: the
-			// reserve covers that): start over with cleared reservation tables, in stream order
+			// reserve covers that): start over with cleared reservation tables, in stream order.
+			// The flag is the kernel's to write; it reads 0 again once a call has run after the
+			// reset, until then it is not looked at.
 			bool ok = hipMemsetAsync(w->owner[0], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->owner[1], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 16, stream) == hipSuccess;
@@ -2999,7 +3028,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 			if (!ok)
 				return MKV_EHIP;
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull);
-			*w->host_flag &= ~2u;
+			w->reset_cooldown = 64;
 			w->stamp_resets++;
 		}
 		*out = w;
@@ -3007,9 +3036,10 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	}
 	const uint64_t nb = nbuckets > w->nbuckets ? nbuckets : w->nbuckets;
 	const int64_t rc = req_cap > w->req_cap ? req_cap : w->req_cap;
-	// growing: finish what the old buffers may still be used by
+	// growing: finish what the old buffers may still be used by (any stream of the device)
 	if (w->device >= 0)
-		(void)hipStreamSynchronize(stream);
+		(void)hipDeviceSynchronize();
+	const uint32_t dropped_seen = w->dropped_seen;
 	free_ws(w);
 	w->device = dev;
 	w->nbuckets = nb;
@@ -3031,7 +3061,9 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess;
 		if (ok) {
 			w->host_flag = reinterpret_cast<volatile uint32_t *>(hf);
-			*w->host_flag = 0;
+			w->host_flag[0] = w->host_flag[1] = 0;
+			w->host_flag[2] = dropped_seen;          // (the count goes on over a regrown workspace)
+			w->dropped_seen = dropped_seen;
 			void *dp = nullptr;
 			ok = hipHostGetDevicePointer(&dp, hf, 0) == hipSuccess;
 			w->host_flag_dev = reinterpret_cast<uint32_t *>(dp);
@@ -3046,6 +3078,8 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
 					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1));
+		// the buffers are shared by all streams: they are ready before any other stream uses them
+		ok = ok && hipStreamSynchronize(stream) == hipSuccess;
 	}
 	if (ok && salt == kCycleSalt) {
 		ok = ok && hipStreamCreateWithFlags(&w->aux, hipStreamNonBlocking) == hipSuccess;
@@ -3060,42 +3094,57 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	return MKV_OK;
 }
 
-// ---- one table, several streams ---------------------------------------------------------
+// ---- several streams ----------------------------------------------------------------------
 // The reference's scheduler issues the deletes and inserts of all its workers on ONE table,
 // a stream per worker (src/mega_scheduler.c:393-500); its kernels then race benignly.  Here an
-// update keeps reservation state per stream, and a roll-back restores words -- two updates of
-// one table running side by side would not be anybody's serialisation.  So updates of a table
-// are put in the order the host issued them: the call that finds the table's last update on
-// ANOTHER stream makes its stream wait for that one (an event recorded there now).  A host
-// that keeps to one stream per table never records or waits.  Searches are not ordered
-// against updates of other streams (neither are the reference's).
-struct TableOrder {
+// update keeps its reservation state in the device's workspace, and a roll-back restores words
+// -- two updates running side by side would not be anybody's serialisation.  So the updates of
+// a device are put in the order the host issued them.  A host that keeps to one stream never
+// pays for it.  The first time a second stream turns up the device is synchronised once (no
+// handle of the first stream is touched: it may have been destroyed since); from then on
+// every update call records an event behind its last kernel (updates_issued) and an update on
+// another stream waits for it.  Searches are not ordered against updates of other streams
+// (neither are the reference's).  Not called by mkv_slots_cycle: the sharded engines order
+// the local phases of their lanes' streams with events of their own.
+struct UpdateOrder {
 	hipStream_t last = nullptr;
-	bool any = false;
+	bool any = false, multi = false;
 	hipEvent_t ev = nullptr;
 };
-static std::unordered_map<uint64_t, TableOrder> g_table_order;   // key: device<<56 ^ table address
+static std::unordered_map<int, UpdateOrder> g_order;   // key: device
 
-static int order_table_updates(const void *table, hipStream_t stream)
+static int order_updates(hipStream_t stream)
 {
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess)
 		return MKV_EHIP;
 	std::lock_guard<std::mutex> lock(g_ws_mutex);
-	TableOrder &o = g_table_order[((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)table];
+	UpdateOrder &o = g_order[dev];
 	if (o.any && o.last != stream) {
-		if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess)
-			return MKV_EHIP;
-		// (a stream that has been destroyed since has finished its work: nothing to wait for)
-		if (hipEventRecord(o.ev, o.last) == hipSuccess) {
-			if (hipStreamWaitEvent(stream, o.ev, 0) != hipSuccess)
+		if (!o.multi) {
+			if (hipDeviceSynchronize() != hipSuccess ||
+					hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess)
 				return MKV_EHIP;
-		} else {
-			(void)hipGetLastError();
+			o.multi = true;
+		} else if (hipStreamWaitEvent(stream, o.ev, 0) != hipSuccess) {
+			return MKV_EHIP;
 		}
 	}
 	o.last = stream;
 	o.any = true;
+	return MKV_OK;
+}
+
+// behind the last kernel of an update call
+static int updates_issued(hipStream_t stream)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return MKV_EHIP;
+	std::lock_guard<std::mutex> lock(g_ws_mutex);
+	UpdateOrder &o = g_order[dev];
+	if (o.multi && hipEventRecord(o.ev, stream) != hipSuccess)
+		return MKV_EHIP;
 	return MKV_OK;
 }
 
@@ -3148,7 +3197,7 @@ static uint32_t mark_blocks_for(long long hint)
 static bool chains_lately(Workspace *w)
 {
 	if (w && w->host_flag) {
-		if (*w->host_flag & 1u)
+		if (w->host_flag[0] & 1u)
 			w->barrier_score = tuning().barrier_sticky;
 		else if (w->barrier_score > 0)
 			w->barrier_score--;
@@ -3206,7 +3255,7 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		return MKV_ETOOBIG;
 	if (hint > kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = order_table_updates(table, stream);
+	int rc = order_updates(stream);
 	if (rc != MKV_OK)
 		return rc;
 	rc = ensure_ws(&w, (uint64_t)g.hash_mask + 1, ws_need(src, hint), stream);
@@ -3224,7 +3273,31 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		if (rc != MKV_OK)
 			return rc;
 	}
-	return MKV_OK;
+	return updates_issued(stream);
+}
+
+// The work-groups of the tail launch meet at spin barriers (grid_sync): every one of them must be
+// resident at once.  Asked once per device and kernel (a CU-masked or partitioned device holds
+// fewer than Tuning::tail_groups may ask for).
+template <Op OP>
+static unsigned tail_groups_for()
+{
+	static int cap[64] = {0};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	int g = tuning().tail_groups;
+	if (dev >= 0 && dev < 64) {
+		if (cap[dev] == 0) {
+			int per_cu = 0, cus = 0;
+			if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k_tail<OP>, kTailThreads, 0) != hipSuccess ||
+					hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+				per_cu = cus = 0;
+			cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+		}
+		if (cap[dev] > 0 && g > cap[dev])
+			g = cap[dev];
+	}
+	return (unsigned)(g < 1 ? 1 : g);
 }
 
 // K2..K4
@@ -3241,7 +3314,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
 			(uint32_t)(2 * w->req_cap), (w->record_hint ? 1 : 0) | (tuning().debug_skip & 4));
-	hipLaunchKernelGGL((k_tail<OP>), dim3((unsigned)tuning().tail_groups), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
+	hipLaunchKernelGGL((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
 			w->owner[1], w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3);
@@ -3304,7 +3377,7 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *ta
 	hipStream_t s = (hipStream_t)stream;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = mkv::order_table_updates(table, s);
+	int rc = mkv::order_updates(s);
 	if (rc != MKV_OK)
 		return rc;
 	rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
@@ -3345,7 +3418,7 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	hipStream_t s = (hipStream_t)stream;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
-	int rc = mkv::order_table_updates(table, s);
+	int rc = mkv::order_updates(s);
 	if (rc != MKV_OK)
 		return rc;
 	rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
@@ -3415,7 +3488,7 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 		if (rc != MKV_OK)
 			return rc;
 	}
-	return MKV_OK;
+	return mkv::updates_issued(s);
 }
 
 // Local phase of a sharded step in one call: search every received slot and insert
@@ -3517,17 +3590,20 @@ extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 			(hipStream_t)stream);
 }
 
-// A stream is about to be destroyed (the library's own: pipeline, shard engine): it must not be
-// named as "where this table was last updated" any more -- its work is waited for here instead.
-// A host that destroys streams of its own while the library remembers them should call this
-// first (declared in megakv_hip.h).
+// A stream is about to be destroyed (the library's own: pipeline, shard engine; or the host's):
+// its work is waited for, and it is no longer named as "where the last update was issued".
+// (Nothing else refers to a stream: the update workspaces belong to the device, and the
+// cross-stream order is kept with an event of the library's own, never with a stream handle.)
 extern "C" void mkv_forget_stream(void *stream)
 {
 	(void)hipStreamSynchronize((hipStream_t)stream);
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return;
 	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
-	for (auto &kv : mkv::g_table_order)
-		if (kv.second.any && kv.second.last == (hipStream_t)stream)
-			kv.second.any = false;
+	auto it = mkv::g_order.find(dev);
+	if (it != mkv::g_order.end() && it->second.any && it->second.last == (hipStream_t)stream)
+		it->second.any = false;
 }
 
 extern "C" int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *stream)
@@ -3547,18 +3623,50 @@ extern "C" int mkv_reserve(const mkv_geom_t *geom, int64_t max_requests, void *s
 	return rc;
 }
 
+// Frees the update workspaces of the calling process (both of every device).  Synchronises.
 extern "C" void mkv_release_all(void)
 {
+	(void)hipDeviceSynchronize();
 	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
 	for (auto &kv : mkv::g_ws) {
 		mkv::free_ws(kv.second);
 		delete kv.second;
 	}
 	mkv::g_ws.clear();
-	for (auto &kv : mkv::g_table_order)
+	for (auto &kv : mkv::g_order)
 		if (kv.second.ev)
 			(void)hipEventDestroy(kv.second.ev);
-	mkv::g_table_order.clear();
+	mkv::g_order.clear();
+}
+
+// Batches dropped so far because they exceeded the update workspace (see mkv_reserve); the
+// count is current up to the last insert/delete call that has COMPLETED before this one.
+extern "C" unsigned long long mkv_dropped_batches(void)
+{
+	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+	for (auto &kv : mkv::g_ws)
+		mkv::report_dropped(kv.second);
+	return mkv::g_dropped_total;
+}
+
+// Bytes of device memory the update workspaces of the current device hold.
+extern "C" long long mkv_workspace_bytes(void)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return -1;
+	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+	long long total = 0;
+	for (auto &kv : mkv::g_ws) {
+		const mkv::Workspace *w = kv.second;
+		if (!w || w->device != dev)
+			continue;
+		total += (long long)w->nbuckets * 40 +
+				(long long)(((size_t)w->req_cap * 2 + (size_t)mkv::kChainLogCap * 8) * sizeof(uint2)) +
+				(long long)w->req_cap * (1 + 16 + 16 + 4) +
+				(long long)(((size_t)mkv::kChainLogCap + mkv::kTailLanes) * sizeof(mkv::ChainLog)) + (long long)sizeof(mkv::Ctl);
+	}
+	return total;
 }
 
 extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
@@ -3578,8 +3686,7 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	mkv::Workspace *w = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
-		auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^
-				(cycle_insert ? mkv::kCycleSalt : 0ull));
+		auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
 		if (it == mkv::g_ws.end() || !it->second->ctl)
 			return MKV_EINVAL;
 		w = it->second;
@@ -3611,8 +3718,7 @@ extern "C" int mkv_debug_stamp_resets(void *stream, int cycle_insert)
 	if (hipGetDevice(&dev) != hipSuccess)
 		return -1;
 	std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
-	auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^
-			(cycle_insert ? mkv::kCycleSalt : 0ull));
+	auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
 	return it == mkv::g_ws.end() ? -1 : it->second->stamp_resets;
 }
 
@@ -3626,8 +3732,7 @@ extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_u
 	mkv::Workspace *w = nullptr;
 	{
 		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
-		auto it = mkv::g_ws.find(((uint64_t)dev << 56) ^ (uint64_t)(uintptr_t)stream ^
-				(cycle_insert ? mkv::kCycleSalt : 0ull));
+		auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
 		if (it == mkv::g_ws.end() || !it->second->ctl)
 			return MKV_EINVAL;
 		w = it->second;

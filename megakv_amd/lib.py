@@ -33,11 +33,11 @@ ABI_SYMBOLS = [
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
-    "mkv_forget_stream", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
+    "mkv_forget_stream", "mkv_dropped_batches", "mkv_workspace_bytes", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
-    "cudaGetLastError", "cudaGetErrorString",
+    "cudaGetLastError", "cudaGetErrorString", "cudaMemGetInfo",
 ]
 
 _lib = None
@@ -73,6 +73,10 @@ def load_library():
     L.mkv_cycle.argtypes = [G, P, P, P, I64, P, I64, P, P, INT, I64, U32, P, P, INT]
     L.mkv_insert_hinted.restype = INT
     L.mkv_insert_hinted.argtypes = [G, P, P, P, INT, ctypes.c_longlong, P]
+    L.mkv_dropped_batches.restype = ctypes.c_ulonglong
+    L.mkv_dropped_batches.argtypes = []
+    L.mkv_workspace_bytes.restype = ctypes.c_longlong
+    L.mkv_workspace_bytes.argtypes = []
     L.mkv_timer_create.restype = P
     L.mkv_timer_create.argtypes = [INT]
     L.mkv_timer_elapsed_ms.restype = INT
