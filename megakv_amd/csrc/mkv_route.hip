@@ -348,51 +348,126 @@ __global__ __launch_bounds__(256) void k_pack_scatter(const uint32_t *__restrict
 }
 
 // ---- one-launch pack ----------------------------------------------------------
-// GET tiles place their requests with atomics (order inside a slot is free: `where`
-// brings every result home); SET tiles keep batch order -- per-tile counts, one meeting
-// of the SET tiles, prefix over the earlier tiles, ranked scatter.  The last work-group
-// to finish writes the slot headers and clears the control words for the next call.
-constexpr int kPackTile = 2048;      // requests per work-group
+// Work-groups of 1024 lanes.  The first `set_tiles` take the SETs, 4096 each, and keep batch
+// order: per-tile counts, one meeting of the SET tiles (they are the first work-groups of the
+// grid and all resident: the host checks), prefix over the earlier tiles, ranked scatter.  The
+// others take the GETs, 8192 (4096) each; the order inside a GET slot is free -- `where` brings
+// every result home -- so a tile ranks its requests per shard with wave ballots (one pass),
+// takes its range of every slot with ONE atomic per shard (the cursors lie in different
+// 128-byte lines; 122 work-groups instead of the 512 of the first version queue on them),
+// gathers the requests shard by shard in LDS and writes each shard's run as one contiguous,
+// coalesced piece.  (The un-pack of the results stays a gather through `where`: reading the runs
+// back tile by tile through LDS was built and measured -- 8.0 / 10.0 us against 7.8 / 7.7 us at
+// 1 / 8 shards: two dependent round trips either way.)
+// The last work-group to finish writes the slot headers and clears the control words.
+constexpr int kPackThreads = 1024;
+constexpr int kSetTile = 4096;       // SETs per work-group (4 per lane: three 16-byte loads)
 constexpr int kPackBins = 16;        // shards the one-launch pack handles
-constexpr int kPackCtlWords = 32;    // cursors[16], arrive, done, pad; per-tile counts follow
+constexpr int kCursorStride = 32;    // words between two shards' cursors (a 128-byte line each)
+constexpr int kPackArrive = kPackBins * kCursorStride, kPackDone = kPackArrive + kCursorStride;
+constexpr int kPackCtlWords = kPackDone + kCursorStride;    // cursors, arrive, done; then the SET tiles' counts
+constexpr int64_t kTileR8From = 1 << 19;                    // batches from this many GETs on: 8 per lane, else 4
 
 __device__ __forceinline__ uint32_t pack_ld(const uint32_t *p)
 {
 	return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-__global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__ gets, int64_t n_get,
+// Ranks of a wave's requests inside their shards, in the order (lane, then the lane's own
+// requests): every lane counts its requests per shard in 16-bit fields of 64-bit words (four
+// shards a word), the words are prefix-summed over the wave (six shuffle steps per word
+// instead of a ballot per shard and request: 512 vector instructions at 8 shards x 8 requests,
+// 4 cycles each on a 16-lane SIMD), and a lane numbers its own requests on top of what the lanes
+// before it hold.  mine (lane k): the wave's count for shard k.
+template <int R>
+__device__ __forceinline__ void wave_rank(const uint32_t (&sh)[R], uint32_t G, uint32_t (&rank)[R], uint32_t &mine)
+{
+	const uint32_t lane = threadIdx.x & 63u;
+	const uint32_t nw = (G + 3u) >> 2;                  // words in use (uniform)
+	unsigned long long pc[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+	for (int j = 0; j < R; j++) {
+		const unsigned long long inc = sh[j] != 0xffffffffu ? 1ull << (16u * (sh[j] & 3u)) : 0ull;
+		const uint32_t w = (sh[j] >> 2) & 3u;
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			pc[q] += w == (uint32_t)q ? inc : 0ull;
+	}
+	unsigned long long ex[4] = {0ull, 0ull, 0ull, 0ull}, tot[4] = {0ull, 0ull, 0ull, 0ull};
+#pragma unroll
+	for (int q = 0; q < 4; q++) {
+		if ((uint32_t)q < nw) {
+			unsigned long long incl = pc[q];
+#pragma unroll
+			for (int off = 1; off < 64; off <<= 1) {
+				const unsigned long long o = __shfl_up(incl, off);
+				if ((int)lane >= off)
+					incl += o;
+			}
+			ex[q] = incl - pc[q];
+			tot[q] = __shfl(incl, 63);
+		}
+	}
+#pragma unroll
+	for (int j = 0; j < R; j++) {
+		const uint32_t w = (sh[j] >> 2) & 3u, f = 16u * (sh[j] & 3u);
+		const unsigned long long x = w == 0u ? ex[0] : w == 1u ? ex[1] : w == 2u ? ex[2] : ex[3];
+		rank[j] = (uint32_t)(x >> f) & 0xffffu;
+		const unsigned long long inc = sh[j] != 0xffffffffu ? 1ull << f : 0ull;
+#pragma unroll
+		for (int q = 0; q < 4; q++)
+			ex[q] += w == (uint32_t)q ? inc : 0ull;
+	}
+	const uint32_t kw = (lane >> 2) & 3u;
+	const unsigned long long t = kw == 0u ? tot[0] : kw == 1u ? tot[1] : kw == 2u ? tot[2] : tot[3];
+	mine = lane < G ? (uint32_t)(t >> (16u * (lane & 3u))) & 0xffffu : 0u;
+}
+
+template <int R>      // GETs per lane: 8 or 4
+__global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__restrict__ gets, int64_t n_get,
 		const uint32_t *__restrict__ sets, int64_t n_set, uint32_t hash_mask, uint32_t shift, int nshards,
 		uint32_t *__restrict__ sendbuf, int64_t slot_words, uint32_t cap_get, uint32_t cap_set,
-		int32_t *__restrict__ perm_get, uint32_t *ctl, int *overflow, uint32_t set_tiles, uint32_t get_tiles)
+		int32_t *__restrict__ perm_get, uint32_t *ctl, int *overflow, uint32_t set_tiles, uint32_t get_tiles,
+		uint32_t self, uint32_t *__restrict__ self_slot)
 {
-	__shared__ uint32_t s_cnt[kPackBins], s_base[kPackBins], s_wcnt[4][kPackBins];
+	// (self_slot: the slot of shard `self` is written THERE -- the rank's own receive buffer: what a
+	// rank sends to itself need not pass through the exchange; self >= nshards: none)
+	constexpr int kTile = kPackThreads * R;
+	__shared__ uint2 s_stage[kTile];
+	__shared__ uint32_t s_wcnt[16][kPackBins];
+	__shared__ uint32_t s_base[kPackBins], s_off[kPackBins + 1];
 	__shared__ uint32_t s_last;
 	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
 	const uint32_t G = (uint32_t)nshards;
-	uint32_t *cursors = ctl, *arrive = ctl + kPackBins, *done = ctl + kPackBins + 1;
+	uint32_t *cursors = ctl, *arrive = ctl + kPackArrive, *done = ctl + kPackDone;
 	uint32_t *tile_counts = ctl + kPackCtlWords;
+	const bool sets16 = (reinterpret_cast<uintptr_t>(sets) & 15u) == 0u;
+	const bool gets16 = (reinterpret_cast<uintptr_t>(gets) & 15u) == 0u;
+	const bool perm8 = (reinterpret_cast<uintptr_t>(perm_get) & 7u) == 0u;
 	if (blockIdx.x < set_tiles) {
+		// ---- SETs: lane L of wave w holds the four consecutive requests 256 w + 4 L .. + 3 of the tile
 		const uint32_t tile = blockIdx.x;
-		const int64_t lo = (int64_t)tile * kPackTile + (int64_t)wave * (kPackTile / 4);
-		uint32_t w0[8], w1[8], w2[8], sh[8];
+		const int64_t e0 = (int64_t)tile * kSetTile + (int64_t)wave * 256 + (int64_t)lane * 4;
+		uint32_t w[12], sh[4];
+		if (e0 + 4 <= n_set && sets16) {
+			const uint4 *p = reinterpret_cast<const uint4 *>(sets + e0 * 3);
+			const uint4 a = p[0], b = p[1], c = p[2];
+			w[0] = a.x; w[1] = a.y; w[2] = a.z; w[3] = a.w; w[4] = b.x; w[5] = b.y; w[6] = b.z; w[7] = b.w;
+			w[8] = c.x; w[9] = c.y; w[10] = c.z; w[11] = c.w;
+		} else {
 #pragma unroll
-		for (int it = 0; it < 8; it++) {
-			const int64_t e = lo + it * 64 + lane;
-			const bool live = e < n_set;
-			w0[it] = live ? sets[e * 3] : 0u;
-			w1[it] = live ? sets[e * 3 + 1] : 0u;
-			w2[it] = live ? sets[e * 3 + 2] : 0u;
-			sh[it] = live ? (w1[it] & hash_mask) >> shift : 0xffffffffu;
+			for (int c = 0; c < 4; c++)
+#pragma unroll
+				for (int j = 0; j < 3; j++)
+					w[3 * c + j] = e0 + c < n_set ? sets[(e0 + c) * 3 + j] : 0u;
 		}
-		uint32_t mine = 0;                     // lane k: this wave's count for shard k
 #pragma unroll
-		for (int it = 0; it < 8; it++)
-			for (uint32_t k = 0; k < G; k++) {
-				const uint32_t c = (uint32_t)__popcll(__ballot(sh[it] == k));
-				if (lane == k)
-					mine += c;
-			}
+		for (int c = 0; c < 4; c++)
+			sh[c] = e0 + c < n_set ? (w[3 * c + 1] & hash_mask) >> shift : 0xffffffffu;
+		// rank inside the wave, in request order (lane-major, then c)
+		uint32_t rank[4];
+		uint32_t mine;                         // lane k: this wave's count for shard k
+		wave_rank<4>(sh, G, rank, mine);
 		if (lane < kPackBins)
 			s_wcnt[wave][lane] = lane < G ? mine : 0u;
 		if (t < kPackBins)
@@ -400,10 +475,12 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 		__syncthreads();
 		// counts and the meeting go through agent-scope atomics only: no cache write-back
 		// (an agent-scope fence flushes the L2 the GET tiles are filling -- 100 us of them)
-		if (t < G)
-			__hip_atomic_store(&tile_counts[(size_t)tile * kPackBins + t],
-					s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t], __ATOMIC_RELAXED,
-					__HIP_MEMORY_SCOPE_AGENT);
+		if (t < G) {
+			uint32_t c = 0;
+			for (int wv = 0; wv < 16; wv++)
+				c += s_wcnt[wv][t];
+			__hip_atomic_store(&tile_counts[(size_t)tile * kPackBins + t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+		}
 		__syncthreads();                       // (waits for those stores)
 		if (t == 0) {
 			atomicAdd(arrive, 1u);
@@ -414,34 +491,29 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 		for (uint32_t j = t; j < tile * G; j += blockDim.x)
 			atomicAdd(&s_base[j % G], pack_ld(&tile_counts[(size_t)(j / G) * kPackBins + j % G]));
 		__syncthreads();
-		uint32_t cursor = 0;
+		uint32_t cursor = 0;                   // lane k: where this wave's requests of shard k start in the slot
 		if (lane < G) {
 			cursor = s_base[lane];
-			for (uint32_t w = 0; w < wave; w++)
-				cursor += s_wcnt[w][lane];
+			for (uint32_t wv = 0; wv < wave; wv++)
+				cursor += s_wcnt[wv][lane];
 		}
 		const int64_t region = kHdrWords + (int64_t)cap_get * 2;
 #pragma unroll
-		for (int it = 0; it < 8; it++) {
-			uint32_t dst = 0;
-			for (uint32_t k = 0; k < G; k++) {
-				const unsigned long long m = __ballot(sh[it] == k);
-				const uint32_t base = __shfl(cursor, (int)k);
-				if (sh[it] == k)
-					dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-				if (lane == k)
-					cursor += (uint32_t)__popcll(m);
-			}
-			if (sh[it] != 0xffffffffu && dst < cap_set) {
-				uint32_t *p = sendbuf + (int64_t)sh[it] * slot_words + region + (int64_t)dst * 3;
-				p[0] = w0[it];
-				p[1] = w1[it];
-				p[2] = w2[it];
+		for (int c = 0; c < 4; c++) {
+			const uint32_t base = __shfl(cursor, (int)(sh[c] & 63u));
+			const uint32_t dst = base + rank[c];
+			if (sh[c] != 0xffffffffu && dst < cap_set) {
+				uint32_t *p = (sh[c] == self ? self_slot : sendbuf + (int64_t)sh[c] * slot_words) + region + (int64_t)dst * 3;
+				p[0] = w[3 * c];
+				p[1] = w[3 * c + 1];
+				p[2] = w[3 * c + 2];
 			}
 		}
 		if (tile == set_tiles - 1u && t < G) {
-			const uint32_t total = s_base[t] + s_wcnt[0][t] + s_wcnt[1][t] + s_wcnt[2][t] + s_wcnt[3][t];
-			uint32_t *hdr = sendbuf + (int64_t)t * slot_words;
+			uint32_t total = s_base[t];
+			for (int wv = 0; wv < 16; wv++)
+				total += s_wcnt[wv][t];
+			uint32_t *hdr = t == self ? self_slot : sendbuf + (int64_t)t * slot_words;
 			if (total > cap_set) {
 				*overflow = 1;
 				hdr[1] = 0;                    // nothing of this kind is sent for this slot
@@ -450,60 +522,96 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 			}
 		}
 	} else if (blockIdx.x < set_tiles + get_tiles) {
+		// ---- GETs: lane t holds the request pairs {2 (i 1024 + t), + 1} of the tile, i < R / 2
 		const uint32_t tile = blockIdx.x - set_tiles;
-		if (t < kPackBins)
-			s_cnt[t] = 0;
-		__syncthreads();
-		const uint2 *g2 = reinterpret_cast<const uint2 *>(gets);
-		uint2 rq[8];
-		uint32_t sh[8];
+		const int64_t tile0 = (int64_t)tile * kTile;
+		uint2 rq[R];
+		uint32_t sh[R], rank[R];
 #pragma unroll
-		for (int it = 0; it < 8; it++) {
-			const int64_t e = (int64_t)tile * kPackTile + it * 256 + t;
-			const bool live = e < n_get;
-			rq[it] = live ? g2[e] : make_uint2(0u, 0u);
-			sh[it] = live ? (rq[it].y & hash_mask) >> shift : 0xffffffffu;
-		}
-		// ranks by ballots (no per-request atomics): lane k counts shard k for its wave, takes
-		// the wave's range in the work-group's count (one LDS atomic), the work-group takes
-		// its range in the slot (one global atomic per shard)
-		uint32_t mine = 0;
-#pragma unroll
-		for (int it = 0; it < 8; it++)
-			for (uint32_t k = 0; k < G; k++) {
-				const uint32_t c = (uint32_t)__popcll(__ballot(sh[it] == k));
-				if (lane == k)
-					mine += c;
-			}
-		uint32_t cursor = 0;
-		if (lane < G && mine)
-			cursor = atomicAdd(&s_cnt[lane], mine);
-		__syncthreads();
-		if (t < G && s_cnt[t])
-			s_base[t] = atomicAdd(&cursors[t], s_cnt[t]);
-		__syncthreads();
-		if (lane < G)
-			cursor += s_base[lane];
-#pragma unroll
-		for (int it = 0; it < 8; it++) {
-			uint32_t dst = 0;
-			for (uint32_t k = 0; k < G; k++) {
-				const unsigned long long m = __ballot(sh[it] == k);
-				const uint32_t base = __shfl(cursor, (int)k);
-				if (sh[it] == k)
-					dst = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-				if (lane == k)
-					cursor += (uint32_t)__popcll(m);
-			}
-			if (sh[it] != 0xffffffffu) {
-				if (dst < cap_get) {
-					uint2 *p = reinterpret_cast<uint2 *>(sendbuf + (int64_t)sh[it] * slot_words + kHdrWords) + dst;
-					*p = rq[it];
+		for (int i = 0; i < R / 2; i++) {
+			const int64_t e = tile0 + 2 * ((int64_t)i * kPackThreads + t);
+			uint4 v = make_uint4(0u, 0u, 0u, 0u);
+			if (e + 2 <= n_get && gets16) {
+				v = *reinterpret_cast<const uint4 *>(gets + e * 2);
+			} else if (e < n_get) {
+				const uint2 h = *reinterpret_cast<const uint2 *>(gets + e * 2);
+				v.x = h.x;
+				v.y = h.y;
+				if (e + 1 < n_get) {
+					const uint2 h2 = *reinterpret_cast<const uint2 *>(gets + e * 2 + 2);
+					v.z = h2.x;
+					v.w = h2.y;
 				}
-				// where the request went (its result comes back to the same place): written in
-				// request order, i.e. coalesced -- the un-pack gathers through it
-				perm_get[(int64_t)tile * kPackTile + it * 256 + t] =
-						dst < cap_get ? (int32_t)((int64_t)sh[it] * cap_get + dst) : -1;
+			}
+			rq[2 * i] = make_uint2(v.x, v.y);
+			rq[2 * i + 1] = make_uint2(v.z, v.w);
+			sh[2 * i] = e < n_get ? (v.y & hash_mask) >> shift : 0xffffffffu;
+			sh[2 * i + 1] = e + 1 < n_get ? (v.w & hash_mask) >> shift : 0xffffffffu;
+		}
+		// ranks inside the wave per shard (any order will do), counts in lane k
+		uint32_t mine;
+		wave_rank<R>(sh, G, rank, mine);
+		if (lane < kPackBins)
+			s_wcnt[wave][lane] = lane < G ? mine : 0u;
+		__syncthreads();
+		// the work-group's count per shard -> its range of the slot (one atomic per shard), the
+		// shard's place in the LDS staging area, and where the tile went (for the un-pack)
+		if (t < kPackBins) {
+			uint32_t c = 0;
+			for (int wv = 0; wv < 16; wv++)
+				c += s_wcnt[wv][t];
+			const uint32_t base = (t < G && c) ? atomicAdd(&cursors[t * kCursorStride], c) : 0u;
+			s_base[t] = base;
+			// exclusive prefix of the counts over the shards (16 lanes of one wave)
+			uint32_t incl = c;
+			for (int off = 1; off < kPackBins; off <<= 1) {
+				const uint32_t o = __shfl_up(incl, off);
+				if ((int)t >= off)
+					incl += o;
+			}
+			s_off[t] = incl - c;
+			if (t == kPackBins - 1)
+				s_off[kPackBins] = incl;
+		}
+		__syncthreads();
+		uint32_t wbase = 0;                    // lane k: this wave's first place inside shard k's run of the tile
+		if (lane < G)
+			for (uint32_t wv = 0; wv < wave; wv++)
+				wbase += s_wcnt[wv][lane];
+		int32_t wh[R];
+#pragma unroll
+		for (int j = 0; j < R; j++) {
+			const uint32_t k = sh[j] & 63u;
+			const uint32_t in_run = __shfl(wbase, (int)k) + rank[j];      // place inside the tile's run for shard k
+			wh[j] = -1;
+			if (sh[j] != 0xffffffffu) {
+				s_stage[s_off[k] + in_run] = rq[j];
+				const uint32_t dst = s_base[k] + in_run;
+				if (dst < cap_get)
+					wh[j] = (int32_t)((int64_t)k * cap_get + dst);
+			}
+		}
+		// where the requests went (their results come back to the same place): request order, coalesced
+#pragma unroll
+		for (int i = 0; i < R / 2; i++) {
+			const int64_t e = tile0 + 2 * ((int64_t)i * kPackThreads + t);
+			if (e + 2 <= n_get && perm8) {
+				*reinterpret_cast<int2 *>(perm_get + e) = make_int2(wh[2 * i], wh[2 * i + 1]);
+			} else if (e < n_get) {
+				perm_get[e] = wh[2 * i];
+				if (e + 1 < n_get)
+					perm_get[e + 1] = wh[2 * i + 1];
+			}
+		}
+		__syncthreads();
+		// every shard's run leaves as one contiguous piece
+		for (uint32_t k = 0; k < G; k++) {
+			const uint32_t lo = s_off[k], hi = s_off[k + 1u], base = s_base[k];
+			uint2 *slot = reinterpret_cast<uint2 *>((k == self ? self_slot : sendbuf + (int64_t)k * slot_words) + kHdrWords);
+			for (uint32_t j = lo + t; j < hi; j += kPackThreads) {
+				const uint32_t dst = base + (j - lo);
+				if (dst < cap_get)
+					slot[dst] = s_stage[j];
 			}
 		}
 	}
@@ -514,8 +622,8 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 	if (s_last) {
 		// (the cursors are atomics; the slots' contents need not be visible here)
 		if (t < G) {
-			const uint32_t c = pack_ld(&cursors[t]);
-			uint32_t *hdr = sendbuf + (int64_t)t * slot_words;
+			const uint32_t c = pack_ld(&cursors[t * kCursorStride]);
+			uint32_t *hdr = t == self ? self_slot : sendbuf + (int64_t)t * slot_words;
 			if (c > cap_get) {
 				*overflow = 1;
 				hdr[0] = 0;
@@ -529,7 +637,7 @@ __global__ __launch_bounds__(256) void k_pack_fused(const uint32_t *__restrict__
 		}
 		__syncthreads();
 		if (t < kPackBins)
-			cursors[t] = 0;
+			cursors[t * kCursorStride] = 0;
 		if (t == 0) {
 			*arrive = 0;
 			*done = 0;
@@ -546,7 +654,7 @@ __global__ __launch_bounds__(256) void k_search_slots(const uint32_t *__restrict
 	if (blockIdx.x == 0 && threadIdx.x < (uint32_t)nslots)
 		set_counts[threadIdx.x] = (int)recvbuf[(int64_t)threadIdx.x * slot_words + 1];
 	search_slots_body(blockIdx.x, recvbuf, slot_words, cap_get, out, table, hash_mask, blk_mask,
-			chunks_per_slot);
+			chunks_per_slot, 0xffffffffu, nullptr);
 }
 
 // results come back in the layout the requests were sent in; request e went to position
@@ -555,10 +663,23 @@ __global__ __launch_bounds__(256) void k_search_slots(const uint32_t *__restrict
 __global__ __launch_bounds__(256) void k_unpack_results(const uint2 *__restrict__ back,
 		const int32_t *__restrict__ where, int64_t n_get, uint2 *__restrict__ out)
 {
-	for (int64_t e = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; e < n_get;
-			e += (int64_t)gridDim.x * blockDim.x) {
-		const int32_t w = where[e];
-		out[e] = w >= 0 ? back[w] : make_uint2(0u, 0u);
+	// two requests per lane: one 8-byte load of their `where` entries, two gathers, one 16-byte store
+	const bool wide = ((reinterpret_cast<uintptr_t>(where) & 7u) | (reinterpret_cast<uintptr_t>(out) & 15u)) == 0u;
+	for (int64_t e = 2 * ((int64_t)blockIdx.x * blockDim.x + threadIdx.x); e < n_get;
+			e += 2 * (int64_t)gridDim.x * blockDim.x) {
+		if (wide && e + 2 <= n_get) {
+			const int2 w = *reinterpret_cast<const int2 *>(where + e);
+			const uint2 a = w.x >= 0 ? back[w.x] : make_uint2(0u, 0u);
+			const uint2 b = w.y >= 0 ? back[w.y] : make_uint2(0u, 0u);
+			*reinterpret_cast<uint4 *>(out + e) = make_uint4(a.x, a.y, b.x, b.y);
+		} else {
+			const int32_t w0 = where[e];
+			out[e] = w0 >= 0 ? back[w0] : make_uint2(0u, 0u);
+			if (e + 1 < n_get) {
+				const int32_t w1 = where[e + 1];
+				out[e + 1] = w1 >= 0 ? back[w1] : make_uint2(0u, 0u);
+			}
+		}
 	}
 }
 
@@ -574,16 +695,35 @@ extern "C" int64_t mkv_pack_scratch_bytes(int64_t n_get, int64_t n_set, int nsha
 	const int64_t nw_get = (n_get + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
 	const int64_t nw_set = (n_set + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
 	const int64_t three_pass = (nw_get + nw_set) * nshards * 4 + 64;
-	const int64_t set_tiles = (n_set + mkv::kPackTile - 1) / mkv::kPackTile;
+	const int64_t set_tiles = (n_set + mkv::kSetTile - 1) / mkv::kSetTile;
 	const int64_t one_pass = (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4 + 64;
 	return three_pass > one_pass ? three_pass : one_pass;
 }
+
+extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, void *stream);
 
 extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
 		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
 		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
 		void *stream)
 {
+	return mkv_pack_requests_self(gets, n_get, sets, n_set, hash_mask_agg, shard_shift, nshards, sendbuf, cap_get,
+			cap_set, perm_get, scratch, scratch_bytes, overflow, -1, nullptr, stream);
+}
+
+// The same with the slot of shard `self` written to self_slot instead of its place in sendbuf (the
+// sharded engine: a rank's requests for its own shard go straight into its receive buffer).
+// self < 0: none.  Not with the three-pass fall-back (MKV_EINVAL: the caller packs without).
+extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, void *stream)
+{
+	if (self >= nshards || (self >= 0 && !self_slot))
+		return MKV_EINVAL;
 	if (n_get < 0 || n_set < 0 || nshards < 1 || nshards > mkv::kMaxShards || shard_shift > 31 ||
 			cap_get < 0 || cap_set < 0 || cap_get > 0x7fffffffLL || cap_set > 0x7fffffffLL || !sendbuf ||
 			!scratch || !overflow || (n_get && (!gets || !perm_get)) || (n_set && !sets))
@@ -599,8 +739,10 @@ extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem
 	const int64_t waves = nw_get + nw_set;
 	const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gets);
 	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sets);
-	const int64_t set_tiles = (n_set + mkv::kPackTile - 1) / mkv::kPackTile;
-	const int64_t get_tiles = (n_get + mkv::kPackTile - 1) / mkv::kPackTile;
+	const bool r8 = n_get >= mkv::kTileR8From;
+	const int64_t get_tile = mkv::kPackThreads * (r8 ? 8 : 4);
+	const int64_t set_tiles = (n_set + mkv::kSetTile - 1) / mkv::kSetTile;
+	const int64_t get_tiles = (n_get + get_tile - 1) / get_tile;
 	// The SET tiles of the one-launch pack meet once (they spin on an arrival counter): every one
 	// of them must be resident at the same time.  They are the first work-groups of the grid, so
 	// it is enough that the device can hold that many -- asked once per device (a CU-masked or
@@ -610,7 +752,7 @@ extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem
 	(void)hipGetDevice(&dev);
 	if (dev >= 0 && dev < 64 && resident_cap[dev] == 0) {
 		int per_cu = 0, cus = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_fused, 256, 0) != hipSuccess ||
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8>, mkv::kPackThreads, 0) != hipSuccess ||
 				hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
 			per_cu = cus = 0;
 		resident_cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
@@ -622,12 +764,20 @@ extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem
 		// one launch; its control words (the head of `scratch`) are zero between calls: zeroed
 		// by the caller once, cleared again by the kernel's last work-group
 		const int64_t blocks = set_tiles + get_tiles ? set_tiles + get_tiles : 1;
-		hipLaunchKernelGGL(mkv::k_pack_fused, dim3((unsigned)blocks), dim3(256), 0, s, g32, n_get, s32, n_set,
-				hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set,
-				perm_get, reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles,
-				(uint32_t)get_tiles);
+		if (r8)
+			hipLaunchKernelGGL(mkv::k_pack_tiles<8>, dim3((unsigned)blocks), dim3(mkv::kPackThreads), 0, s, g32, n_get, s32,
+					n_set, hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set,
+					perm_get, reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles, (uint32_t)get_tiles,
+					self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot);
+		else
+			hipLaunchKernelGGL(mkv::k_pack_tiles<4>, dim3((unsigned)blocks), dim3(mkv::kPackThreads), 0, s, g32, n_get, s32,
+					n_set, hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set,
+					perm_get, reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles, (uint32_t)get_tiles,
+					self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot);
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
+	if (self >= 0)
+		return MKV_EINVAL;
 	if (waves > 0) {
 		dim3 grid((unsigned)((waves + 3) / 4)), block(256);
 		hipLaunchKernelGGL(mkv::k_pack_count, grid, block, 0, s, g32, n_get, s32, n_set, hash_mask_agg,
@@ -667,7 +817,7 @@ extern "C" int mkv_unpack_results(const loc_t *back, const int32_t *where, int64
 		return MKV_EINVAL;
 	if (n_get == 0)
 		return MKV_OK;
-	int64_t blocks = (n_get + 255) / 256;
+	int64_t blocks = (n_get + 511) / 512;
 	if (blocks > 4096)
 		blocks = 4096;
 	hipLaunchKernelGGL(mkv::k_unpack_results, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
@@ -779,31 +929,81 @@ __global__ __launch_bounds__(256) void k_resolve(const uint2 *__restrict__ pairs
 		atomicAdd(&counters[(blockIdx.x * 4u + (threadIdx.x >> 6)) & 63u], (unsigned long long)hits);
 }
 
-// KEY_MATCH: one lane per request.  Only the location the sender would pick is looked at --
-// the primary bucket's if it is non-zero, else the alternate's (:408-414); a false positive
-// in the primary bucket therefore hides a true entry in the alternate one, as in the reference.
+// KEY_MATCH.  Only the location the sender would pick is looked at -- the primary bucket's
+// if it is non-zero, else the alternate's (:408-414); a false positive in the primary bucket
+// therefore hides a true entry in the alternate one, as in the reference.  The compare is the
+// reference's `it->nkey == key_len && strncmp(ITEM_key(it), key, key_len) == 0`
+// (src/mega_send.c:544, also :712, 820, 847): strncmp stops at the first NUL, and the
+// reference's own keys are binary with NUL bytes ({k, (k & 7) << 29 | k}, src/mega_recv.c:700-704),
+// so two keys that agree up to and including their first NUL ARE equal to the reference.
+// BYTES = true compares all key_len bytes instead (what a host with binary keys would want).
+// Four lanes serve a request: 16 bytes of the item's key and of the request's key each per
+// step (dword loads where the addresses allow), every lane notes the first differing byte and
+// the first NUL of its piece, a quad reduction decides.
+template <bool BYTES>
 __global__ __launch_bounds__(256) void k_resolve_verify(const uint2 *__restrict__ pairs, int64_t n,
 		const uint8_t *__restrict__ keys, int64_t key_stride, uint32_t key_len, const uint8_t *__restrict__ arena,
 		int64_t item_stride, uint64_t arena_items, uint32_t nkey_off, uint32_t key_off,
 		uint32_t *__restrict__ loc, unsigned long long *__restrict__ counters)
 {
+	const uint32_t q = threadIdx.x & 3u;
 	uint32_t hits = 0, fps = 0;
-	for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n;
-			i += (int64_t)gridDim.x * blockDim.x) {
+	const int64_t groups = ((int64_t)gridDim.x * blockDim.x) >> 2;
+	for (int64_t i = ((int64_t)blockIdx.x * blockDim.x + threadIdx.x) >> 2; i < n; i += groups) {
 		const uint2 p = pairs[i];
 		const uint32_t l = p.x ? p.x : p.y;
-		bool ok = false;
-		if (l != 0u && (uint64_t)l < arena_items) {
-			const uint8_t *it = arena + (uint64_t)l * (uint64_t)item_stride;
-			const uint32_t nkey = (uint32_t)it[nkey_off] | ((uint32_t)it[nkey_off + 1u] << 8);   // uint16_t nkey
-			ok = nkey == key_len;
-			const uint8_t *k = keys + i * key_stride;
-			for (uint32_t b = 0; ok && b < key_len; b++)
-				ok = it[key_off + b] == k[b];
+		bool ok = l != 0u && (uint64_t)l < arena_items;
+		const uint8_t *it = arena + (ok ? (uint64_t)l * (uint64_t)item_stride : 0ull);
+		if (ok)
+			ok = ((uint32_t)it[nkey_off] | ((uint32_t)it[nkey_off + 1u] << 8)) == key_len;   // uint16_t nkey
+		const uint8_t *a = it + key_off, *k = keys + i * key_stride;
+		const bool a4 = (((uintptr_t)a) & 3u) == 0u, k4 = (((uintptr_t)k) & 3u) == 0u;
+		uint32_t d = 0xffffffffu, z = 0xffffffffu;     // first differing byte, first NUL of the item's key
+		if (ok) {
+			for (uint32_t base = q * 16u; base < key_len && d == 0xffffffffu; base += 64u) {
+				uint32_t av[4], kv[4];
+#pragma unroll
+				for (uint32_t w = 0; w < 4u; w++) {
+					const uint32_t o = base + 4u * w;
+					av[w] = kv[w] = 0u;
+					if (o + 4u <= key_len) {
+						av[w] = a4 ? *reinterpret_cast<const uint32_t *>(a + o) :
+								((uint32_t)a[o] | ((uint32_t)a[o + 1u] << 8) | ((uint32_t)a[o + 2u] << 16) | ((uint32_t)a[o + 3u] << 24));
+						kv[w] = k4 ? *reinterpret_cast<const uint32_t *>(k + o) :
+								((uint32_t)k[o] | ((uint32_t)k[o + 1u] << 8) | ((uint32_t)k[o + 2u] << 16) | ((uint32_t)k[o + 3u] << 24));
+					} else {
+						for (uint32_t c = 0; c < 4u && o + c < key_len; c++) {
+							av[w] |= (uint32_t)a[o + c] << (8u * c);
+							kv[w] |= (uint32_t)k[o + c] << (8u * c);
+						}
+					}
+				}
+#pragma unroll
+				for (uint32_t w = 0; w < 4u; w++)
+#pragma unroll
+					for (uint32_t c = 0; c < 4u; c++) {
+						const uint32_t o = base + 4u * w + c;
+						const uint32_t ab = (av[w] >> (8u * c)) & 0xffu, kb = (kv[w] >> (8u * c)) & 0xffu;
+						if (o < key_len && ab != kb && d == 0xffffffffu)
+							d = o;
+						if (o < key_len && ab == 0u && z == 0xffffffffu)
+							z = o;
+					}
+			}
 		}
-		loc[i] = ok ? l : 0u;
-		hits += ok ? 1u : 0u;
-		fps += (l != 0u && !ok) ? 1u : 0u;
+		// the quad's first difference / first NUL
+		for (int m = 1; m <= 2; m <<= 1) {
+			const uint32_t od = __shfl_xor(d, m), oz = __shfl_xor(z, m);
+			d = od < d ? od : d;
+			z = oz < z ? oz : z;
+		}
+		// strncmp: equal unless a byte differs before (or at) the first NUL
+		ok = ok && (d == 0xffffffffu || (!BYTES && z < d));
+		if (q == 0u) {
+			loc[i] = ok ? l : 0u;
+			hits += ok ? 1u : 0u;
+			fps += (l != 0u && !ok) ? 1u : 0u;
+		}
 	}
 	for (int off = 32; off > 0; off >>= 1) {
 		hits += __shfl_down(hits, off);
@@ -854,9 +1054,9 @@ extern "C" int mkv_resolve_results(const loc_t *pairs, int64_t num_elem, loc_t *
 
 extern "C" int mkv_resolve_verify(const loc_t *pairs, int64_t num_elem, const void *keys, int64_t key_stride,
 		int key_len, const void *arena, int64_t item_stride, int64_t arena_items, int nkey_off, int key_off,
-		loc_t *loc, uint64_t *counters, void *stream)
+		int compare, loc_t *loc, uint64_t *counters, void *stream)
 {
-	if (num_elem < 0 || !counters || key_len < 0 || key_len > 65535 || item_stride <= 0 || arena_items < 0 ||
+	if (num_elem < 0 || (compare != MKV_KEYCMP_STRNCMP && compare != MKV_KEYCMP_BYTES) || !counters || key_len < 0 || key_len > 65535 || item_stride <= 0 || arena_items < 0 ||
 			nkey_off < 0 || key_off < 0 || (int64_t)nkey_off + 2 > item_stride || (int64_t)key_off + key_len > item_stride ||
 			key_stride < key_len || (num_elem && (!pairs || !loc || !keys || !arena)))
 		return MKV_EINVAL;
@@ -864,13 +1064,19 @@ extern "C" int mkv_resolve_verify(const loc_t *pairs, int64_t num_elem, const vo
 	if (hipMemsetAsync(counters, 0, 68 * sizeof(uint64_t), s) != hipSuccess)
 		return MKV_EHIP;
 	if (num_elem) {
-		int64_t blocks = (num_elem + 255) / 256;
-		if (blocks > 4096)
-			blocks = 4096;
-		hipLaunchKernelGGL(mkv::k_resolve_verify, dim3((unsigned)blocks), dim3(256), 0, s,
-				reinterpret_cast<const uint2 *>(pairs), num_elem, reinterpret_cast<const uint8_t *>(keys), key_stride,
-				(uint32_t)key_len, reinterpret_cast<const uint8_t *>(arena), item_stride, (uint64_t)arena_items,
-				(uint32_t)nkey_off, (uint32_t)key_off, loc, reinterpret_cast<unsigned long long *>(counters));
+		int64_t blocks = (num_elem + 63) / 64;          // four lanes per request
+		if (blocks > 8192)
+			blocks = 8192;
+		if (compare == MKV_KEYCMP_BYTES)
+			hipLaunchKernelGGL((mkv::k_resolve_verify<true>), dim3((unsigned)blocks), dim3(256), 0, s,
+					reinterpret_cast<const uint2 *>(pairs), num_elem, reinterpret_cast<const uint8_t *>(keys), key_stride,
+					(uint32_t)key_len, reinterpret_cast<const uint8_t *>(arena), item_stride, (uint64_t)arena_items,
+					(uint32_t)nkey_off, (uint32_t)key_off, loc, reinterpret_cast<unsigned long long *>(counters));
+		else
+			hipLaunchKernelGGL((mkv::k_resolve_verify<false>), dim3((unsigned)blocks), dim3(256), 0, s,
+					reinterpret_cast<const uint2 *>(pairs), num_elem, reinterpret_cast<const uint8_t *>(keys), key_stride,
+					(uint32_t)key_len, reinterpret_cast<const uint8_t *>(arena), item_stride, (uint64_t)arena_items,
+					(uint32_t)nkey_off, (uint32_t)key_off, loc, reinterpret_cast<unsigned long long *>(counters));
 	}
 	hipLaunchKernelGGL(mkv::k_resolve_fold, dim3(1), dim3(64), 0, s,
 			reinterpret_cast<unsigned long long *>(counters), (long long)num_elem);

@@ -228,9 +228,11 @@ __device__ __forceinline__ void search_body_lds(uint32_t block, const uint2 *__r
 // from its header on the device.
 constexpr int kSlotHdrWords = 4;
 
+// (self_out: the results of slot `self` go THERE -- the rank's own buffer of returned results:
+// what a rank answers to itself need not pass through the exchange; self out of range: none)
 __device__ __forceinline__ void search_slots_body(uint32_t block, const uint32_t *__restrict__ recvbuf,
 		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
-		uint32_t hash_mask, uint32_t blk_mask, uint32_t chunks_per_slot)
+		uint32_t hash_mask, uint32_t blk_mask, uint32_t chunks_per_slot, uint32_t self, uint32_t *__restrict__ self_out)
 {
 	const uint32_t seg = block / chunks_per_slot;
 	const uint32_t chunk = block - seg * chunks_per_slot;
@@ -239,7 +241,7 @@ __device__ __forceinline__ void search_slots_body(uint32_t block, const uint32_t
 	if ((uint64_t)chunk * 256u >= n)
 		return;
 	search_body<4, true, false>(chunk, reinterpret_cast<const uint2 *>(slot + kSlotHdrWords),
-			out + (int64_t)seg * cap_get * 2, table, (int64_t)n, hash_mask, blk_mask);
+			seg == self ? self_out : out + (int64_t)seg * cap_get * 2, table, (int64_t)n, hash_mask, blk_mask);
 }
 
 }  // namespace mkv

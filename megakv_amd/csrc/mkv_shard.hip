@@ -19,6 +19,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <time.h>
 #include <new>
 
 #include "megakv_hip.h"
@@ -34,6 +35,8 @@ struct Rccl {
 	const char *(*GetErrorString)(ncclResult_t) = nullptr;
 	ncclResult_t (*GroupStart)() = nullptr;
 	ncclResult_t (*GroupEnd)() = nullptr;
+	ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 };
 
 struct Lane {
@@ -66,12 +69,22 @@ struct mkv_shard {
 	int loopback = 0;               // rccl_path "loopback": the exchanges are local copies (tests)
 	int fused = 0;                  // one grouped collective per batch (run_fused): default with several ranks,
 	                                // MKV_SHARD_FUSED=0/1 overrides
+	long long packed = 0;           // batches packed so far
+	int self_direct = 0;            // plain schedule: what a rank sends to itself bypasses the exchange (the pack
+	                                // writes that slot into the receive buffer, the slot search its results into the
+	                                // buffer of returned results); the peers' slots go by grouped send / receive.
+	                                // MKV_SHARD_SELF=0: everything through ncclAllToAll (which copies the own slot itself)
 	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
 	Lane lane[4];
 	hipEvent_t ev_start = nullptr;
 	hipStream_t cstream = nullptr;  // fused schedule: every local phase, one after the other (no hand-over between streams)
 	hipEvent_t ev_cdone = nullptr;
 	int one_compute_stream = 0;     // MKV_SHARD_CSTREAM=1
+	int sched_cs = 0;               // the default schedule (run_cs): local phases on `cstream`, everything else of
+	                                // a batch on a service stream; MKV_SHARD_SCHED=plain|fused selects the older two
+	int host_paced = 1;             // run_cs: the host, not the stream, waits for a local phase's requests (MKV_SHARD_PACED=0)
+	int nsvc = 1;                   // service streams of run_cs (MKV_SHARD_SVC = 1..3; default 1 rank: 1, else 2)
+	hipStream_t svc[3] = {nullptr, nullptr, nullptr};
 	Rccl api;
 	ncclComm_t comm = nullptr;
 	char err[256] = {0};
@@ -149,7 +162,57 @@ ncclResult_t loop_a2a(const void *send, void *recv, size_t count, ncclDataType_t
 			? ncclSuccess : ncclUnhandledCudaError;
 }
 const char *loop_err(ncclResult_t) { return "loopback exchange failed"; }
-ncclResult_t loop_group() { return ncclSuccess; }
+// grouped send / receive: what is sent to peer p comes back as what is received from peer p --
+// the k-th send to a peer in a group meets the k-th receive from it, as in RCCL
+struct LoopOp { const void *send; void *recv; size_t sbytes, rbytes; hipStream_t s; };
+constexpr int kLoopOps = 4;                 // sends (receives) per peer in one group
+LoopOp g_loop_ops[64][kLoopOps];
+int g_loop_ns[64], g_loop_nr[64];
+bool g_loop_open = false;
+ncclResult_t loop_group_start()
+{
+	memset(g_loop_ops, 0, sizeof(g_loop_ops));
+	memset(g_loop_ns, 0, sizeof(g_loop_ns));
+	memset(g_loop_nr, 0, sizeof(g_loop_nr));
+	g_loop_open = true;
+	return ncclSuccess;
+}
+ncclResult_t loop_send(const void *buf, size_t count, ncclDataType_t, int peer, ncclComm_t, hipStream_t s)
+{
+	if (!g_loop_open || peer < 0 || peer >= 64 || g_loop_ns[peer] >= kLoopOps)
+		return ncclInvalidUsage;
+	LoopOp &o = g_loop_ops[peer][g_loop_ns[peer]++];
+	o.send = buf;
+	o.sbytes = count * 4u;
+	o.s = s;
+	return ncclSuccess;
+}
+ncclResult_t loop_recv(void *buf, size_t count, ncclDataType_t, int peer, ncclComm_t, hipStream_t s)
+{
+	if (!g_loop_open || peer < 0 || peer >= 64 || g_loop_nr[peer] >= kLoopOps)
+		return ncclInvalidUsage;
+	LoopOp &o = g_loop_ops[peer][g_loop_nr[peer]++];
+	o.recv = buf;
+	o.rbytes = count * 4u;
+	o.s = s;
+	return ncclSuccess;
+}
+ncclResult_t loop_group_end()
+{
+	g_loop_open = false;
+	for (int p = 0; p < 64; p++) {
+		if (g_loop_ns[p] != g_loop_nr[p])
+			return ncclInvalidUsage;         // a send without its receive (or the other way round)
+		for (int k = 0; k < g_loop_ns[p]; k++) {
+			const LoopOp &o = g_loop_ops[p][k];
+			if (o.sbytes != o.rbytes)
+				return ncclInvalidUsage;
+			if (hipMemcpyAsync(o.recv, o.send, o.sbytes, hipMemcpyDeviceToDevice, o.s) != hipSuccess)
+				return ncclUnhandledCudaError;
+		}
+	}
+	return ncclSuccess;
+}
 Rccl loopback_api()
 {
 	Rccl a;
@@ -158,8 +221,10 @@ Rccl loopback_api()
 	a.CommDestroy = loop_destroy;
 	a.AllToAll = loop_a2a;
 	a.GetErrorString = loop_err;
-	a.GroupStart = loop_group;
-	a.GroupEnd = loop_group;
+	a.GroupStart = loop_group_start;
+	a.GroupEnd = loop_group_end;
+	a.Send = loop_send;
+	a.Recv = loop_recv;
 	return a;
 }
 }  // namespace
@@ -196,8 +261,11 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 	(void)hipDeviceSynchronize();
 	if (e->comm && e->api.CommDestroy)
 		(void)e->api.CommDestroy(e->comm);
+	for (hipStream_t sv : e->svc)
+		if (sv)
+			(void)hipStreamDestroy(sv);
 	for (Lane &l : e->lane) {
-		if (!l.stream)
+		if (!l.sendbuf)
 			continue;
 		if (l.sendbuf) (void)hipFree(l.sendbuf);
 		if (l.recvbuf) (void)hipFree(l.recvbuf);
@@ -264,14 +332,44 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		if (n >= 2 && n <= 4)
 			e->nlanes = n;
 	}
-	// one rank: the exchanges are local copies, the plain schedule is faster (99 vs 106 us per
-	// step); several ranks: exchanges take time and RCCL runs them one after the other, so the
-	// grouped exchange wins (120 vs 131 us with 40 us of stand-in transfer time)
-	e->fused = world > 1;
-	if (const char *v = getenv("MKV_SHARD_FUSED"))
+	// Schedules.  Default: run_cs.  MKV_SHARD_SCHED=plain / fused: the two older ones (lanes with a
+	// stream each; fused = one grouped collective per batch, packs on streams of their own), kept
+	// for comparison; MKV_SHARD_FUSED=0/1 selects between those two as before.
+	const char *sched = getenv("MKV_SHARD_SCHED");
+	e->sched_cs = !sched || !strcmp(sched, "cs");
+	e->fused = sched && !strcmp(sched, "fused");
+	if (const char *v = getenv("MKV_SHARD_FUSED")) {
 		e->fused = atoi(v) != 0;
-	if (const char *v = getenv("MKV_SHARD_CSTREAM"))
-		e->one_compute_stream = atoi(v) != 0;
+		e->sched_cs = 0;
+	}
+	if (e->sched_cs) {
+		e->fused = 0;
+		// buffer sets = batches in flight: two with one rank (67.9 - 69.7 us per step against 70.3 - 71.7
+		// with three), three with several (the exchanges take their time on the service streams)
+		e->nlanes = world > 1 ? 3 : 2;
+		if (const char *v = getenv("MKV_SHARD_LANES")) {
+			const int n = atoi(v);
+			if (n >= 2 && n <= 4)
+				e->nlanes = n;
+		}
+		e->one_compute_stream = 1;
+		if (const char *v = getenv("MKV_SHARD_PACED"))
+			e->host_paced = atoi(v) != 0;
+		e->nsvc = world > 1 ? 2 : 1;
+		if (const char *v = getenv("MKV_SHARD_SVC")) {
+			const int n = atoi(v);
+			if (n >= 1 && n <= 3)
+				e->nsvc = n;
+		}
+	} else {
+		e->one_compute_stream = 0;
+		if (const char *v = getenv("MKV_SHARD_CSTREAM"))
+			e->one_compute_stream = atoi(v) != 0;
+	}
+	// what a rank sends to itself bypasses the exchange (not in the fused schedule)
+	e->self_direct = !e->fused && world <= 16;      // (the one-launch pack handles up to 16 shards)
+	if (const char *v = getenv("MKV_SHARD_SELF"))
+		e->self_direct = atoi(v) != 0 && !e->fused && world <= 16;
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
 	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
 
@@ -297,6 +395,8 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	SH_SYM(GetErrorString, "ncclGetErrorString");
 	SH_SYM(GroupStart, "ncclGroupStart");
 	SH_SYM(GroupEnd, "ncclGroupEnd");
+	SH_SYM(Send, "ncclSend");
+	SH_SYM(Recv, "ncclRecv");
 #undef SH_SYM
 	}
 
@@ -307,12 +407,14 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	const size_t res_bytes = (size_t)world * (size_t)(cap_get ? cap_get : 1) * sizeof(loc_t) * 2u;
 	for (int li = 0; li < e->nlanes; li++) {
 		Lane &l = e->lane[li];
-		SH_HIP(e, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
+		if (!e->sched_cs)
+			SH_HIP(e, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
 		SH_HIP(e, hipMalloc(&l.sendbuf, slot_bytes));
 		SH_HIP(e, hipMalloc(&l.recvbuf, slot_bytes));
 		SH_HIP(e, hipMalloc(&l.out_slots, res_bytes));
 		SH_HIP(e, hipMalloc(&l.back_slots, res_bytes));
-		SH_HIP(e, hipMalloc(&l.perm, (size_t)(n_get ? n_get : 1) * sizeof(int32_t)));   // where each GET went
+		const size_t where_bytes = (size_t)(n_get ? n_get : 1) * sizeof(int32_t);
+		SH_HIP(e, hipMalloc(&l.perm, where_bytes));   // where each GET went
 		SH_HIP(e, hipMalloc(&l.scratch, (size_t)e->scratch_bytes + 64));
 		SH_HIP(e, hipMemset(l.sendbuf, 0, slot_bytes));
 		SH_HIP(e, hipMemset(l.recvbuf, 0, slot_bytes));
@@ -327,9 +429,13 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		for (hipEvent_t &ev : l.ev_local)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		SH_HIP(e, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
-		SH_HIP(e, hipStreamCreateWithFlags(&l.aux, hipStreamNonBlocking));
+		// (streams are multiplexed over a handful of hardware queues: two streams that share one wait
+		// for each other's kernels -- only the streams a schedule uses are created)
+		if (e->fused)
+			SH_HIP(e, hipStreamCreateWithFlags(&l.aux, hipStreamNonBlocking));
 		l.perm2[0] = l.perm;
-		SH_HIP(e, hipMalloc(&l.perm2[1], (size_t)(n_get ? n_get : 1) * sizeof(int32_t)));
+		if (e->fused || e->sched_cs)
+			SH_HIP(e, hipMalloc(&l.perm2[1], where_bytes));
 		for (hipEvent_t &ev : l.ev_xchg)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		for (hipEvent_t &ev : l.ev_pack)
@@ -337,13 +443,16 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		for (hipEvent_t &ev : l.ev_recv)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		SH_HIP(e, hipEventCreateWithFlags(&l.ev_aux_done, hipEventDisableTiming));
-		if (cap_set) {
+		if (cap_set && l.stream) {
 			const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, l.stream);
 			if (rc != MKV_OK)
 				return fail(e, rc, "mkv_reserve", nullptr);
 		}
 	}
-	SH_HIP(e, hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+	for (int k = 0; k < (e->sched_cs ? e->nsvc : 0); k++)
+		SH_HIP(e, hipStreamCreateWithFlags(&e->svc[k], hipStreamNonBlocking));
+	if (e->one_compute_stream)
+		SH_HIP(e, hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
 	SH_HIP(e, hipEventCreateWithFlags(&e->ev_cdone, hipEventDisableTiming));
 	if (cap_set && e->one_compute_stream) {
 		const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, e->cstream);
@@ -387,8 +496,9 @@ extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
 	SH_HIP(e, hipMalloc(&drecv, (size_t)w * 16));
 	SH_HIP(e, hipMemcpy(dsend, host, (size_t)w * 16, hipMemcpyHostToDevice));
 	SH_HIP(e, hipMemset(drecv, 0xff, (size_t)w * 16));
-	SH_NCCL(e, e->api.AllToAll(dsend, drecv, 4, ncclInt32, e->comm, e->lane[0].stream));
-	SH_HIP(e, hipStreamSynchronize(e->lane[0].stream));
+	hipStream_t cs0 = e->lane[0].stream ? e->lane[0].stream : e->svc[0];
+	SH_NCCL(e, e->api.AllToAll(dsend, drecv, 4, ncclInt32, e->comm, cs0));
+	SH_HIP(e, hipStreamSynchronize(cs0));
 	SH_HIP(e, hipMemcpy(host, drecv, (size_t)w * 16, hipMemcpyDeviceToHost));
 	(void)hipFree(dsend);
 	(void)hipFree(drecv);
@@ -396,6 +506,39 @@ extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
 		for (int k = 0; k < 4; k++)
 			if (host[i * 4 + k] != (((uint32_t)i << 16) | ((uint32_t)e->rank << 8) | (uint32_t)k))
 				return fail(e, MKV_EHIP, "all-to-all self-check", "block from a peer is not where it belongs");
+	return MKV_OK;
+}
+
+extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, void *stream);
+extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
+		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
+		void *stream, void *timer, int slot, int self, loc_t *self_out, void *done_event);
+
+// Block p of `send` (count words each) to peer p, block p of `recv` from peer p, for every peer but
+// this rank: the all-to-all as RCCL itself composes it (grouped ncclSend / ncclRecv), minus the copy
+// of the own block, which the producing kernels have already put in place.  One rank: nothing.
+static int exchange_peers(mkv_shard *e, const void *send, void *recv, size_t count, hipStream_t s)
+{
+	if (e->world == 1)
+		return MKV_OK;
+	const uint32_t *sp = static_cast<const uint32_t *>(send);
+	uint32_t *rp = static_cast<uint32_t *>(recv);
+	SH_NCCL(e, e->api.GroupStart());
+	ncclResult_t bad = ncclSuccess;
+	for (int p = 0; p < e->world; p++) {
+		if (p == e->rank)
+			continue;
+		ncclResult_t r = e->api.Send(sp + (size_t)p * count, count, ncclInt32, p, e->comm, s);
+		if (r == ncclSuccess)
+			r = e->api.Recv(rp + (size_t)p * count, count, ncclInt32, p, e->comm, s);
+		if (r != ncclSuccess && bad == ncclSuccess)
+			bad = r;
+	}
+	SH_NCCL(e, e->api.GroupEnd());
+	SH_NCCL(e, bad);
 	return MKV_OK;
 }
 
@@ -407,11 +550,33 @@ static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, co
 	int rc;
 	{
 		Span sp("pack", lane, batch, l.stream, tr);
-		rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
-				e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
+		if (e->self_direct) {
+			rc = mkv_pack_requests_self(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
+					e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, e->rank,
+					l.recvbuf + (size_t)e->rank * (size_t)e->slot_words, l.stream);
+			if (rc == MKV_EINVAL) {
+				if (e->packed)
+					return fail(e, MKV_EINVAL, "the pack changed its form in the middle of a run", nullptr);
+				e->self_direct = 0;           // (the pack fell back to its three-pass form: everything by all-to-all)
+				rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
+						e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
+			}
+		} else {
+			rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
+					e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
+		}
 	}
 	if (rc != MKV_OK)
 		return fail(e, rc, "mkv_pack_requests", nullptr);
+	e->packed++;
+	if (e->self_direct) {
+		if (e->world > 1) {
+			Span sp("xchg-fwd", lane, batch, l.stream, tr);
+			rc = exchange_peers(e, l.sendbuf, l.recvbuf, (size_t)e->slot_words, l.stream);
+			fake_xfer(l.stream);
+		}
+		return rc;
+	}
 	Span sp("a2a-fwd", lane, batch, l.stream, tr);
 	SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
 	fake_xfer(l.stream);
@@ -420,7 +585,15 @@ static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, co
 
 static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get, int lane, int batch, bool tr)
 {
-	{
+	if (e->self_direct) {
+		if (e->world > 1) {
+			Span sp("xchg-back", lane, batch, l.stream, tr);
+			const int rc = exchange_peers(e, l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, l.stream);
+			if (rc != MKV_OK)
+				return rc;
+			fake_xfer(l.stream);
+		}
+	} else {
 		Span sp("a2a-back", lane, batch, l.stream, tr);
 		SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
 		fake_xfer(l.stream);
@@ -564,6 +737,186 @@ static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 	return MKV_OK;
 }
 
+// The default schedule.  The local phases update ONE table in batch order: they run back to
+// back on a stream of their own (`cstream`) and never wait for an event that has not long been
+// signalled.  Everything else of a batch -- pack, exchanges, un-pack -- runs on a service stream;
+// B buffer sets (3) keep as many batches in flight.  For batch i (set b = i mod B, which always
+// uses the same service stream) the service stream does, once local(i) is done:
+//     pack(i+B) -> { results of batch i back, requests of batch i+B out } -> un-pack(i)
+// the exchange as ONE grouped launch (or nothing at all with one rank), the pack of batch i+B
+// ahead of it into the set's other `where` array, so that what local(i+B) needs is on its way
+// first and the un-pack, which nobody waits for, comes last.  Streams are multiplexed over a
+// handful of hardware queues, and two streams sharing one wait for each other's kernels
+// (MKV_SHARD_TRACE showed 20 - 60 us holes between local phases with 3 lanes x 2 streams + 1):
+// this schedule keeps 2 streams busy with one rank, 3 with several.
+// Collective order on every rank: fwd(0) .. fwd(B-1), {back(0), fwd(B)}, {back(1), fwd(B+1)}, ...
+static int exchange_pair(mkv_shard *e, Lane &l, bool back, bool fwd, hipStream_t s)
+{
+	if (!back && !fwd)
+		return MKV_OK;
+	if (e->self_direct && e->world == 1)
+		return MKV_OK;
+	SH_NCCL(e, e->api.GroupStart());
+	ncclResult_t bad = ncclSuccess;
+	auto note = [&](ncclResult_t r) { if (r != ncclSuccess && bad == ncclSuccess) bad = r; };
+	if (e->self_direct) {
+		for (int p = 0; p < e->world; p++) {
+			if (p == e->rank)
+				continue;
+			if (back) {
+				const size_t c = (size_t)e->cap_get * 2u;
+				note(e->api.Send(l.out_slots + (size_t)p * c, c, ncclInt32, p, e->comm, s));
+				note(e->api.Recv(l.back_slots + (size_t)p * c, c, ncclInt32, p, e->comm, s));
+			}
+			if (fwd) {
+				const size_t c = (size_t)e->slot_words;
+				note(e->api.Send(l.sendbuf + (size_t)p * c, c, ncclInt32, p, e->comm, s));
+				note(e->api.Recv(l.recvbuf + (size_t)p * c, c, ncclInt32, p, e->comm, s));
+			}
+		}
+	} else {
+		if (back)
+			note(e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, s));
+		if (fwd)
+			note(e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, s));
+	}
+	SH_NCCL(e, e->api.GroupEnd());
+	SH_NCCL(e, bad);
+	fake_xfer(s);
+	return MKV_OK;
+}
+
+static double host_us()
+{
+	struct timespec ts;
+	clock_gettime(CLOCK_MONOTONIC, &ts);
+	return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
+}
+
+static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, hipStream_t main, void *timer,
+		int timer_every, int trace_from)
+{
+	const int B = e->nlanes, K = e->nsvc;
+	static int host_trace = -1;                 // MKV_SHARD_HOSTTIME=1 (diagnostics): host clock at the call's milestones
+	if (host_trace < 0)
+		host_trace = getenv("MKV_SHARD_HOSTTIME") ? 1 : 0;
+	const double h0 = host_trace ? host_us() : 0.0;
+	double h_pro = 0, h_first = 0, h_sync_sum = 0, h_sync_max = 0;
+	hipStream_t C = e->cstream;
+	SH_HIP(e, hipEventRecord(e->ev_start, main));
+	SH_HIP(e, hipStreamWaitEvent(C, e->ev_start, 0));
+	for (int k = 0; k < K; k++)
+		SH_HIP(e, hipStreamWaitEvent(e->svc[k], e->ev_start, 0));
+	auto pack = [&](Lane &l, int j, hipStream_t s, int set, bool tr) -> int {
+		if (n_get[j] > e->n_get || n_set[j] > e->n_set)
+			return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
+		Span sp("pack", set, j, s, tr);
+		int rc;
+		int32_t *where = l.perm2[(j / B) & 1];
+		if (e->self_direct) {
+			rc = mkv_pack_requests_self(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
+					e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, e->rank,
+					l.recvbuf + (size_t)e->rank * (size_t)e->slot_words, s);
+			if (rc == MKV_EINVAL && !e->packed) {
+				e->self_direct = 0;           // (the pack fell back to its three-pass form: everything by all-to-all)
+				rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
+						e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, s);
+			}
+		} else {
+			rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
+					e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, s);
+		}
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_pack_requests", nullptr);
+		e->packed++;
+		return MKV_OK;
+	};
+	int rc = MKV_OK;
+	for (int j = 0; j < B && j < nbatches; j++) {
+		Lane &l = e->lane[j];
+		hipStream_t S = e->svc[j % K];
+		if ((rc = pack(l, j, S, j, false)) != MKV_OK)
+			return rc;
+		if ((rc = exchange_pair(e, l, false, true, S)) != MKV_OK)
+			return rc;
+		SH_HIP(e, hipEventRecord(l.ev_recv[0], S));
+	}
+	if (host_trace)
+		h_pro = host_us();
+	for (int i = 0; i < nbatches; i++) {
+		const int b = i % B, k = (i / B) & 1, k2 = k ^ 1;
+		Lane &l = e->lane[b];
+		hipStream_t S = e->svc[b % K];
+		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
+		const bool more = i + B < nbatches;
+		// Local phase: its requests have arrived (and, earlier on the same service stream, the results
+		// of batch i-B have left the set's result buffers).  The HOST waits for that -- it happened a
+		// local phase or two ago on the device -- and then enqueues the local phase with no wait on
+		// the stream at all: on this runtime a kernel that follows a cross-stream wait starts ~10 us
+		// late even when the event completed long before (tools/probes/event_probe.hip: 72.3 against
+		// 61.5 us per 60-us kernel), while a wait on an event the host already sees complete costs
+		// nothing.  So the call runs at most B - 1 local phases ahead of the device.
+		if (e->host_paced) {
+			const double a = host_trace ? host_us() : 0.0;
+			SH_HIP(e, hipEventSynchronize(l.ev_recv[k]));
+			if (host_trace) {
+				const double d = host_us() - a;
+				h_sync_sum += d;
+				h_sync_max = d > h_sync_max ? d : h_sync_max;
+				if (i == 0)
+					h_first = host_us();
+			}
+		} else
+			SH_HIP(e, hipStreamWaitEvent(C, l.ev_recv[k], 0));
+		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
+		{
+			Span sp("local", b, i, C, tr);
+			rc = mkv_slots_cycle_self(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
+					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, C, timed ? timer : nullptr,
+					timed ? i / timer_every : 0, e->self_direct ? e->rank : -1,
+					l.back_slots + (size_t)e->rank * (size_t)e->cap_get * 2u, tr ? nullptr : l.ev_local[k]);
+		}
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_slots_cycle", nullptr);
+		if (tr)                                          // (a traced span puts an event of its own behind the phase)
+			SH_HIP(e, hipEventRecord(l.ev_local[k], C));
+		// service stream: the set's next batch first, the results of this one behind it
+		SH_HIP(e, hipStreamWaitEvent(S, l.ev_local[k], 0));
+		if (more && (rc = pack(l, i + B, S, b, tr)) != MKV_OK)
+			return rc;
+		{
+			Span sp("exchange", b, i, S, tr);
+			if ((rc = exchange_pair(e, l, true, more, S)) != MKV_OK)
+				return rc;
+		}
+		if (more)
+			SH_HIP(e, hipEventRecord(l.ev_recv[k2], S));
+		{
+			Span sp("unpack", b, i, S, tr);
+			rc = mkv_unpack_results(l.back_slots, l.perm2[k], n_get[i], outs[i], S);
+		}
+		if (rc != MKV_OK)
+			return fail(e, rc, "mkv_unpack_results", nullptr);
+		SH_HIP(e, hipEventRecord(l.ev_xchg[k], S));      // the set's result buffers are free again
+	}
+	for (int k = 0; k < K; k++) {
+		SH_HIP(e, hipEventRecord(e->lane[k].ev_done, e->svc[k]));
+		SH_HIP(e, hipStreamWaitEvent(main, e->lane[k].ev_done, 0));
+	}
+	SH_HIP(e, hipEventRecord(e->ev_cdone, C));
+	SH_HIP(e, hipStreamWaitEvent(main, e->ev_cdone, 0));
+	if (host_trace) {
+		const double h1 = host_us();
+		(void)hipStreamSynchronize(main);
+		const double h2 = host_us();
+		fprintf(stderr, "run_cs %d batches: prologue enqueued %.0f us, first requests in %.0f us, loop done %.0f us, "
+				"device done %.0f us; host waits %.0f us in all, longest %.0f us\n", nbatches, h_pro - h0, h_first - h0,
+				h1 - h0, h2 - h0, h_sync_sum, h_sync_max);
+	}
+	return MKV_OK;
+}
+
 // nbatches batches of this rank: gets[i] (n_get[i] x selem_t), sets[i] (n_set[i] x ielem_t),
 // outs[i] (n_get[i] x 2 loc_t, request order) -- all device pointers, host arrays of them.
 // Everything is enqueued (no host synchronisation); the lanes start after what is queued
@@ -586,6 +939,12 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	const int trace_from = g_trace.on > 0 && nbatches > g_trace.on + 16 ? nbatches - g_trace.on - 8 : nbatches + 1;
 	g_trace.n = 0;
 	int rc = MKV_OK;
+	if (e->sched_cs) {
+		rc = run_cs(e, nbatches, gets, n_get, sets, n_set, outs, main, timer, timer_every, trace_from);
+		if (rc == MKV_OK)
+			print_trace();
+		return rc;
+	}
 	if (e->fused) {
 		rc = run_fused(e, nbatches, gets, n_get, sets, n_set, outs, main, timer, timer_every, trace_from);
 		if (rc == MKV_OK)
@@ -595,12 +954,25 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	SH_HIP(e, hipEventRecord(e->ev_start, main));
 	for (int li = 0; li < L; li++)
 		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
+	// The local phases update ONE table in batch order.  On the lanes' own streams each would wait
+	// for the one before it through an event of ANOTHER stream -- 12 - 20 us of hand-over per batch
+	// on the critical path (MKV_SHARD_TRACE).  By default they all run on one stream of their own,
+	// back to back; what a local phase waits for there -- its requests packed and exchanged -- has
+	// been done for a whole local phase by then, and its lane's stream waits for IT before the
+	// results go back (MKV_SHARD_CSTREAM=0: the lanes' streams chained by events).
+	const bool cs = e->one_compute_stream != 0;
+	hipStream_t C = e->cstream;
+	if (cs)
+		SH_HIP(e, hipStreamWaitEvent(C, e->ev_start, 0));
 	// L batches in flight: the forward half of batch i+L-1 is queued before the local phase
 	// of batch i, so a lane has the time of L-1 local phases for its exchanges
 	for (int j = 0; j < L - 1 && j < nbatches; j++) {
-		rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j], j % L, j, false);
+		Lane &lj = e->lane[j % L];
+		rc = forward(e, lj, gets[j], n_get[j], sets[j], n_set[j], j % L, j, false);
 		if (rc != MKV_OK)
 			return rc;
+		if (cs)
+			SH_HIP(e, hipEventRecord(lj.ev_recv[(j / L) & 1], lj.stream));
 	}
 	hipEvent_t prev_local = nullptr;
 	for (int i = 0; i < nbatches; i++) {
@@ -608,23 +980,32 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
 		const int j = i + L - 1;
 		if (j < nbatches) {
-			rc = forward(e, e->lane[j % L], gets[j], n_get[j], sets[j], n_set[j], j % L, j, tr);
+			Lane &lj = e->lane[j % L];
+			rc = forward(e, lj, gets[j], n_get[j], sets[j], n_set[j], j % L, j, tr);
 			if (rc != MKV_OK)
 				return rc;
+			if (cs)
+				SH_HIP(e, hipEventRecord(lj.ev_recv[(j / L) & 1], lj.stream));
 		}
-		if (prev_local)
+		hipStream_t ls = cs ? C : l.stream;               // where this batch's local phase runs
+		if (cs)
+			SH_HIP(e, hipStreamWaitEvent(C, l.ev_recv[(i / L) & 1], 0));   // (also: the lane's un-pack of batch i-L is done)
+		else if (prev_local)
 			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
 		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
 		{
-			Span sp("local", i % L, i, l.stream, tr);
-			rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
-					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, l.stream, timed ? timer : nullptr,
-					timed ? i / timer_every : 0);
+			Span sp("local", i % L, i, ls, tr);
+			rc = mkv_slots_cycle_self(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
+					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, ls, timed ? timer : nullptr,
+					timed ? i / timer_every : 0, e->self_direct ? e->rank : -1,
+					l.back_slots + (size_t)e->rank * (size_t)e->cap_get * 2u, nullptr);
 		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_slots_cycle", nullptr);
 		prev_local = l.ev_local[(i / L) & 1];
-		SH_HIP(e, hipEventRecord(prev_local, l.stream));
+		SH_HIP(e, hipEventRecord(prev_local, ls));
+		if (cs)
+			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
 		rc = backward(e, l, outs[i], n_get[i], i % L, i, tr);
 		if (rc != MKV_OK)
 			return rc;
@@ -633,6 +1014,10 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 		Lane &l = e->lane[li];
 		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
 		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
+	}
+	if (cs) {
+		SH_HIP(e, hipEventRecord(e->ev_cdone, C));
+		SH_HIP(e, hipStreamWaitEvent(main, e->ev_cdone, 0));
 	}
 	print_trace();
 	return MKV_OK;

@@ -991,7 +991,8 @@ template <Op OP>
 __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__restrict__ recvbuf,
 		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
 		uint32_t chunks_per_slot, uint32_t search_blocks, Ctl *ctl, ReqSrc src, DevGeom g,
-		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx)
+		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx,
+		uint32_t self, uint32_t *__restrict__ self_out)
 {
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
@@ -999,7 +1000,7 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 				reinterpret_cast<const uint32_t *>(table));
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
-				g.blk_mask, chunks_per_slot);
+				g.blk_mask, chunks_per_slot, self, self_out);
 }
 
 __device__ __forceinline__ bool tag_logged(uint32_t st)
@@ -3171,7 +3172,7 @@ static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipSt
 
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
-		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1);
+		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1, hipEvent_t done_ev = nullptr);
 
 // Canonical-index passes of one call.  With a size hint from the caller a large batch runs
 // pass after pass (stream order = canonical order), Tuning::insert_chunk requests each; no
@@ -3301,9 +3302,12 @@ static unsigned tail_groups_for()
 }
 
 // K2..K4
+// done_ev: an event that completes with the LAST kernel of the pass (the tail launch delivers its
+// end into it, hipExtLaunchKernelGGL): what a hipEventRecord behind the launch would give, without
+// the marker packet of its own (3 us between two kernels of a stream, tools/probes/event_probe.hip)
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
-		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk)
+		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev)
 {
 	int tail_rounds = tuning().tail_rounds;
 	if (tail_rounds > kMaxTailRounds)
@@ -3314,7 +3318,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
 			(uint32_t)(2 * w->req_cap), (w->record_hint ? 1 : 0) | (tuning().debug_skip & 4));
-	hipLaunchKernelGGL((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[0],
+	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[0],
 			w->owner[1], w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3);
@@ -3495,10 +3499,29 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 // what the slots carry (one block per source rank, counts read from the slot headers
 // on the device).  set_ptrs: device array of the nslots device pointers to the slots'
 // insert regions (fixed per receive buffer).
+extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
+		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
+		void *stream, void *timer, int slot, int self, loc_t *self_out, void *done_event);
+
 extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
 		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
 		void *stream, void *timer, int slot)
 {
+	return mkv_slots_cycle_self(geom, recvbuf, nslots, cap_get, cap_set, out_slots, table, set_ptrs, size_hint, stream,
+			timer, slot, -1, nullptr, nullptr);
+}
+
+// The same with the results of slot `self` written to self_out (cap_get x 2 loc_t) instead of their
+// place in out_slots (the sharded engine: a rank's answers to itself go straight into its buffer of
+// returned results).  self < 0: none.  done_event (a hipEvent_t, or NULL): completes with the call's
+// last kernel, as if recorded behind it.
+extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
+		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
+		void *stream, void *timer, int slot, int self, loc_t *self_out, void *done_event)
+{
+	if (self >= nslots || (self >= 0 && !self_out))
+		return MKV_EINVAL;
+	const uint32_t self_u = self >= 0 ? (uint32_t)self : 0xffffffffu;
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || nslots < 1 || nslots > mkv::kMaxBlocks || cap_get < 0 ||
 			cap_get > 0x7fffffffLL || cap_set < 0 || !recvbuf || !out_slots || !table)
@@ -3517,7 +3540,9 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), s, tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr,
 				recvbuf, slot_words, (uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks,
 				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (uint4 *)nullptr,
-				(uint8_t *)nullptr, 0u, 0u);
+				(uint8_t *)nullptr, 0u, 0u, self_u, self_out);
+		if (done_event && hipEventRecord((hipEvent_t)done_event, s) != hipSuccess)
+			return MKV_EHIP;
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
 	mkv::ReqSrc src;
@@ -3546,22 +3571,23 @@ extern "C" int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, 
 	if (cuckoo)
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
+				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
+				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
 		mkv::chunk_range(c, ck, &lo, &hi);
+		hipEvent_t dev = c == nchunks - 1 ? (hipEvent_t)done_event : nullptr;
 		if (cuckoo) {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, dev);
 		} else {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, dev);
 		}
 		if (rc != MKV_OK)
 			return rc;

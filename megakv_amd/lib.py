@@ -143,7 +143,7 @@ def load_library():
     L.mkv_resolve_results.restype = INT
     L.mkv_resolve_results.argtypes = [P, I64, P, P, P]
     L.mkv_resolve_verify.restype = INT
-    L.mkv_resolve_verify.argtypes = [P, I64, P, I64, INT, P, I64, I64, INT, INT, P, P, P]
+    L.mkv_resolve_verify.argtypes = [P, I64, P, I64, INT, P, I64, I64, INT, INT, INT, P, P, P]
     L.mkv_unpack_results.restype = INT
     L.mkv_unpack_results.argtypes = [P, P, I64, P, P]
     L.mkv_unroute_results.restype = INT

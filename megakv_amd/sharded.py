@@ -151,19 +151,27 @@ class NativeEngine:
                 self.close()                      # a half-built engine is of no use: free what it holds
             raise RuntimeError(f"{what} failed ({rc}): {text}")
 
-    def run(self, batches, stream=None, timer=None, timer_every=0):
+    def prepare(self, batches, timer=None, timer_every=0):
+        """The argument arrays of a run (device pointers and counts) built once; returns a callable
+        that enqueues the run on the stream current at call time."""
         n = len(batches)
         if n == 0:
-            return
+            return lambda: None
         P, I64 = ctypes.c_void_p, ctypes.c_int64
         gets = (P * n)(*[b["q"].data_ptr() if b["q"].shape[0] else None for b in batches])
         sets = (P * n)(*[b["s"].data_ptr() if b["s"].shape[0] else None for b in batches])
         outs = (P * n)(*[b["out"].data_ptr() for b in batches])
         ng = (I64 * n)(*[b["q"].shape[0] for b in batches])
         ns = (I64 * n)(*[b["s"].shape[0] for b in batches])
-        self._check(self.lib.mkv_shard_run(self.h, n, gets, ng, sets, ns, outs, _stream_ptr(stream),
-                                           ctypes.c_void_p(timer) if timer else None, int(timer_every)),
-                    "mkv_shard_run")
+        tm = ctypes.c_void_p(timer) if timer else None
+
+        def go(stream=None):
+            self._check(self.lib.mkv_shard_run(self.h, n, gets, ng, sets, ns, outs, _stream_ptr(stream), tm,
+                                               int(timer_every)), "mkv_shard_run")
+        return go
+
+    def run(self, batches, stream=None, timer=None, timer_every=0):
+        self.prepare(batches, timer, timer_every)(stream)
 
     def overflowed(self):
         flag = ctypes.c_int(0)
@@ -290,6 +298,19 @@ class ShardedIndex:
         self._local(ln, getattr(self, "_timing", None))
         self._backward(ln, out)
 
+    def prepare_pipelined(self, batches, timing_of=None):
+        """run_pipelined with the marshalling done now: returns a callable that enqueues the run."""
+        if self.native is None or not batches:
+            return lambda: self.run_pipelined(batches, timing_of) if batches else None
+        timer, every = None, 0
+        if timing_of is not None:
+            # (timing_of(i) -> [timer handle, slot] on every `every`-th batch, slot = i // every)
+            hits = [i for i in range(len(batches)) if timing_of(i)]
+            if hits:
+                timer = timing_of(hits[0])[0]
+                every = hits[1] - hits[0] if len(hits) > 1 else len(batches)
+        return self.native.prepare(batches, timer if isinstance(timer, int) or timer is None else timer.h, every)
+
     def run_pipelined(self, batches, timing_of=None):
         """All batches, software-pipelined over two lanes: the forward exchange of batch
         i+1 and the result exchange of batch i-1 overlap the local kernels of batch i.
@@ -301,14 +322,7 @@ class ShardedIndex:
         if not batches:
             return
         if self.native is not None:
-            timer, every = None, 0
-            if timing_of is not None:
-                # (timing_of(i) -> [timer handle, slot] on every `every`-th batch, slot = i // every)
-                hits = [i for i in range(len(batches)) if timing_of(i)]
-                if hits:
-                    timer = timing_of(hits[0])[0]
-                    every = hits[1] - hits[0] if len(hits) > 1 else len(batches)
-            self.native.run(batches, None, timer if isinstance(timer, int) or timer is None else timer.h, every)
+            self.prepare_pipelined(batches, timing_of)()
             return
         main = torch.cuda.current_stream()
         start = torch.cuda.Event()

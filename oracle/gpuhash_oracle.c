@@ -530,3 +530,38 @@ int orc_parse_packet(const uint8_t *b, uint32_t len, uint32_t packet, uint32_t k
 	}
 	return 0;
 }
+
+/* The sender's result consumption with KEY_MATCH (ref src/mega_send.c:408-414: the primary
+ * bucket's location unless it is 0, then the alternate's; :464-466: 0 = miss; :543-553: the
+ * item's nkey and key against the request's, with strncmp -- the libc function itself is
+ * called here, so its stop-at-NUL behaviour is the reference's by construction). */
+void orc_resolve_verify(const uint32_t *pairs, int64_t n, const uint8_t *keys, int64_t key_stride, int key_len,
+		const uint8_t *arena, int64_t item_stride, int64_t arena_items, int nkey_off, int key_off, int bytes_mode,
+		uint32_t *out_loc, uint64_t totals[3])
+{
+	totals[0] = totals[1] = totals[2] = 0;
+	for (int64_t i = 0; i < n; i++) {
+		uint32_t loc = pairs[2 * i];                       /* :408 */
+		if (loc == 0)
+			loc = pairs[2 * i + 1];                        /* :409-411 */
+		int ok = 0;
+		if (loc != 0 && (int64_t)loc < arena_items) {
+			const uint8_t *it = arena + (int64_t)loc * item_stride;
+			uint16_t nkey;
+			memcpy(&nkey, it + nkey_off, sizeof(nkey));    /* items.h: uint16_t nkey */
+			const char *ikey = (const char *)it + key_off; /* ITEM_key(it) */
+			const char *key = (const char *)keys + i * key_stride;
+			if (bytes_mode)
+				ok = nkey == key_len && memcmp(ikey, key, (size_t)key_len) == 0;
+			else
+				ok = nkey == key_len && strncmp(ikey, key, (size_t)key_len) == 0;   /* :544 */
+		}
+		out_loc[i] = ok ? loc : 0;
+		if (ok)
+			totals[0]++;                                   /* cc->hit ++ */
+		else
+			totals[1]++;                                   /* cc->miss ++ */
+		if (loc != 0 && !ok)
+			totals[2]++;
+	}
+}

@@ -74,6 +74,18 @@ int orc_parse_packet(const uint8_t *payload, uint32_t len, uint32_t packet, uint
 		uint32_t value_len, int fold, uint32_t *gets, int64_t *n_get, uint32_t *sets, int64_t *n_set,
 		int64_t *n_bad);
 
+/* What the reference's sender does with the pair a search returned, KEY_MATCH build
+ * (src/mega_send.c:408-414 pick, :543-553 verify): loc = pair[0] ? pair[0] : pair[1]; the item it
+ * names must hold the request's key -- `it->nkey == key_len && strncmp(ITEM_key(it), key, key_len)
+ * == 0` -- else the request counts as a miss.  A flat arena stands in for the slab store (item
+ * `l` at arena + l * item_stride, l < arena_items; header src/include/items.h:37-50: nkey at byte
+ * nkey_off, key at key_off).  bytes_mode != 0 compares all key_len bytes (memcmp) instead of the
+ * reference's strncmp, which stops at the first NUL.  out_loc[i] = loc or 0;
+ * totals[0..2] = hits, misses, false positives (a location whose item fails the compare). */
+void orc_resolve_verify(const uint32_t *pairs, int64_t n, const uint8_t *keys, int64_t key_stride, int key_len,
+		const uint8_t *arena, int64_t item_stride, int64_t arena_items, int nkey_off, int key_off, int bytes_mode,
+		uint32_t *out_loc, uint64_t totals[3]);
+
 #ifdef __cplusplus
 }
 #endif

@@ -194,3 +194,24 @@ def parse_packets(payloads, lens, key_len, value_len, fold=False):
                                 ctypes.byref(nb))
         bad_packets += 1 if rc != 0 else 0
     return gets[:ng.value].copy(), sets[:ns.value].copy(), bad_packets, nb.value
+
+
+def resolve_verify(pairs, keys, key_len, arena, item_stride, nkey_off=10, key_off=24, bytes_mode=False):
+    """orc_resolve_verify: the sender's pick + KEY_MATCH compare (src/mega_send.c:408-414, 543-553).
+    pairs [n,2] uint32, keys [n,key_stride] uint8, arena [items,item_stride] uint8.
+    Returns (loc [n] uint32, hits, misses, false positives)."""
+    L = lib()
+    L.orc_resolve_verify.restype = None
+    L.orc_resolve_verify.argtypes = [ctypes.c_void_p, ctypes.c_int64, ctypes.c_void_p, ctypes.c_int64, ctypes.c_int,
+                                     ctypes.c_void_p, ctypes.c_int64, ctypes.c_int64, ctypes.c_int, ctypes.c_int,
+                                     ctypes.c_int, ctypes.c_void_p, ctypes.c_void_p]
+    pairs = np.ascontiguousarray(pairs, dtype=np.uint32)
+    keys = np.ascontiguousarray(keys, dtype=np.uint8)
+    arena = np.ascontiguousarray(arena, dtype=np.uint8)
+    n = pairs.shape[0]
+    out = np.zeros(n, np.uint32)
+    tot = np.zeros(3, np.uint64)
+    L.orc_resolve_verify(pairs.ctypes.data, n, keys.ctypes.data, keys.shape[1] if n else key_len, key_len,
+                         arena.ctypes.data, item_stride, arena.shape[0], nkey_off, key_off, 1 if bytes_mode else 0,
+                         out.ctypes.data, tot.ctypes.data)
+    return out, int(tot[0]), int(tot[1]), int(tot[2])

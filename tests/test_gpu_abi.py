@@ -98,6 +98,19 @@ def test_plain_c_scheduler_driver_runs_clean():
     assert "errors 0" in r.stdout and "no copies" in r.stdout
 
 
+def test_cycle_captured_into_a_hipgraph_through_the_c_api():
+    """examples/graph_cycle.c (gcc, HIP's C header): one mkv_cycle captured with
+    hipStreamBeginCapture, replayed, against the same cycles issued eagerly from the same start:
+    identical table, every GET answered with its own location."""
+    import os
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "megakv_amd", "_lib", "graph_cycle")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    r = subprocess.run([exe, "24", "16", "50", "20"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "tables identical" in r.stdout and "wrong results 0" in r.stdout, r.stdout + r.stderr
+
+
 def test_pipelines_come_and_go_without_leaking_device_memory():
     """The library-owned streams of a pipeline (and of a shard engine) hold no update workspace
     of their own: creating and destroying pipelines leaves the free device memory where it was."""

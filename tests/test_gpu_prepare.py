@@ -153,27 +153,50 @@ def test_resolve_results_like_the_sender(n):
     assert int(c[64]) == int((exp != 0).sum()) and int(c[65]) == n - int((exp != 0).sum())
 
 
-@pytest.mark.parametrize("n,key_len", [(0, 8), (1, 8), (5000, 8), (200003, 16), (3001, 33)])
-def test_resolve_with_key_match_like_the_sender(n, key_len):
-    """src/mega_send.c:408-414 + 543-553 (KEY_MATCH): the location picked from the pair must
-    name an item whose key length and key bytes equal the request's; else it is a miss.  The
-    slab store is a flat arena here (reference item header: nkey at byte 10, key at byte 24,
-    src/include/items.h:37-50).  Host restatement vs the device, incl. false positives (a
-    location whose item holds another key), a wrong nkey, out-of-range locations and the
-    reference's blind spot (a false positive in the primary bucket hides the alternate)."""
+def _verify_on_device(pairs, keys, key_len, arena, stride, items, nkey_off, key_off, compare):
     L = load_library()
+    n = pairs.shape[0]
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+    d_pairs = dev(pairs) if n else torch.zeros((1, 2), dtype=torch.int32, device="cuda")
+    d_keys, d_arena = d(keys if n else np.zeros((1, keys.shape[1]), np.uint8)), d(arena)
+    loc = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
+    ctr = torch.zeros(68, dtype=torch.int64, device="cuda")
+    assert L.mkv_resolve_verify(_dev_ptr(d_pairs), n, _dev_ptr(d_keys), keys.shape[1], key_len, _dev_ptr(d_arena), stride,
+                                items, nkey_off, key_off, compare, _dev_ptr(loc), _dev_ptr(ctr), _stream_ptr(None)) == 0
+    torch.cuda.synchronize()
+    c = ctr.cpu().numpy()
+    return host(loc)[:n], (int(c[64]), int(c[65]), int(c[66]))
+
+
+@pytest.mark.parametrize("compare", [0, 1], ids=["strncmp", "bytes"])
+@pytest.mark.parametrize("n,key_len,pad", [(0, 8, 3), (1, 8, 0), (5000, 8, 0), (200003, 16, 3), (3001, 33, 3), (777, 130, 1)])
+def test_resolve_with_key_match_like_the_sender(n, key_len, pad, compare):
+    """src/mega_send.c:408-414 + 543-553 (KEY_MATCH): the location picked from the pair must
+    name an item whose key length equals the request's and whose key compares equal -- with
+    strncmp in the reference (compare 0: it stops at the first NUL), or byte for byte (compare
+    1); else it is a miss.  The slab store is a flat arena here (reference item header: nkey at
+    byte 10, key at byte 24, src/include/items.h:37-50).  Checked against the C restatement of
+    those lines (oracle/gpuhash_oracle.c: orc_resolve_verify, which calls libc's strncmp), incl.
+    false positives (a location whose item holds another key), a wrong nkey, out-of-range
+    locations, the reference's blind spot (a false positive in the primary bucket hides the
+    alternate), keys full of NUL bytes, and unaligned key strides."""
     rng = np.random.default_rng(n + key_len)
-    items, stride, nkey_off, key_off = 4096, 64, 10, 24
+    items, stride, nkey_off, key_off = 4096, 24 + ((key_len + 15) // 16) * 16, 10, 24
     arena = rng.integers(0, 256, size=(items, stride), dtype=np.uint8)
     item_keys = rng.integers(0, 256, size=(items, key_len), dtype=np.uint8)
+    item_keys[rng.random(item_keys.shape) < 0.15] = 0                   # NUL bytes anywhere
     arena[:, key_off:key_off + key_len] = item_keys
     arena[:, nkey_off] = key_len & 0xff
     arena[:, nkey_off + 1] = key_len >> 8
     wrong_len = rng.random(items) < 0.05
     arena[wrong_len, nkey_off] = (key_len + 1) & 0xff                  # same bytes, another length
     true_loc = rng.integers(1, items, size=n).astype(np.uint32)
-    keys = np.zeros((n, key_len + 3), np.uint8)                        # (a stride wider than the key)
+    keys = np.zeros((n, key_len + pad), np.uint8)                      # (a stride wider than the key, unaligned)
     keys[:, :key_len] = item_keys[true_loc] if n else 0
+    # some requests differ from their item only in ONE byte, before or after a NUL
+    flip = rng.random(n) < 0.3
+    pos = rng.integers(0, key_len, size=n)
+    keys[flip, pos[flip]] ^= 0x5a
     pairs = np.zeros((n, 2), np.uint32)
     kind = rng.integers(0, 6, size=n)
     other = rng.integers(1, items, size=n).astype(np.uint32)
@@ -183,30 +206,43 @@ def test_resolve_with_key_match_like_the_sender(n, key_len):
     pairs[kind == 2, 1] = true_loc[kind == 2]                           # ... the true entry (reference: a miss)
     pairs[kind == 3, 1] = other[kind == 3]                              # false positive (unless other == true)
     pairs[kind == 5, 0] = items + 77                                    # a location outside the arena
-    # host restatement
-    pick = np.where(pairs[:, 0] != 0, pairs[:, 0], pairs[:, 1])
-    exp = np.zeros(n, np.uint32)
-    fp = 0
-    for i in range(n):
-        l = int(pick[i])
-        if l == 0:
-            continue
-        ok = l < items and (int(arena[l, nkey_off]) | int(arena[l, nkey_off + 1]) << 8) == key_len \
-            and bytes(arena[l, key_off:key_off + key_len]) == bytes(keys[i, :key_len])
-        if ok:
-            exp[i] = l
-        else:
-            fp += 1
-    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
-    d_pairs = dev(pairs) if n else torch.zeros((1, 2), dtype=torch.int32, device="cuda")
-    d_keys, d_arena = d(keys if n else np.zeros((1, key_len + 3), np.uint8)), d(arena)
-    loc = torch.zeros(max(n, 1), dtype=torch.int32, device="cuda")
-    ctr = torch.zeros(68, dtype=torch.int64, device="cuda")
-    assert L.mkv_resolve_verify(_dev_ptr(d_pairs), n, _dev_ptr(d_keys), key_len + 3, key_len, _dev_ptr(d_arena), stride,
-                                items, nkey_off, key_off, _dev_ptr(loc), _dev_ptr(ctr), _stream_ptr(None)) == 0
-    torch.cuda.synchronize()
-    assert np.array_equal(host(loc)[:n], exp)
-    c = ctr.cpu().numpy()
-    assert (int(c[64]), int(c[65]), int(c[66])) == (int((exp != 0).sum()), n - int((exp != 0).sum()), fp)
+    exp, hits, misses, fp = O.resolve_verify(pairs, keys, key_len, arena, stride, nkey_off, key_off, bytes_mode=bool(compare))
+    got, totals = _verify_on_device(pairs, keys, key_len, arena, stride, items, nkey_off, key_off, compare)
+    assert np.array_equal(got, exp)
+    assert totals == (hits, misses, fp)
     if n > 1000:
-        assert fp > 0 and int(c[64]) > 0
+        assert fp > 0 and hits > 0
+
+
+def test_key_match_on_the_reference_keys_differs_from_a_byte_compare():
+    """The reference's LOCAL_TEST / benchmark keys are 8 bytes {k, (k & 7) << 29 | k}
+    (src/mega_recv.c:700-704, benchmark/benchmark.c:495-499): little-endian k < 2^24 has NUL
+    bytes from byte 1..3 on, so to strncmp (src/mega_send.c:544) every item whose key shares the
+    bytes before the first NUL IS the key.  The device follows the reference on exactly that
+    (compare 0) and tells the keys apart byte for byte on request (compare 1)."""
+    items, stride, nkey_off, key_off, key_len = 1 << 16, 40, 10, 24, 8
+    k = np.arange(items, dtype=np.uint32)
+    item_keys = np.stack([k, ((k & 7) << 29) | k], axis=1).astype(np.uint32).view(np.uint8).reshape(items, 8)
+    arena = np.zeros((items, stride), np.uint8)
+    arena[:, key_off:key_off + 8] = item_keys
+    arena[:, nkey_off] = key_len
+    n = 50000
+    rng = np.random.default_rng(3)
+    want = rng.integers(1, items, size=n).astype(np.uint32)                 # the key the request asks for
+    # the location a 32-bit signature collision would return: another key id with the same low byte
+    # (and, for ids < 256, the same bytes up to the first NUL)
+    coll = ((rng.integers(0, items >> 8, size=n).astype(np.uint32) << 8) | (want & 0xff)).astype(np.uint32)
+    coll[coll == 0] = 256
+    keys = item_keys[want]
+    pairs = np.zeros((n, 2), np.uint32)
+    pairs[:, 0] = np.where(rng.random(n) < 0.5, want, coll)
+    for compare in (0, 1):
+        exp, hits, misses, fp = O.resolve_verify(pairs, keys, key_len, arena, stride, nkey_off, key_off, bytes_mode=bool(compare))
+        got, totals = _verify_on_device(pairs, keys, key_len, arena, stride, items, nkey_off, key_off, compare)
+        assert np.array_equal(got, exp) and totals == (hits, misses, fp), compare
+        if compare == 0:
+            accepted_wrong = int(((got != 0) & (pairs[:, 0] != want)).sum())
+        else:
+            assert int(((got != 0) & (pairs[:, 0] != want)).sum()) == 0
+    assert accepted_wrong > 0, "strncmp accepts keys that differ behind a NUL: the reference's behaviour"
+

@@ -21,12 +21,14 @@ def test_sharded_pipelined_two_lanes(world):
 
 
 @pytest.mark.parametrize("g,n_get,n_set,three_pass", [(1, 5000, 300, 0), (2, 70001, 4099, 0), (8, 200000, 30000, 0),
-                                                        (4, 0, 2500, 0), (4, 3000, 0, 0), (8, 50000, 5000, 1)])
+                                                        (4, 0, 2500, 0), (4, 3000, 0, 0), (8, 50000, 5000, 1),
+                                                        (1, 1 << 20, 52428, 0), (8, 996149, 52427, 0), (16, 600001, 9, 0),
+                                                        (2, 1, 1, 0), (8, 4097, 4097, 0)])
 def test_pack_layout(g, n_get, n_set, three_pass):
     """mkv_pack_requests: every request lands in the slot of its shard; SET slots keep
     batch order (the canonical insert order of a shard is source rank, then index); GET
     slots hold the right requests in any order, `perm[e]` telling where request e went;
-    headers count."""
+    headers count.  Then the way back: results laid out like the slots return to request order."""
     import ctypes
     import numpy as np
     import torch
@@ -40,13 +42,13 @@ def test_pack_layout(g, n_get, n_set, three_pass):
         mask, shift = (1 << (mem_p_agg - 6)) - 1, mem_p_agg - 6 - (g.bit_length() - 1)
         gets = rng.integers(0, 2**32, size=(n_get, 2), dtype=np.uint64).astype(np.uint32)
         sets = rng.integers(0, 2**32, size=(n_set, 3), dtype=np.uint64).astype(np.uint32)
-        cap_get = (int(n_get / g * 1.5) + 255) // 256 * 256 if n_get else 0
+        cap_get = max(256, (int(n_get / g * 1.5) + 255) // 256 * 256) if n_get else 0
         cap_set = (int(n_set / g * 1.5) + 15) // 16 * 16 + 16 if n_set else 0
         sw = int(L.mkv_pack_slot_words(cap_get, cap_set))
         dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).cuda()
         dg, ds = dev(gets), dev(sets)
         sendbuf = torch.zeros((g, sw), dtype=torch.int32, device="cuda")
-        perm = torch.full((g * max(cap_get, 1),), -1, dtype=torch.int32, device="cuda")
+        perm = torch.full((max(n_get, 1) + 3,), -1, dtype=torch.int32, device="cuda")
         nbytes = int(L.mkv_pack_scratch_bytes(max(n_get, 1), max(n_set, 1), g))
         scratch = torch.zeros((nbytes // 4 + 16,), dtype=torch.int32, device="cuda")
         overflow = torch.zeros((1,), dtype=torch.int32, device="cuda")
@@ -77,12 +79,26 @@ def test_pack_layout(g, n_get, n_set, three_pass):
                 assert np.array_equal(got_g[pos], gets[want_g])
                 got_s = sb[s, 4 + 2 * cap_get:4 + 2 * cap_get + 3 * len(want_s)].reshape(-1, 3)
                 assert np.array_equal(got_s, sets[want_s])
+            if n_get:
+                # results as the peers would send them back: position p of slot s holds {s * cap_get + p, ~}
+                back = np.arange(g * cap_get, dtype=np.uint32)
+                back = np.stack([back, ~back], axis=1)
+                dback = dev(back)
+                for shift_words in (0, 2):                                               # (16-byte aligned results or not)
+                    outbuf = torch.full((2 * (n_get + 1) + 2,), -1, dtype=torch.int32, device="cuda")
+                    out = outbuf[shift_words:shift_words + 2 * (n_get + 1)].view(n_get + 1, 2)
+                    rc = L.mkv_unpack_results(_dev_ptr(dback), _dev_ptr(perm), n_get, _dev_ptr(out), _stream_ptr(None))
+                    assert rc == 0
+                    torch.cuda.synchronize()
+                    o = out.cpu().numpy().view(np.uint32)
+                    assert np.array_equal(o[:n_get], back[where]), "un-pack"
+                    assert (o[n_get] == 0xffffffff).all()                                # nothing written past the end
     finally:
         L.mkv_set_tuning(b"pack_three_pass", 0)
 
 
-@pytest.mark.parametrize("scheme,fused", [(0, 0), (1, 0), (0, 1)])
-def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
+@pytest.mark.parametrize("scheme,sched,selfd", [(0, "cs", 1), (1, "cs", 1), (0, "cs", 0), (0, "plain", 1), (1, "plain", 0), (0, "fused", 0)])
+def test_native_engine_one_rank_through_rccl(scheme, sched, selfd, monkeypatch):
     """The C engine (mkv_shard_*: pack, ncclAllToAll, local search+insert, result exchange,
     unpack; two batches in flight) with a one-rank communicator -- the only RCCL shape a
     one-GPU box can run -- against the oracle, results and final table."""
@@ -91,7 +107,9 @@ def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
     from bench import late_imports, sharded_engine as ShardedIndex
     from oracle import oracle as O
     late_imports()
-    monkeypatch.setenv("MKV_SHARD_FUSED", str(fused))      # the engine reads it when it is created
+    monkeypatch.setenv("MKV_SHARD_SCHED", sched)           # the engine reads it when it is created
+    monkeypatch.setenv("MKV_SHARD_SELF", str(selfd))       # 0: the own slot through ncclAllToAll like the peers'
+    monkeypatch.delenv("MKV_SHARD_FUSED", raising=False)
     mem_p = 16
     rng = np.random.default_rng(77 + scheme)
     n_get, n_set = 6000, 900
@@ -127,9 +145,16 @@ def test_native_engine_one_rank_through_rccl(scheme, fused, monkeypatch):
         sh.native.close()
 
 
-@pytest.mark.parametrize("world,fused,scheme,lanes,cstream", [(4, 1, 0, 2, 0), (4, 0, 0, 2, 0), (8, 1, 0, 2, 0), (2, 1, 1, 2, 0),
-                                                              (4, 1, 0, 3, 0), (4, 1, 0, 2, 1), (2, 1, 0, 4, 1), (4, 0, 0, 3, 0)])
-def test_native_engine_schedule_with_several_slots(world, fused, scheme, lanes, cstream, monkeypatch):
+@pytest.mark.parametrize("world,sched,scheme,lanes,cstream,selfd,svc", [
+    # the default schedule (run_cs: local phases on one stream, the rest of a batch on a service stream, three
+    # buffer sets, the own slot past the exchange, the peers' slots by grouped send / receive) and its variants
+    (4, "cs", 0, 3, 1, 1, 2), (8, "cs", 0, 3, 1, 1, 2), (2, "cs", 1, 3, 1, 1, 1), (8, "cs", 0, 2, 1, 1, 1), (4, "cs", 0, 4, 1, 1, 3),
+    (4, "cs", 0, 3, 1, 0, 2), (8, "cs", 0, 3, 1, 0, 1), (8, "cs", 0, 2, 1, 1, 2),
+    # the older ones
+    (4, "fused", 0, 2, 0, 1, 1), (4, "plain", 0, 2, 0, 1, 1), (8, "fused", 0, 2, 0, 1, 1), (2, "fused", 1, 2, 0, 1, 1),
+    (4, "fused", 0, 3, 0, 1, 1), (4, "fused", 0, 2, 1, 1, 1), (2, "fused", 0, 4, 1, 1, 1), (4, "plain", 0, 3, 0, 1, 1),
+    (4, "plain", 0, 3, 1, 1, 1), (8, "plain", 0, 2, 1, 0, 1), (8, "plain", 0, 2, 0, 0, 1)])
+def test_native_engine_schedule_with_several_slots(world, sched, scheme, lanes, cstream, selfd, svc, monkeypatch):
     """The C engine's W-rank schedules (run_fused: one grouped exchange per batch, packs on
     a stream of their own into alternating `where` arrays; and the plain two-lane one) with
     every peer looped back to this process (two to four batches in flight, local phases on the
@@ -142,12 +167,15 @@ def test_native_engine_schedule_with_several_slots(world, fused, scheme, lanes, 
     from bench import late_imports, sharded_engine as ShardedIndex
     from oracle import oracle as O
     late_imports()
-    monkeypatch.setenv("MKV_SHARD_FUSED", str(fused))
+    monkeypatch.setenv("MKV_SHARD_SCHED", sched)
+    monkeypatch.delenv("MKV_SHARD_FUSED", raising=False)
+    monkeypatch.setenv("MKV_SHARD_SVC", str(svc))              # service streams of the default schedule
     monkeypatch.setenv("MKV_SHARD_LANES", str(lanes))          # batches in flight
     monkeypatch.setenv("MKV_SHARD_CSTREAM", str(cstream))      # local phases on a stream of their own
+    monkeypatch.setenv("MKV_SHARD_SELF", str(selfd))           # the rank's own slot bypasses the exchange (plain schedule)
     mem_p = 18
     k = world.bit_length() - 1
-    rng = np.random.default_rng(500 + world + fused)
+    rng = np.random.default_rng(500 + world + len(sched))
     n_get, n_set = 60000, 6000
     sh = ShardedIndex(mem_p, world, 0, scheme, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6)
     sh.enable_native(None, loopback=True)

@@ -310,3 +310,22 @@ def test_oracle_reproduces_index_fixture():
             else:
                 out = O.search(g, t, np.array(op["requests"], dtype=np.uint32).reshape(-1, 2))
             check_step(sc["name"], k, exp, lambda i: t[i], lambda: t, out)
+
+
+def test_sender_key_match_restatement_uses_strncmp_semantics():
+    """orc_resolve_verify restates src/mega_send.c:408-414 (pick) and :543-553 (KEY_MATCH) and calls
+    libc's strncmp as the reference does: keys that agree up to and including their first NUL are
+    equal to it, whatever follows -- the reference's own 8-byte keys {k, (k&7)<<29|k}
+    (src/mega_recv.c:700-704) are full of NULs."""
+    arena = np.zeros((4, 40), np.uint8)
+    arena[:, 10] = 8                                              # nkey (items.h: uint16 at byte 10)
+    arena[1, 24:32] = [1, 0, 0, 0, 1, 0, 0, 0x20]                 # key id 1: {1, (1&7)<<29 | 1}
+    arena[2, 24:32] = [1, 0, 5, 0, 9, 0, 0, 0]                    # differs only BEHIND the first NUL
+    arena[3, 24:32] = [2, 0, 0, 0, 2, 0, 0, 0x40]
+    arena[3, 10] = 9                                              # wrong nkey
+    keys = np.array([[1, 0, 0, 0, 1, 0, 0, 0x20]] * 3 + [[2, 0, 0, 0, 2, 0, 0, 0x40]] * 2, np.uint8)
+    pairs = np.array([[1, 0], [2, 0], [0, 1], [3, 0], [0, 0]], np.uint32)
+    loc, hits, misses, fp = O.resolve_verify(pairs, keys, 8, arena, 40)
+    assert loc.tolist() == [1, 2, 1, 0, 0] and (hits, misses, fp) == (3, 2, 1)
+    loc, hits, misses, fp = O.resolve_verify(pairs, keys, 8, arena, 40, bytes_mode=True)
+    assert loc.tolist() == [1, 0, 1, 0, 0] and (hits, misses, fp) == (2, 3, 2)
