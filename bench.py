@@ -264,8 +264,12 @@ def main():
         native = engine.native is not None
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
+    # (on the stream the steps will run on: a host that updates its table from ONE stream never makes
+    # the library order updates across streams)
+    run_stream = torch.cuda.Stream(device=device)
     t0 = time.time()
-    engine.preload(stream_gen.P, stream_gen.keying)
+    with torch.cuda.stream(run_stream):
+        engine.preload(stream_gen.P, stream_gen.keying)
     torch.cuda.synchronize()
     t_preload = time.time() - t0
 
@@ -277,7 +281,6 @@ def main():
     torch.cuda.synchronize()
     t_gen += time.time() - t0
 
-    run_stream = torch.cuda.Stream(device=device)
     use_events = not args.no_events
     ev = []
 

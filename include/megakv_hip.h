@@ -107,12 +107,12 @@ long long mkv_workspace_bytes(void);
  * insert/delete call, and counted here.  Nothing aborts. */
 unsigned long long mkv_dropped_batches(void);
 
-/* Updates issued on different streams are put in issue order (from the second stream on, every
- * update call records an event of the library's own behind its last kernel and an update on
- * another stream waits for it; the first time a second stream turns up, the device is
- * synchronised once).  No stream handle is kept beyond the name of the last one used: a host
- * that destroys a stream may call this first (the stream is synchronised and forgotten); it is
- * not required. */
+/* Updates issued on different streams are put in issue order (while updates have been changing
+ * streams lately every update call records an event of the library's own behind its last kernel
+ * and an update on another stream waits for it; a change of stream after a long run on one
+ * stream synchronises the device instead).  No stream handle is kept beyond the name of the last
+ * one used: a host that destroys a stream may call this first (the stream is synchronised and
+ * forgotten); it is not required. */
 void mkv_forget_stream(void *stream);
 
 /* Diagnostics of the most recent insert/delete on `stream` (synchronises the

@@ -168,6 +168,7 @@ struct Ctl {
 	unsigned long long tstamp_next;  // next stamp of the touched record (persists across calls)
 	unsigned long long tstamp_cur;   // stamp a tail launch builds its touched record with (set by round 1)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
+	uint32_t hf_last[2];             // what the host-mapped flag words hold (they are written only when they change)
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
@@ -2856,8 +2857,18 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			ctl->late_score = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? kLateSticky :
 					(ctl->late_score ? ctl->late_score - 1u : 0u);
 		if (last_chunk && host_flag) {
-			host_flag[0] = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u;
-			host_flag[1] = ctl->stamp_base > kStampMax - kStampReserve ? 1u : 0u;
+			// (a store to host memory makes the end of this kernel wait for the PCIe write: 4 us between
+			// this launch and the next search, every step -- the words are written when they change)
+			const uint32_t f0 = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u;
+			const uint32_t f1 = ctl->stamp_base > kStampMax - kStampReserve ? 1u : 0u;
+			if (f0 != ctl->hf_last[0]) {
+				host_flag[0] = f0;
+				ctl->hf_last[0] = f0;
+			}
+			if (f1 != ctl->hf_last[1]) {
+				host_flag[1] = f1;
+				ctl->hf_last[1] = f1;
+			}
 			if (ctl->overflow)
 				host_flag[2] = host_flag[2] + 1u;
 		}
@@ -2877,10 +2888,12 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	}
 }
 
-__global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
+__global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *host_flag)
 {
 	const uint32_t t = threadIdx.x;
 	if (t == 0) {
+		if (host_flag)
+			host_flag[0] = host_flag[1] = 0;     // (in step with hf_last below)
 		ctl->stamp_base = first_stamp;
 		ctl->next_stamp = first_stamp + kStampsPerCall;
 		ctl->total = 0;
@@ -2899,6 +2912,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp)
 		ctl->hard_tail = 0;
 		ctl->late_score = 0;
 		ctl->tstamp_next = 1;
+		ctl->hf_last[0] = ctl->hf_last[1] = 0;
 		for (int k = 0; k < 8; k++)
 			ctl->dbg[k] = 0;
 		reset_tail_scratch(ctl);
@@ -3028,7 +3042,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 			ok = ok && hipMemsetAsync(w->touched, 0, w->nbuckets * 8, stream) == hipSuccess;
 			if (!ok)
 				return MKV_EHIP;
-			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull);
+			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull, w->host_flag_dev);
 			w->reset_cooldown = 64;
 			w->stamp_resets++;
 		}
@@ -3078,7 +3092,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = ok && hipMemsetAsync(w->touched, 0, nb * 8, stream) == hipSuccess;
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
-					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1));
+					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1), w->host_flag_dev);
 		// the buffers are shared by all streams: they are ready before any other stream uses them
 		ok = ok && hipStreamSynchronize(stream) == hipSuccess;
 	}
@@ -3100,16 +3114,23 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 // a stream per worker (src/mega_scheduler.c:393-500); its kernels then race benignly.  Here an
 // update keeps its reservation state in the device's workspace, and a roll-back restores words
 // -- two updates running side by side would not be anybody's serialisation.  So the updates of
-// a device are put in the order the host issued them.  A host that keeps to one stream never
-// pays for it.  The first time a second stream turns up the device is synchronised once (no
-// handle of the first stream is touched: it may have been destroyed since); from then on
-// every update call records an event behind its last kernel (updates_issued) and an update on
-// another stream waits for it.  Searches are not ordered against updates of other streams
-// (neither are the reference's).  Not called by mkv_slots_cycle: the sharded engines order
-// the local phases of their lanes' streams with events of their own.
+// a device are put in the order the host issued them: an update on another stream than the last
+// one waits for it.  No handle of the earlier stream is touched for that (it may have been
+// destroyed since): while updates have been changing streams lately, every update call records
+// an event of the library's own behind its last kernel (updates_issued) and the next stream
+// waits for that; a change of stream that finds no such event -- the first one, or one after a
+// long run on one stream -- synchronises the device instead.  A host that keeps to one stream
+// pays nothing: an event behind every call costs 5.7 us per call on this runtime (the marker
+// packet holds up the next launch; kernel timeline of bench.py, whose pre-load runs on another
+// stream than its steps), so recording stops kUpdateSwitchMemory calls after the last change.
+// Searches are not ordered against updates of other streams (neither are the reference's).
+// Not called by mkv_slots_cycle: the sharded engines order their local phases themselves.
+constexpr int kUpdateSwitchMemory = 4;
 struct UpdateOrder {
 	hipStream_t last = nullptr;
-	bool any = false, multi = false;
+	bool any = false;
+	bool ev_valid = false;          // `ev` was recorded behind the last update issued
+	int active = 0;                 // update calls for which an event is still recorded behind each
 	hipEvent_t ev = nullptr;
 };
 static std::unordered_map<int, UpdateOrder> g_order;   // key: device
@@ -3122,17 +3143,21 @@ static int order_updates(hipStream_t stream)
 	std::lock_guard<std::mutex> lock(g_ws_mutex);
 	UpdateOrder &o = g_order[dev];
 	if (o.any && o.last != stream) {
-		if (!o.multi) {
-			if (hipDeviceSynchronize() != hipSuccess ||
-					hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess)
+		if (!o.ev && hipEventCreateWithFlags(&o.ev, hipEventDisableTiming) != hipSuccess)
+			return MKV_EHIP;
+		if (o.ev_valid) {
+			if (hipStreamWaitEvent(stream, o.ev, 0) != hipSuccess)
 				return MKV_EHIP;
-			o.multi = true;
-		} else if (hipStreamWaitEvent(stream, o.ev, 0) != hipSuccess) {
+		} else if (hipDeviceSynchronize() != hipSuccess) {
 			return MKV_EHIP;
 		}
+		o.active = kUpdateSwitchMemory;
+	} else if (o.active > 0) {
+		o.active--;
 	}
 	o.last = stream;
 	o.any = true;
+	o.ev_valid = false;             // (what is enqueued from here on lies behind any event recorded so far)
 	return MKV_OK;
 }
 
@@ -3144,8 +3169,11 @@ static int updates_issued(hipStream_t stream)
 		return MKV_EHIP;
 	std::lock_guard<std::mutex> lock(g_ws_mutex);
 	UpdateOrder &o = g_order[dev];
-	if (o.multi && hipEventRecord(o.ev, stream) != hipSuccess)
-		return MKV_EHIP;
+	if (o.active > 0 && o.ev) {
+		if (hipEventRecord(o.ev, stream) != hipSuccess)
+			return MKV_EHIP;
+		o.ev_valid = true;
+	}
 	return MKV_OK;
 }
 

@@ -54,6 +54,17 @@ def test_gpus_2_starts_its_own_ranks():
     assert d["config"]["mem_p_aggregate"] == 23 and "2 shards" in d["config"]["sharding"]
 
 
+def test_gpus_8_starts_its_own_ranks():
+    """`python bench.py --gpus 8` (BASELINE configs[4]'s shape: 8 shards, aggregate MEM_P = local + 3):
+    eight ranks sharing cuda:0, the exchange staged through host memory; the N > 1 line carries the
+    roofline of the local slot search and the checks of what the timed region did."""
+    d = run_bench("--gpus", "8", "--comm", "staged", "--mem-p", "21", "--batch-log2", "15", "--steps", "4",
+                  "--warmup", "2", "--no-cpu", "--no-pcie", "--kernel-launches", "8", "--prewarm-ms", "10", timeout=1500)
+    check_common(d, 8, 4, 2)
+    assert d["config"]["mem_p_aggregate"] == 24 and "8 shards" in d["config"]["sharding"]
+    assert "k_search_slots_mark" in d["roofline"]["kernel"]
+
+
 def test_one_rank_through_the_rccl_engine():
     d = run_bench("--force-sharded", "--steps", "6", "--warmup", "2", *SMALL)
     check_common(d, 1, 6, 2)
