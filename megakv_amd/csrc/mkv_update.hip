@@ -29,9 +29,7 @@
 //               request runs its chain if every further bucket is its own or
 //               nobody's.  Losers re-register for round 2.  A hard request whose
 //               chain meets somebody else is left to the tail -- nobody waits for it.
-//   K3 round 2  the same over the losers.  Its idle lanes keep the "touched record"
-//               (per bucket: the commits of this pass that used it) when chains
-//               are running late.
+//   K3 round 2  the same over the losers, who registered in a second owner table.
 //   K4 tail     one launch of 32 work-groups of 1024 lanes (the helpers leave at
 //               once unless there is much to scan).  Reservation rounds over what
 //               is left (register / decide / commit with work-group barriers; the
@@ -87,7 +85,7 @@ constexpr int kViolCap = 128;       // order violations recorded per turn of the
 constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
 constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
                                     // launch stays free of scratch memory and calls)
-constexpr uint32_t kLateSticky = 16; // calls for which round 2 keeps the touched record after a call whose chains ran late
+constexpr uint32_t kLateSticky = 16; // calls for which a call whose chains ran late counts as "chains lately" (diagnostics)
 constexpr int kDeferCap = 768;           // k_round: requests a work-group may hold back for its second phase
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
@@ -157,16 +155,13 @@ struct Ctl {
 	uint32_t g_progress[2], g_left[2];
 	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
 	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
-	uint32_t record_by_r2;           // round 2 has kept the touched record of this pass (the tail need not build it)
 	uint32_t viol[kMaxRegions];      // tail: lowest index per region whose chain met a bucket a LATER request already used
 	uint32_t vlist_n;                // ... and the violations themselves: {index, bucket} (the first kViolCap of a turn)
 	uint2 vlist[kViolCap];
-	uint32_t tflags;                 // tail: bit 0 = a violation was recorded, bit 1 = the touched record is needed
+	uint32_t tflags;                 // tail: bit 0 = a violation was recorded
 	uint32_t violations;             // order violations handled this call (each rolls back a region's later commits)
 	uint32_t hard_tail;              // hard requests the grid-wide rounds left to the tail this call
 	uint32_t late_score;             // > 0: chains ran late in one of the last kLateSticky calls (persists across calls)
-	unsigned long long tstamp_next;  // next stamp of the touched record (persists across calls)
-	unsigned long long tstamp_cur;   // stamp a tail launch builds its touched record with (set by round 1)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t hf_last[2];             // what the host-mapped flag words hold (they are written only when they change)
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
@@ -921,8 +916,20 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 		// in ROUND 1, where everybody's right to a bucket is read from this table; in round 2 the
 		// losers' rights are in the other table -- one of them may own b there -- so only a bucket
 		// nobody of the pass has entered will do.
-		const unsigned long long old = atomicMin(&owner1[b], mykey);
-		if ((old >> kIdxBits) == stamp_field && (old != mykey || !own_ok)) {
+		// The round-1 table also names, per bucket, the one request that can have committed there in
+		// this round (its lowest registrant) -- the tail finds order violations by it (later_commit_on)
+		// -- so a foreign entry of this pass is left as it is: the claim is a compare-and-swap on what
+		// was read, and only over an entry of an earlier pass (or the request's own, from its pre-walk).
+		bool mine = false;
+		for (int attempt = 0; attempt < 4 && !mine; attempt++) {
+			const unsigned long long cur = ld_agent(&owner1[b]);
+			if ((cur >> kIdxBits) == stamp_field) {
+				mine = cur == mykey && own_ok;
+				break;
+			}
+			mine = atomicCAS(&owner1[b], cur, mykey) == cur;
+		}
+		if (!mine) {
 			ok = false;
 			break;
 		}
@@ -1009,46 +1016,6 @@ __device__ __forceinline__ bool tag_logged(uint32_t st)
 	return st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2;
 }
 
-// The touched record: per bucket, the list of the commits of this pass that used it.
-//   head  touched[b] = (stamp << kNodeBits) | (node + 1)     (another stamp: empty)
-//   node  tnodes[n]  = {index of the commit (kNone: taken back since), next node + 1 (0: end)}
-// Node numbers are static: 2 idx for a commit's primary bucket, 2 idx + 1 for its alternate
-// bucket, node_base + 8 slot + i for the i-th further bucket of the chain logged in `slot`.
-constexpr int kNodeBits = 26;
-
-__device__ __forceinline__ void touched_enter(unsigned long long *touched, uint2 *tnodes, unsigned long long tstamp,
-		uint32_t b, uint32_t node, uint32_t idx)
-{
-	const unsigned long long old = atomicExch(&touched[b], (tstamp << kNodeBits) | (unsigned long long)(node + 1u));
-	const uint32_t next = (old >> kNodeBits) == tstamp ? (uint32_t)(old & ((1ull << kNodeBits) - 1ull)) : 0u;
-	tnodes[node] = make_uint2(idx, next);
-}
-
-// enters the commit idx (tag st, undo record u) on the list of every bucket it used
-__device__ __forceinline__ void enter_commit(const DevGeom &g, const ChainLog *chain_logs, unsigned long long *touched,
-		uint2 *tnodes, uint32_t node_base, unsigned long long tstamp, uint32_t idx, uint32_t st, uint32_t sig,
-		uint32_t hash, const Undo &u)
-{
-	const uint32_t P = hash & g.hash_mask;
-	const uint32_t A = alt_bucket(hash, sig, g.hash_mask, g.blk_mask);
-	touched_enter(touched, tnodes, tstamp, P, 2u * idx, idx);
-	if (st == ST_CHAIN1 || st == ST_CHAIN2) {
-		if (A != P)
-			touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
-		const ChainLog *L = &chain_logs[u.word0];
-		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-		uint32_t last = A, k = 0;
-		for (uint32_t i = 0; i < n; i++) {
-			const uint32_t b = L->word[i] >> 4;       // kBucketWords = 16
-			if (b != last && b != P && b != A && k < 8u)
-				touched_enter(touched, tnodes, tstamp, b, node_base + 8u * u.word0 + k++, idx);
-			last = b;
-		}
-	} else if ((u.word0 >> 4) != P) {
-		touched_enter(touched, tnodes, tstamp, A, 2u * idx + 1u, idx);
-	}
-}
-
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
 // ROUND 1 iterates every request; ROUND 2 the round-1 losers.  A request that is the lowest
 // registrant of every bucket it needs executes with plain loads and stores and logs what it
@@ -1060,30 +1027,19 @@ __device__ __forceinline__ void enter_commit(const DevGeom &g, const ChainLog *c
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
-		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, unsigned long long *touched,
-		uint2 *tnodes, uint32_t node_base, int record_hint)
+		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint)
 {
-	// Round 2 also keeps the touched record when round 1 has left hard requests to the tail: its
-	// many idle lanes enter round 1's commits (final by now), its losers their own as they
-	// commit -- the tail, with far fewer lanes, then need not build it.
-	// (chains have been running late in recent calls -- one may only turn up in this round: the tail's
-	// note in the control block, or the host's hint, which lags behind by the calls in flight)
 	// The first turn's request and tag are fetched before anything is known from the control block
 	// (one round trip less on the critical path of a launch that is all latency); used if the
 	// work-group's first index turns out to be what was guessed (no carried requests).
 	const uint32_t pre_base = lo_idx + blockIdx.x * blockDim.x;
 	const uint32_t pre_idx = pre_base + threadIdx.x;
-	const bool pre_ok = pre_idx < (node_base >> 1) && pre_idx >= lo_idx;      // (node_base: twice the request capacity)
+	const bool pre_ok = pre_idx < req_cap && pre_idx >= lo_idx;
 	const uint8_t pre_st = pre_ok ? state[pre_idx] : (uint8_t)ST_DONE;
 	const uint4 pre_rc = pre_ok ? reqc[pre_idx] : make_uint4(0u, 0u, 0u, 0u);
-	const bool record = ROUND == 2 && OP == OP_CUCKOO &&
-			(ctl->any_hard != 0u || (record_hint & 1) != 0 || ctl->late_score != 0u);
 	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
-	if (ROUND == 2 && ctl->any_loser == 0u && !record)
+	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
-	const unsigned long long tstamp = record ? ctl->tstamp_cur : 0ull;
-	if (record && blockIdx.x == 0 && threadIdx.x == 0)
-		ctl->record_by_r2 = 1u;
 	if (ROUND == 1 && blockIdx.x == 0 && threadIdx.x == 0)
 		reset_tail_scratch(ctl);
 	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
@@ -1140,8 +1096,6 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 						state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
 						if (OP == OP_CUCKOO)
 							undo[idx] = u;
-						if (record)
-							enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx, ST_ROUND2, r.sig, r.hash, u);
 						ndone++;
 					} else {
 						s_q[atomicAdd(&s_qn, 1u)] = make_uint4(r.sig, r.hash, r.loc, idx);
@@ -1208,9 +1162,6 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					state[idx] = chained ? (ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2) : (ROUND == 1 ? ST_ROUND1 : ST_ROUND2);
 					if (OP == OP_CUCKOO)
 						undo[idx] = u;
-					if (record)
-						enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx,
-								chained ? ST_CHAIN2 : ST_ROUND2, r.sig, r.hash, u);
 					if (chained)
 						atomicAdd(&ctl->chain_ok, 1u);
 					ndone++;
@@ -1249,79 +1200,92 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 		__syncthreads();
 	}
 	count_add(ctl->committed[ROUND - 1], ndone);
-	if (record) {
-		const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-		for (uint32_t idx = start + blockIdx.x * blockDim.x + threadIdx.x; idx < count && idx >= start; idx += span) {
-			const uint32_t st = state[idx];
-			if (st != ST_ROUND1 && st != ST_CHAIN1)
-				continue;
-			const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);
-			enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx, st, sh.x, sh.y, undo[idx]);
-		}
-	}
 }
 
 // ---- order validation of eviction chains that run late ------------------------------
 // The grid-wide rounds commit a request as soon as it is the lowest registrant of the
 // buckets it needs -- without asking whether an EARLIER request that is still pending will
 // turn hard and walk its chain into one of those buckets.  That is found out when the chain
-// walks: the "touched record" holds, per bucket, the highest canonical index among the
-// requests of this pass that the grid-wide rounds have committed on it (built from the undo
-// and chain logs by the tail, only when a chain does run late); a chain of request j that
-// steps on a bucket touched by some k > j has met an order violation -- k should have run
-// after j.  Every logged commit >= j of that closed region is then rolled back and redone
-// behind j (roll_back_from).  Tail commits are never logged or undone: the tail only commits
-// a request when nothing pending below it in its region can still run a chain.
+// walks.  WHO can have been committed on a bucket by the grid-wide rounds is written in their
+// owner tables: round 1 commits a request only on buckets whose lowest registrant in the
+// round-1 table it is (or that its chain claimed there, for both rounds' chains), round 2 only
+// as the lowest registrant in the round-2 table -- at most two candidates per bucket, read with
+// two loads; whether a candidate did commit, and on that bucket, its tag, undo record and chain
+// log say (commit_used).  A chain of request j that steps on a bucket with such a commit k > j
+// has met an order violation -- k should have run after j.  (Round 2 of this build kept a list
+// per bucket, swapped in with one returning atomicExch per commit: 37 of round 2's 55 us at load
+// factor 0.5, and every pass of a 50/50 batch paid for it as soon as one chain ran late.)
+// Tail commits are never logged or undone: the tail only commits a request when nothing pending
+// below it in its region can still run a chain; its rounds keep their reservations in tables of
+// their own, so the grid-wide rounds' tables stay as those rounds left them.
 struct Tv {
-	const unsigned long long *touched;   // per bucket: head of the list of the commits that used it
-	const uint2 *tnodes;                 // the lists' nodes
-	unsigned long long tstamp;           // stamp of this pass's record; 0 = not built yet
+	const unsigned long long *owner1;    // round-1 reservations of this pass (and every chain's claims)
+	const unsigned long long *owner2;    // round-2 reservations
+	unsigned long long stamp1;           // round-1 stamp of this pass (round 2: + 1)
+	const uint8_t *state;
+	const uint4 *reqc;
+	const Undo *undo;
+	const ChainLog *chain_logs;
 	uint32_t *viol;                      // per region: lowest violating index
-	uint32_t *flags;                     // bit 0: violation recorded; bit 1: record needed
+	uint32_t *flags;                     // bit 0: violation recorded
 	uint32_t *vlist_n;                   // violations of this turn: {index of the chain's request, bucket}
 	uint2 *vlist;
 	ChainLog *lane_logs;                 // one log per lane of the tail launch (apply_serial_checked)
 	uint32_t *dbg;
 };
-constexpr uint32_t kTvViolation = 1u, kTvNeed = 2u;
+constexpr uint32_t kTvViolation = 1u;
 
-// lowest... any commit later than idx on bucket b (its index), or kNone
-__device__ __forceinline__ uint32_t touched_later_who(const Tv &tv, uint32_t b, uint32_t idx)
+// did the grid-wide rounds commit request c, and did that commit use bucket b?  (The primary
+// bucket counts as used even when full: it was examined.)
+__device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint32_t c, uint32_t b)
 {
-	const unsigned long long x = ld_agent(&tv.touched[b]);
-	if ((x >> kNodeBits) != tv.tstamp)
-		return kNone;
-	uint32_t n = (uint32_t)(x & ((1ull << kNodeBits) - 1ull));
-	for (int guard = 0; n != 0u && guard < 64; guard++) {
-		const uint32_t *nw = reinterpret_cast<const uint32_t *>(tv.tnodes + (n - 1u));
-		const uint32_t who = ld_agent32(nw);
-		if (who != kNone && who > idx)
-			return who;
-		n = ld_agent32(nw + 1);
-	}
+	const uint32_t st = tv.state[c];
+	if (!tag_logged(st))
+		return false;                       // pending, done by the tail, or taken back (or selected already)
+	const uint2 sh = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(tv.reqc) + (size_t)c * 4u);
+	const uint32_t P = sh.y & g.hash_mask;
+	if (b == P)
+		return true;
+	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
+	const uint32_t w0 = tv.undo[c].word0;
+	if (b == alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask))
+		return chain || (w0 != kNoWord && (w0 >> 4) != P);      // (kBucketWords = 16)
+	if (!chain)
+		return false;
+	const ChainLog *L = &tv.chain_logs[w0];
+	const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+	for (uint32_t i = 0; i < n; i++)
+		if ((L->word[i] >> 4) == b)
+			return true;
+	return false;
+}
+
+// the two candidates of bucket b from its reservation words (kNone: none of this pass)
+__device__ __forceinline__ void candidates_of(const Tv &tv, unsigned long long v1, unsigned long long v2, uint32_t &c1,
+		uint32_t &c2)
+{
+	const unsigned long long f1 = kStampMax - tv.stamp1, f2 = kStampMax - (tv.stamp1 + 1ull);
+	c1 = (v1 >> kIdxBits) == f1 ? (uint32_t)(v1 & ((1ull << kIdxBits) - 1ull)) : kNone;
+	c2 = (v2 >> kIdxBits) == f2 ? (uint32_t)(v2 & ((1ull << kIdxBits) - 1ull)) : kNone;
+}
+
+// a commit later than idx on bucket b (its index), or kNone -- from reservation words the caller
+// has loaded beside its other accesses to the bucket
+__device__ __forceinline__ uint32_t later_commit_from(const Tv &tv, const DevGeom &g, uint32_t b, unsigned long long v1,
+		unsigned long long v2, uint32_t idx)
+{
+	uint32_t c1, c2;
+	candidates_of(tv, v1, v2, c1, c2);
+	if (c1 != kNone && c1 > idx && commit_used(tv, g, c1, b))
+		return c1;
+	if (c2 != kNone && c2 > idx && c2 != c1 && commit_used(tv, g, c2, b))
+		return c2;
 	return kNone;
 }
 
-// true = a later request of this pass has already been committed on bucket b
-__device__ __forceinline__ bool touched_later(const Tv &tv, uint32_t b, uint32_t idx)
+__device__ __forceinline__ uint32_t later_commit_on(const Tv &tv, const DevGeom &g, uint32_t b, uint32_t idx)
 {
-	return touched_later_who(tv, b, idx) != kNone;
-}
-
-// the same, from the head of the bucket's list (loaded by the caller beside its other accesses to the bucket)
-__device__ __forceinline__ bool touched_later_from(const Tv &tv, unsigned long long head, uint32_t idx)
-{
-	if ((head >> kNodeBits) != tv.tstamp)
-		return false;
-	uint32_t n = (uint32_t)(head & ((1ull << kNodeBits) - 1ull));
-	for (int guard = 0; n != 0u && guard < 64; guard++) {
-		const uint32_t *nw = reinterpret_cast<const uint32_t *>(tv.tnodes + (n - 1u));
-		const uint32_t who = ld_agent32(nw);
-		if (who != kNone && who > idx)
-			return true;
-		n = ld_agent32(nw + 1);
-	}
-	return false;
+	return later_commit_from(tv, g, b, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), idx);
 }
 
 __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g, uint32_t P, uint32_t idx,
@@ -1336,9 +1300,9 @@ __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g,
 
 // One request run to completion, eviction chain included, at its place in the canonical
 // order (nothing else of its region runs meanwhile).  Every bucket the chain goes on to is
-// checked against the touched record first; the chain logs what it overwrites (it may come
+// checked for later commits of the grid-wide rounds first (later_commit_on); the chain logs what it overwrites (it may come
 // back to a bucket it has used, so a read-only walk would not do) and restores it when it
-// has to give up.  0 = done, 1 = order violation, 2 = touched record needed (1, 2: nothing written).
+// has to give up.  0 = done, 1 = order violation (nothing written).
 template <Op OP>
 __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGeom &g, const Req &r, uint32_t idx, const Tv &tv)
 {
@@ -1347,10 +1311,6 @@ __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGe
 	if (apply_static<OP, true, false>(table, r, P, A, nullptr))
 		return 0;
 	// cuckoo, P and A full without duplicate (ref :357-423)
-	if (tv.tstamp == 0ull) {
-		atomicOr(tv.flags, kTvNeed);
-		return 2;
-	}
 	// (the log lives in this lane's slot of global memory: local arrays would cost the launch its
 	// scratch-free dispatch)
 	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
@@ -1372,7 +1332,7 @@ __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGe
 		sig = vsig;
 		loc = vloc;
 		b = alt_bucket(r.hash, sig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (:334)
-		if (touched_later(tv, b, idx)) {
+		if (later_commit_on(tv, g, b, idx) != kNone) {
 			for (uint32_t i = n; i-- > 0;)
 				table[L->word[i]] = L->old[i];
 			report_violation(tv, g, P, idx, b);
@@ -1424,9 +1384,7 @@ __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 	ctl->g_dupw[0] = ctl->g_dupw[1] = 0;
 	ctl->tail_rounds_used = 0;
 	ctl->tflags = 0;
-	ctl->record_by_r2 = 0;
 	ctl->vlist_n = 0;
-	ctl->tstamp_cur = ctl->tstamp_next++;
 	for (int k = 0; k < kMaxRegions; k++) {
 		ctl->g_rbar[0][k] = ctl->g_rbar[1][k] = kNone;
 		ctl->g_rmin[0][k] = ctl->g_rmin[1][k] = kNone;
@@ -1474,8 +1432,8 @@ __device__ __forceinline__ void lds_sort(uint32_t *keys, uint32_t n2)
 // Replay of the sorted requests lkeys[0..n) one at a time per closed region, regions side
 // by side (one wave each): the region of every request is fetched by all threads at once,
 // then a region's wave walks the list with ballots and its first lane replays.  A region
-// stops at the first request whose chain meets an order violation (or needs the touched
-// record): everything from there on stays pending.  Returns the number replayed.
+// stops at the first request whose chain meets an order violation: everything from there on
+// stays pending.  Returns the number replayed.
 template <Op OP>
 __device__ __forceinline__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
 		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const Tv &tv, uint32_t *s_count)
@@ -1624,19 +1582,15 @@ __device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const D
 // that request nor anything behind it commits in the same round.  True = the walk got
 // through, the chain never returns to a bucket it already used (so the walk saw what the real
 // run will see), and no later request of this pass was COMMITTED on one of the buckets by the
-// grid-wide rounds (touched record; else: order violation, reported) -- the request may run
+// grid-wide rounds (later_commit_from; else: order violation, reported) -- the request may run
 // its chain in this round's commit phase if it still owns everything then (run_owned_chain:
 // an earlier chain may come by after it).
 __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
 		uint32_t idx, unsigned long long *owner, unsigned long long stamp, const Tv &tv, uint32_t *rbar, uint32_t vsig)
 {
 	// vsig: the signature in the victim slot of A (the caller holds A's signature row).  Every
-	// further bucket costs ONE round trip: its claim, the head of its touched list and its
-	// signature row -- which also holds the next victim -- go out together.
-	if (tv.tstamp == 0ull) {
-		atomicOr(tv.flags, kTvNeed);        // (the caller treats the request as this round's barrier)
-		return false;
-	}
+	// further bucket costs ONE round trip: its claim, its two reservation words of the grid-wide
+	// rounds and its signature row -- which also holds the next victim -- go out together.
 	const unsigned long long mykey = owner_key(stamp, idx);
 	const unsigned long long stamp_field = kStampMax - stamp;
 	const uint32_t v = r.sig & 7u;
@@ -1656,7 +1610,7 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 				return false;
 			}
 		const unsigned long long old = atomicMin(&owner[nb], mykey);
-		const unsigned long long head = ld_agent(&tv.touched[nb]);
+		const unsigned long long v1 = ld_agent(&tv.owner1[nb]), v2 = ld_agent(&tv.owner2[nb]);
 		uint4 lo, hi;
 		load_sig_row<true>(table, nb, lo, hi);
 		if ((old >> kIdxBits) == stamp_field && old != mykey) {
@@ -1672,7 +1626,7 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 			atomicMin(&rbar[P >> g.region_shift], (uint32_t)(old & ((1ull << kIdxBits) - 1ull)));
 		}
 		// a later request of this pass was committed on nb by the grid-wide rounds: order violation
-		if (touched_later_from(tv, head, idx)) {
+		if (later_commit_from(tv, g, nb, v1, v2, idx) != kNone) {
 			report_violation(tv, g, P, idx, nb);
 			return false;
 		}
@@ -1935,7 +1889,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
 					if (idx == s_rmin[region]) {
-						// first of its region: exact, alone (its chain checked against the touched record)
+						// first of its region: exact, alone (its chain checked for later commits on its way)
 						done = apply_serial_checked<OP>(table, g, r, idx, tv) == 0;
 					} else if (my_bar == kNone) {
 						my_bar = i;                         // its turn may come at the end of this round
@@ -2001,7 +1955,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 		// a round that resolves less than the one-at-a-time replay would in its time
 		// (duplicates of one key, chains in a row) is not worth another
 		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
-		// an order violation (or a chain waiting for the touched record) blocks its region until the
+		// an order violation blocks its region until the
 		// caller has dealt with it
 		if (progress == 0 || (round >= 3 && recent < kMinRoundProgress) || ld_agent32(tv.flags) != 0u)
 			break;
@@ -2214,7 +2168,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 					if (st >= ST_CHAIN_OK)
 						state[idx] = ST_TAIL;
 					if (idx == s_rmin[region]) {
-						// first of its region: exact, alone (its chain checked against the touched record)
+						// first of its region: exact, alone (its chain checked for later commits on its way)
 						done = apply_serial_checked<OP>(table, g, r, idx, tv) == 0;
 					} else if (my_bar == kNone) {
 						my_bar = i;                         // its turn may come at the end of this round
@@ -2315,38 +2269,15 @@ __device__ __forceinline__ bool tag_pending(uint32_t st)
 	return st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK;
 }
 
-// The touched record of this pass: every request the grid-wide rounds have committed (its
-// tag says so) enters its index, under the stamp `tstamp`, on each bucket it used -- the
-// primary bucket always (examined even when full), the alternate bucket when the commit went
-// there, and every bucket of an eviction chain.  atomicMax keeps the highest index; stamps
-// only grow, so entries of earlier passes lose.  Shared by `nwg` work-groups (neighbouring
-// 16-tag groups go to different ones).
-__device__ __forceinline__ void build_touched(const DevGeom &g, const uint8_t *state, const uint4 *reqc, const Undo *undo,
-		const ChainLog *chain_logs, unsigned long long *touched, uint2 *tnodes, uint32_t node_base,
-		unsigned long long tstamp, uint32_t lo_idx, uint32_t total, uint32_t wg, uint32_t nwg)
-{
-	// one request per lane and step (most of a pass is committed: every lane has work, and the
-	// exchanges -- whose old value is waited for -- of a wave go out together)
-	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
-	for (uint32_t idx = lo_idx + wg * blockDim.x + threadIdx.x; idx < total && idx >= lo_idx;
-			idx += nwg * blockDim.x) {
-		const uint32_t st = state[idx];
-		if (!tag_logged(st))
-			continue;
-		const uint2 sh = *reinterpret_cast<const uint2 *>(reqw + (size_t)idx * 4u);   // {sig, hash}
-		enter_commit(g, chain_logs, touched, tnodes, node_base, tstamp, idx, st, sh.x, sh.y, undo[idx]);
-	}
-}
-
 // An order violation {j, X}: the chain of the pending request j steps on bucket X, which
 // a LATER commit of the grid-wide rounds has used.  What has to go:
-//   (a) every logged commit k > j on the list of X;
-//   (b) for every commit u taken back, every logged commit k' > u on the list of one of the
-//       buckets of u's reach (primary, alternate -- used or not: u will run again and may need
-//       it --, chain buckets): it ran there after u.
+//   (a) every logged commit k > j on X (at most two: the candidates of its reservation words);
+//   (b) for every commit u taken back, every logged commit k' > u on one of the buckets of u's
+//       reach (primary, alternate -- used or not: u will run again and may need it --, chain
+//       buckets): it ran there after u.
 // Commits that keep their place ran on their buckets before everything taken back there -- or
-// on other buckets -- so they stand.  One lane per violation walks the lists (they are short),
-// with a stack of {bucket, index} in LDS; a commit is selected by flagging its tag ST_SELECT
+// on other buckets -- so they stand.  One lane per violation follows the buckets, with a stack
+// of {bucket, index} in LDS; a commit is selected by flagging its tag ST_SELECT
 // and noting it in the list `sel`.  Returns false if its stack or the list overflowed (the caller then takes back
 // the whole region suffix).  Nothing is written to the table here.
 constexpr uint32_t kSelCap = 2048, kLaneStack = 24;
@@ -2360,19 +2291,17 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 	bool ok = true;
 	while (sp != 0u) {
 		const uint2 e = stack[--sp];
-		const unsigned long long x = ld_agent(&tv.touched[e.x]);
-		if ((x >> kNodeBits) != tv.tstamp)
-			continue;
-		uint32_t n = (uint32_t)(x & ((1ull << kNodeBits) - 1ull));
-		for (int guard = 0; n != 0u && guard < 64; guard++) {
-			const uint32_t *nw = reinterpret_cast<const uint32_t *>(tv.tnodes + (n - 1u));
-			const uint32_t u = ld_agent32(nw);
-			n = ld_agent32(nw + 1);
-			if (u == kNone || u <= e.y)
+		uint32_t cand[2];
+		candidates_of(tv, ld_agent(&tv.owner1[e.x]), ld_agent(&tv.owner2[e.x]), cand[0], cand[1]);
+		for (int ci = 0; ci < 2; ci++) {
+			const uint32_t u = cand[ci];
+			if (u == kNone || u <= e.y || (ci == 1 && u == cand[0]))
 				continue;
+			if (!commit_used(tv, g, u, e.x))
+				continue;                           // no commit there, or selected already (by this lane or another)
 			const uint32_t st = state[u];
 			if (!tag_logged(st))
-				continue;                           // selected already (by this lane or another), or no commit
+				continue;
 			// (the flag is set with an atomic on the tags' word: exactly one lane selects a commit,
 			// the list holds it once)
 			const uint32_t sh = (u & 3u) * 8u;
@@ -2408,10 +2337,10 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 	return ok;
 }
 
-// takes the selected commit u (tag already checked) back: its words restored, its nodes of the
-// touched record marked dead, its tag ST_DEFER (pending, sitting out one round)
+// takes the selected commit u (tag already checked) back: its words restored, its tag ST_DEFER
+// (pending, sitting out one round -- and no longer a commit to anybody who asks commit_used)
 __device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
-		const Undo *undo, const ChainLog *chain_logs, uint2 *tnodes, uint32_t node_base, uint32_t u, bool chain)
+		const Undo *undo, const ChainLog *chain_logs, uint32_t u, bool chain)
 {
 	const Undo ur = undo[u];
 	if (chain) {
@@ -2419,16 +2348,12 @@ __device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uin
 		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
 		for (uint32_t k = n; k-- > 0;)
 			table[L->word[k]] = L->old[k];
-		for (uint32_t k = 0; k < 8u; k++)
-			tnodes[node_base + 8u * ur.word0 + k].x = kNone;   // (nodes it never entered are in no list)
 	} else {
 		if (ur.word1 != kNoWord)
 			table[ur.word1] = ur.old1;
 		if (ur.word0 != kNoWord)
 			table[ur.word0] = ur.old0;
 	}
-	tnodes[2u * u].x = kNone;
-	tnodes[2u * u + 1u].x = kNone;
 	state[u] = ST_DEFER;
 }
 
@@ -2511,14 +2436,14 @@ __device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *l
 // ---- the tail launch ----------------------------------------------------------------------
 // Finishes what rounds 1 and 2 left: losers of both rounds and hard requests whose chain
 // could not run beside the other requests.  All work-groups share the scans when there is
-// much to scan (touched record, gather) and the rounds when much is left (grid_rounds);
+// much to scan (gather) and the rounds when much is left (grid_rounds);
 // otherwise the helpers leave at once and work-group 0 does the rest: reservation rounds,
 // then the in-order replay per closed region.  A chain that meets an order violation makes
 // the launch roll back the later commits of that region and take them on as well.
 template <Op OP>
 __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
-		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, unsigned long long *touched,
-		uint2 *tnodes, uint32_t node_base, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
+		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, const unsigned long long *owner1,
+		const unsigned long long *owner2, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
 		uint32_t *glist, int max_rounds,
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
 		int dbg_path)
@@ -2531,7 +2456,6 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
-	__shared__ unsigned long long s_tstamp;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	unsigned long long tick = wall_clock64();
 	uint32_t phase_ticks[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
@@ -2542,7 +2466,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	if (carry_in < lo_idx)
 		lo_idx = carry_in;                        // this pass also covered the carried requests
 	const bool work_left = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
-	const bool any_hard = OP == OP_CUCKOO && ctl->any_hard != 0u;
+	const unsigned long long stamp1 = ctl->stamp_base;    // round-1 stamp of this pass
 	if (t == 0) {
 		s_n = 0;
 		s_undone = 0;
@@ -2564,23 +2488,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__syncthreads();
 	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
 	const uint32_t pending_est = span > s_done12 ? span - s_done12 : 0u;
-	const bool use_helpers = nwg > 1u && (pending_est > (uint32_t)kTailAloneMax || span > (uint32_t)kTailAloneSpan ||
-			(any_hard && ctl->record_by_r2 == 0u && span > 8192u));   // (a long tag range is worth sharing even
-			                                                              // if little is left in it; so is the record)
+	const bool use_helpers = nwg > 1u && (pending_est > (uint32_t)kTailAloneMax || span > (uint32_t)kTailAloneSpan);
+			// (a long tag range is worth sharing even if little is left in it)
 	if (wg != 0 && (!work_left || !use_helpers))
 		return;
 	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
-	unsigned long long tstamp = 0;
 	bool grid_mode = false;
 	if (work_left) {
-		// hard requests were left to the tail: their chains will be checked against the touched record
-		if (OP == OP_CUCKOO && ctl->record_by_r2 != 0u) {
-			tstamp = ctl->tstamp_cur;           // round 2 has kept it
-		} else if (any_hard) {
-			tstamp = ctl->tstamp_cur;
-			build_touched(g, state, reqc, undo, chain_logs, touched, tnodes, node_base, tstamp, lo_idx, total, wg,
-					nwg_eff);
-		}
 		MKV_PHASE(0);
 		gather_pending(state, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff);
 		MKV_PHASE(6);
@@ -2597,9 +2511,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	}
 	MKV_PHASE(1);
 	Tv tv;
-	tv.touched = touched;
-	tv.tnodes = tnodes;
-	tv.tstamp = tstamp;
+	tv.owner1 = owner1;
+	tv.owner2 = owner2;
+	tv.stamp1 = stamp1;
+	tv.state = state;
+	tv.reqc = reqc;
+	tv.undo = undo;
+	tv.chain_logs = chain_logs;
 	tv.viol = ctl->viol;
 	tv.flags = &ctl->tflags;
 	tv.vlist_n = &ctl->vlist_n;
@@ -2708,8 +2626,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		const uint32_t flags = ld_agent32(&ctl->tflags);
 		if (flags == 0u)
 			break;                                 // everything is done
-		// -- a chain met an order violation, or needs the touched record ------------------------
-		bool rebuild = (flags & kTvNeed) != 0u;
+		// -- a chain met an order violation -----------------------------------------------------------
 		uint32_t relisted = kNone;                 // entries of the next work list already in glist (kNone: gather anew)
 		if (OP == OP_CUCKOO && (flags & kTvViolation)) {
 			uint32_t nseeds = ld_agent32(&ctl->vlist_n);
@@ -2759,12 +2676,12 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 						const uint32_t st = state[k];
 						if (st != tag && st != ctag)
 							continue;
-						take_back(g, table, state, reqc, undo, chain_logs, tnodes, node_base, k, st == ctag);
+						take_back(g, table, state, reqc, undo, chain_logs, k, st == ctag);
 						u++;
 					}
 					wg_sync();
 				}
-				if (relisted != kNone && !rebuild) {
+				if (relisted != kNone) {
 					for (uint32_t i = t; i < nsel; i += blockDim.x)
 						glist[relisted + i] = sel[i];
 					relisted += nsel;
@@ -2773,29 +2690,20 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				}
 			} else {
 				relisted = kNone;
-				// a stack or the list overflowed: the whole suffix of the regions concerned, and the
-				// record anew (roll_back_from also takes back what is flagged already)
+				// a stack or the list overflowed: the whole suffix of the regions concerned
+				// (roll_back_from also takes back what is flagged already)
 				if (t < kMaxRegions)
 					s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[t]) : kNone;
 				__syncthreads();
 				u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr);
-				rebuild = true;
 			}
 			if (u)
 				atomicAdd(&s_undone, u);
 		}
 		wg_sync();
 		MKV_PHASE(2);
-		// the record is (re)built under a new stamp (the old one names requests that are pending again)
-		if (t == 0) {
-			if (rebuild) {
-				s_tstamp = ctl->tstamp_next;
-				ctl->tstamp_next = s_tstamp + 1ull;
-			} else {
-				s_tstamp = tstamp;
-			}
+		if (t == 0)
 			s_n = 0;
-		}
 		if (t < kMaxRegions)
 			atomicExch(&ctl->viol[t], kNone);
 		if (t == 0) {
@@ -2803,10 +2711,6 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			atomicExch(&ctl->vlist_n, 0u);
 		}
 		__syncthreads();
-		tstamp = s_tstamp;
-		tv.tstamp = tstamp;
-		if (rebuild)
-			build_touched(g, state, reqc, undo, chain_logs, touched, tnodes, node_base, tstamp, lo_idx, total, 0u, 1u);
 		if (relisted == kNone)
 			gather_pending(state, glist, &s_n, lo_idx, total, 0u, 1u);
 		else if (t == 0)
@@ -2911,7 +2815,6 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->violations = 0;
 		ctl->hard_tail = 0;
 		ctl->late_score = 0;
-		ctl->tstamp_next = 1;
 		ctl->hf_last[0] = ctl->hf_last[1] = 0;
 		for (int k = 0; k < 8; k++)
 			ctl->dbg[k] = 0;
@@ -2932,10 +2835,12 @@ struct Workspace {
 	int device = -1;
 	uint64_t nbuckets = 0;
 	int64_t req_cap = 0;
-	unsigned long long *owner[2] = {nullptr, nullptr};
+	// reservation tables, 8 bytes per bucket each: [0] round 1 (and every chain's claims), [1] round 2 --
+	// left as those rounds wrote them until the pass is over: the tail reads from them who can have
+	// been committed where (later_commit_on) --, [2] the tail's rounds, [3] the tail's "lowest
+	// registrant that has the bucket as its alternate"
+	unsigned long long *owner[4] = {nullptr, nullptr, nullptr, nullptr};
 	unsigned long long *cnt = nullptr;
-	unsigned long long *touched = nullptr;   // per bucket: head of the list of the commits of a pass that used it
-	uint2 *tnodes = nullptr;                 // ... and the lists' nodes (2 per request + 8 per chain log)
 	uint8_t *state = nullptr;
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
@@ -2959,7 +2864,6 @@ struct Workspace {
 	int reset_cooldown = 0;            // calls for which word [1] is ignored after a stamp reset was enqueued
 	Chunking cycle_ck = {1, 65536, 0};    // chunking chosen by the first half of an mkv_cycle insert
 	int barrier_score = 0;             // > 0: eviction chains ran late within the last few calls
-	int record_hint = 0;               // ... so round 2 keeps the touched record as a matter of course
 	int stamp_resets = 0;              // times the reservation tables were cleared because the stamps ran low
 };
 
@@ -2975,11 +2879,9 @@ static unsigned long long g_dropped_total = 0;   // batches dropped because they
 
 static void free_ws(Workspace *w)
 {
-	for (int i = 0; i < 2; i++)
+	for (int i = 0; i < 4; i++)
 		if (w->owner[i]) (void)hipFree(w->owner[i]);
 	if (w->cnt) (void)hipFree(w->cnt);
-	if (w->touched) (void)hipFree(w->touched);
-	if (w->tnodes) (void)hipFree(w->tnodes);
 	if (w->state) (void)hipFree(w->state);
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
@@ -3036,10 +2938,10 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 			// reserve covers that): start over with cleared reservation tables, in stream order.
 			// The flag is the kernel's to write; it reads 0 again once a call has run after the
 			// reset, until then it is not looked at.
-			bool ok = hipMemsetAsync(w->owner[0], 0xff, w->nbuckets * 8, stream) == hipSuccess;
-			ok = ok && hipMemsetAsync(w->owner[1], 0xff, w->nbuckets * 8, stream) == hipSuccess;
+			bool ok = true;
+			for (int i = 0; i < 4; i++)
+				ok = ok && hipMemsetAsync(w->owner[i], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 16, stream) == hipSuccess;
-			ok = ok && hipMemsetAsync(w->touched, 0, w->nbuckets * 8, stream) == hipSuccess;
 			if (!ok)
 				return MKV_EHIP;
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl, 1ull, w->host_flag_dev);
@@ -3060,11 +2962,9 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	w->nbuckets = nb;
 	w->req_cap = rc;
 	bool ok = true;
-	for (int i = 0; i < 2 && ok; i++)
+	for (int i = 0; i < 4 && ok; i++)
 		ok = ok && hipMalloc(&w->owner[i], nb * 8) == hipSuccess;
 	ok = ok && hipMalloc(&w->cnt, nb * 16) == hipSuccess;     // registrant counts, then the election words
-	ok = ok && hipMalloc(&w->touched, nb * 8) == hipSuccess;
-	ok = ok && hipMalloc(&w->tnodes, ((size_t)rc * 2 + (size_t)kChainLogCap * 8) * sizeof(uint2)) == hipSuccess;
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
@@ -3086,10 +2986,9 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	}
 	if (ok) {
 		// owner entries start at "no owner" (all ones); counters at zero
-		ok = ok && hipMemsetAsync(w->owner[0], 0xff, nb * 8, stream) == hipSuccess;
-		ok = ok && hipMemsetAsync(w->owner[1], 0xff, nb * 8, stream) == hipSuccess;
+		for (int i = 0; i < 4; i++)
+			ok = ok && hipMemsetAsync(w->owner[i], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 16, stream) == hipSuccess;
-		ok = ok && hipMemsetAsync(w->touched, 0, nb * 8, stream) == hipSuccess;
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
 					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1), w->host_flag_dev);
@@ -3209,10 +3108,8 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 //
 // The tail kernel leaves a word in pinned host memory (bit 0: eviction chains had to run
 // late in that call).  It is read here without synchronising -- possibly a call late, which
-// is fine: it only steers where the touched record is kept (round 2 keeps it as a matter of
-// course while chains have been running late within the last Tuning::barrier_sticky calls;
-// otherwise the tail builds it if it turns out to be needed) and, with calm_factor > 1, the
-// pass size -- never the result.
+// is fine: with calm_factor > 1 it steers the pass size (larger passes while no chain ran late
+// within the last Tuning::barrier_sticky calls) -- never the result.
 // work-groups of the mark pass inside a fused search launch: Tuning::mark_blocks for the usual
 // few per cent of SETs, more when the caller announces many (one per 512 requests, up to 1024)
 static uint32_t mark_blocks_for(long long hint)
@@ -3241,8 +3138,6 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	k.flush = 0;
 	k.step = (uint32_t)tuning().insert_chunk;
 	const bool lately = cuckoo && chains_lately(w);
-	if (w)
-		w->record_hint = lately ? 1 : 0;
 	if (!cuckoo || hint <= 0)
 		return k;
 	long long c = tuning().insert_chunk;
@@ -3341,13 +3236,13 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
-			(uint32_t)(2 * w->req_cap), tuning().debug_skip & 4);
+			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
+			tuning().debug_skip & 4);
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, w->touched, w->tnodes,
-			(uint32_t)(2 * w->req_cap), (w->record_hint ? 1 : 0) | (tuning().debug_skip & 4));
-	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[0],
-			w->owner[1], w->cnt, w->touched, w->tnodes, (uint32_t)(2 * w->req_cap), w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
+			tuning().debug_skip & 4);
+	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
+			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
@@ -3715,8 +3610,7 @@ extern "C" long long mkv_workspace_bytes(void)
 		const mkv::Workspace *w = kv.second;
 		if (!w || w->device != dev)
 			continue;
-		total += (long long)w->nbuckets * 40 +
-				(long long)(((size_t)w->req_cap * 2 + (size_t)mkv::kChainLogCap * 8) * sizeof(uint2)) +
+		total += (long long)w->nbuckets * 48 +
 				(long long)w->req_cap * (1 + 16 + 16 + 4) +
 				(long long)(((size_t)mkv::kChainLogCap + mkv::kTailLanes) * sizeof(mkv::ChainLog)) + (long long)sizeof(mkv::Ctl);
 	}
