@@ -148,6 +148,8 @@ Tuning &tuning()
 		v.tail_groups = s ? atoi(s) : 32;
 		if (v.tail_groups < 1) v.tail_groups = 1;
 		if (v.tail_groups > 64) v.tail_groups = 64;
+		s = getenv("MKV_LAZY_ALT");
+		v.lazy_alt = s ? atoi(s) != 0 : 1;
 		s = getenv("MKV_INSERT_CHUNK");
 		v.insert_chunk = s ? atoll(s) : 524288;
 		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
@@ -256,6 +258,8 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.mark_alone_blocks = (int)value;
 	} else if (!strcmp(name, "debug_first_stamp")) {
 		t.debug_first_stamp = value;
+	} else if (!strcmp(name, "lazy_alt")) {
+		t.lazy_alt = value != 0;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

@@ -104,6 +104,13 @@ constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_
 		                                // out one round unregistered (as that round's barrier), so that the chain
 		                                // finds the bucket free
 constexpr int kShards = 64;         // statistics counters are spread over this many words
+// A request whose primary bucket shows at least this many free slots at mark time does not register
+// on its alternate bucket (bit 0 of the request cache's fourth word says so): half the atomics of
+// the mark pass, which runs at the memory side's atomic rate.  Should the primary bucket fill up
+// before the request's turn after all, its late use of the alternate bucket is checked for later
+// commits there like a chain's step (round 2: inline; tail: later_commit_on).
+constexpr uint32_t kLazyFree = 3;
+constexpr uint32_t kLazyBit = 1u;
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
 // (request index in the owner tables, registrant count in the count table).
@@ -171,6 +178,7 @@ struct Ctl {
 
 struct Req {
 	uint32_t sig, hash, loc;
+	uint32_t aux;       // fourth word of the request cache (kLazyBit)
 };
 
 __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl);
@@ -396,7 +404,13 @@ __device__ __forceinline__ bool apply_alternate(uint32_t *table, const Req &r, u
 	if (try_place<false, LOG>(table, A, r.sig, r.loc, r.sig, u))
 		return true;
 	if (OP == OP_2CHOICE) {
-		table[sig_word(A, r.sig & 7u)] = r.sig;     // ref :197-209
+		const uint64_t w = sig_word(A, r.sig & 7u);
+		if (LOG) {
+			u->word0 = (uint32_t)w;
+			u->old0 = table[w];
+			u->word1 = kNoWord;
+		}
+		table[w] = r.sig;                           // ref :197-209
 		return true;
 	}
 	return false;
@@ -430,6 +444,7 @@ __device__ __forceinline__ Req req_of(const uint4 &rc)
 	r.sig = rc.x;
 	r.hash = rc.y;
 	r.loc = rc.z;
+	r.aux = rc.w;
 	return r;
 }
 
@@ -716,10 +731,9 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 // through the ordinary reservation instead of being committed under the chain's feet.  Only
 // a hint: nothing depends on the walk being right (the table may change before the turn).
 __device__ __forceinline__ void prewalk_register(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P,
-		uint32_t A, unsigned long long *owner, unsigned long long key)
+		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi)
 {
-	uint4 lo, hi;
-	load_sig_row<false>(table, P, lo, hi);
+	// (lo, hi: the signature row of P, loaded by the caller)
 	if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
 		return;
 	if (A != P) {
@@ -744,7 +758,7 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap,
-		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table)
+		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, bool lazy_on)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
@@ -812,9 +826,10 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	for (uint32_t base = first; base < end && base >= start; base += span) {
 		const uint32_t idx = base + t;
 		bool live = idx < end && idx >= start;
+		bool fresh = false;                         // a request of this pass's own range (not carried over)
 		uint32_t P = 0, A = 0;
 		Req rq;
-		rq.sig = rq.hash = rq.loc = 0u;
+		rq.sig = rq.hash = rq.loc = rq.aux = 0u;
 		if (live && idx < lo_idx) {
 			// carried range: unfinished tags ride along (reset to PENDING); commits of the
 			// earlier pass are closed here, so that a later roll-back never takes them for
@@ -848,27 +863,40 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			r.sig = p[0];
 			r.hash = p[1];
 			r.loc = p[2];
-			reqc[idx] = make_uint4(r.sig, r.hash, r.loc, 0u);
+			r.aux = 0u;
 			rq = r;
 			if (OP != OP_DELETE && r.sig == 0u && r.loc == 0u) {
+				reqc[idx] = make_uint4(r.sig, r.hash, r.loc, 0u);
 				state[idx] = ST_DONE;               // skipped by the reference too (:259-262)
 				live = false;
 			} else {
 				state[idx] = ST_PENDING;
 				P = r.hash & g.hash_mask;
 				A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
+				fresh = true;
 			}
 		}
+		// the primary bucket's signature row as the table stands (a hint: deletes of the same cycle
+		// may still be running): room enough there -> no registration on the alternate bucket
+		uint4 plo = make_uint4(1u, 1u, 1u, 1u), phi = plo;
+		bool lazy = false;
+		if (OP != OP_DELETE && live && table && (fresh || OP == OP_CUCKOO)) {
+			load_sig_row<false>(table, P, plo, phi);
+			lazy = fresh && lazy_on && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= kLazyFree;
+		}
+		if (fresh)
+			reqc[idx] = make_uint4(rq.sig, rq.hash, rq.loc, lazy ? kLazyBit : 0u);
 		const unsigned long long key = owner_key(stamp, idx);
 		if (use_fold) {
 			fold_min_dedup<kMarkFoldLog2>(fold, owner, P, key, live);
-			fold_min_dedup<kMarkFoldLog2>(fold, owner, A, key, live && A != P);
+			fold_min_dedup<kMarkFoldLog2>(fold, owner, A, key, live && A != P && !lazy);
 			fold_flush<false, false, kMarkFoldLog2>(fold, owner, nullptr, stamp);
 		} else {
-			reserve_wave(owner, P, A, key, live);
+			atomic_min_dedup(owner, P, key, live);
+			atomic_min_dedup(owner, A, key, live && A != P && !lazy);
 		}
-		if (OP == OP_CUCKOO && live && table)
-			prewalk_register(table, g, rq, P, A, owner, key);
+		if (OP == OP_CUCKOO && live && table && !lazy)
+			prewalk_register(table, g, rq, P, A, owner, key, plo, phi);
 	}
 }
 
@@ -883,8 +911,11 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 // roll-back behind a barrier.  Follows ref gpu_hash.cu:357-423.
 __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint32_t A, uint32_t idx,
 		unsigned long long *owner1, unsigned long long stamp1, Ctl *ctl, ChainLog *logs, uint32_t *log_slot,
-		bool own_ok)
+		bool own_ok, const unsigned long long *owner2)
 {
+	// (owner2: in round 2, that round's own table -- a bucket one of ITS requests is registered on is
+	// not free either: a request that did not register on its alternate bucket in the mark pass, kLazyFree,
+	// does so there)
 	if (g.max_cuckoo + 1u > (uint32_t)kChainLogWords / 2u)
 		return false;
 	const uint32_t slot = atomicAdd(&ctl->chain_n, 1u);
@@ -921,6 +952,10 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 		// -- so a foreign entry of this pass is left as it is: the claim is a compare-and-swap on what
 		// was read, and only over an entry of an earlier pass (or the request's own, from its pre-walk).
 		bool mine = false;
+		if (owner2 && (ld_agent(&owner2[b]) >> kIdxBits) == stamp_field - 1ull) {
+			ok = false;                             // (stamp of round 2 = round 1's + 1: its field is one lower)
+			break;
+		}
 		for (int attempt = 0; attempt < 4 && !mine; attempt++) {
 			const unsigned long long cur = ld_agent(&owner1[b]);
 			if ((cur >> kIdxBits) == stamp_field) {
@@ -970,9 +1005,9 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 template <Op OP>
 __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
-		uint32_t hi_idx, const uint32_t *table)
+		uint32_t hi_idx, const uint32_t *table, int lazy_on)
 {
-	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx, table);
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx, table, lazy_on != 0);
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -982,13 +1017,13 @@ template <Op OP>
 __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ in,
 		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n, uint32_t search_blocks,
 		Ctl *ctl, ReqSrc src, DevGeom g, unsigned long long *owner, uint4 *reqc, uint8_t *state,
-		uint32_t req_cap, uint32_t hi_idx)
+		uint32_t req_cap, uint32_t hi_idx, int lazy_on)
 {
 	// mark blocks first: they are few and latency-bound, let them start early
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table));
+				reinterpret_cast<const uint32_t *>(table), lazy_on != 0);
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
 }
@@ -1000,12 +1035,12 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
 		uint32_t chunks_per_slot, uint32_t search_blocks, Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx,
-		uint32_t self, uint32_t *__restrict__ self_out)
+		uint32_t self, uint32_t *__restrict__ self_out, int lazy_on)
 {
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table));
+				reinterpret_cast<const uint32_t *>(table), lazy_on != 0);
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
 				g.blk_mask, chunks_per_slot, self, self_out);
@@ -1014,6 +1049,32 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 __device__ __forceinline__ bool tag_logged(uint32_t st)
 {
 	return st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2;
+}
+
+// did the grid-wide rounds commit request c, and did that commit use bucket b?  (The primary
+// bucket counts as used even when full: it was examined.)
+__device__ __forceinline__ bool round_commit_used(const uint8_t *state, const uint4 *reqc, const Undo *undo,
+		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b)
+{
+	const uint32_t st = state[c];
+	if (!tag_logged(st))
+		return false;                       // pending, done by the tail, or taken back (or selected already)
+	const uint2 sh = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(reqc) + (size_t)c * 4u);
+	const uint32_t P = sh.y & g.hash_mask;
+	if (b == P)
+		return true;
+	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
+	const uint32_t w0 = undo[c].word0;
+	if (b == alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask))
+		return chain || (w0 != kNoWord && (w0 >> 4) != P);      // (kBucketWords = 16)
+	if (!chain)
+		return false;
+	const ChainLog *L = &chain_logs[w0];
+	const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
+	for (uint32_t i = 0; i < n; i++)
+		if ((L->word[i] >> 4) == b)
+			return true;
+	return false;
 }
 
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
@@ -1092,13 +1153,13 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					u.word1 = kNoWord;
 					u.old0 = 0u;
 					u.old1 = 0u;
-					if (apply_primary<OP, OP == OP_CUCKOO>(table, r, P, kP, &u)) {
+					if (apply_primary<OP, OP != OP_DELETE>(table, r, P, kP, &u)) {
 						state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
-						if (OP == OP_CUCKOO)
+						if (OP != OP_DELETE)
 							undo[idx] = u;
 						ndone++;
 					} else {
-						s_q[atomicAdd(&s_qn, 1u)] = make_uint4(r.sig, r.hash, r.loc, idx);
+						s_q[atomicAdd(&s_qn, 1u)] = make_uint4(r.sig, r.hash, r.loc, idx | ((rc.w & kLazyBit) << 31));
 					}
 				} else {
 					lose = true;
@@ -1136,31 +1197,45 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			r.sig = e.x;
 			r.hash = e.y;
 			r.loc = e.z;
-			const uint32_t idx = e.w;
+			r.aux = 0u;
+			const uint32_t idx = e.w & 0x7fffffffu;
+			const bool lazy = (e.w >> 31) != 0u;        // not registered on A in the mark pass (kLazyFree)
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
 			bool done = false, hard = false;
-			if (live && (A == P || owner[A] == key)) {
+			// Round 2, a request that comes to its alternate bucket unregistered in round 1: a LATER
+			// request may have been committed there by round 1 (the one the round-1 table names; or a
+			// chain that claimed the bucket there) -- then this one is for the tail, which takes that
+			// commit back.  Nobody else can be on A now: the request is its lowest registrant in this
+			// round's table, where every pending request of the pass stands with both its buckets.
+			bool late = false;
+			if (ROUND == 2 && OP != OP_DELETE && live && lazy && A != P) {
+				const unsigned long long v1 = owner_r1[A];
+				const uint32_t c1 = (v1 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v1 & ((1ull << kIdxBits) - 1ull)) : kNone;
+				late = c1 != kNone && c1 > idx && round_commit_used(state, reqc, undo, chain_logs, g, c1, A);
+			}
+			if (live && !late && (A == P || owner[A] == key)) {
 				Undo u;
 				u.word0 = kNoWord;
 				u.word1 = kNoWord;
 				u.old0 = 0u;
 				u.old1 = 0u;
 				bool chained = false;
-				done = apply_alternate<OP, OP == OP_CUCKOO>(table, r, A, &u);
+				done = apply_alternate<OP, OP != OP_DELETE>(table, r, A, &u);
 				if (OP == OP_CUCKOO && !done) {
 					// hard: P and A full without duplicate -> eviction chain
 					atomicMin(&ctl->first_hard, idx);
 					uint32_t log_slot = 0;
 					chained = chains_here &&
-						try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1);
+						try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1,
+								ROUND == 2 ? owner : nullptr);
 					hard = !chained;
 					u.word0 = log_slot;
 				}
 				if (done || chained) {
 					state[idx] = chained ? (ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2) : (ROUND == 1 ? ST_ROUND1 : ST_ROUND2);
-					if (OP == OP_CUCKOO)
+					if (OP != OP_DELETE)
 						undo[idx] = u;
 					if (chained)
 						atomicAdd(&ctl->chain_ok, 1u);
@@ -1235,29 +1310,9 @@ struct Tv {
 };
 constexpr uint32_t kTvViolation = 1u;
 
-// did the grid-wide rounds commit request c, and did that commit use bucket b?  (The primary
-// bucket counts as used even when full: it was examined.)
 __device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint32_t c, uint32_t b)
 {
-	const uint32_t st = tv.state[c];
-	if (!tag_logged(st))
-		return false;                       // pending, done by the tail, or taken back (or selected already)
-	const uint2 sh = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(tv.reqc) + (size_t)c * 4u);
-	const uint32_t P = sh.y & g.hash_mask;
-	if (b == P)
-		return true;
-	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
-	const uint32_t w0 = tv.undo[c].word0;
-	if (b == alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask))
-		return chain || (w0 != kNoWord && (w0 >> 4) != P);      // (kBucketWords = 16)
-	if (!chain)
-		return false;
-	const ChainLog *L = &tv.chain_logs[w0];
-	const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
-	for (uint32_t i = 0; i < n; i++)
-		if ((L->word[i] >> 4) == b)
-			return true;
-	return false;
+	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b);
 }
 
 // the two candidates of bucket b from its reservation words (kNone: none of this pass)
@@ -1298,6 +1353,34 @@ __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g,
 	atomicOr(tv.flags, kTvViolation);
 }
 
+// apply_static in the tail, for a request that may not have registered on its alternate bucket in
+// the mark pass (kLazyBit): before it touches that bucket, the grid-wide rounds' commits there are
+// looked at -- a later one is an order violation like a chain's (reported; the tail takes it back
+// and the request comes again).  0 = done, 1 = order violation reported (nothing written),
+// 3 = needs an eviction chain (cuckoo; nothing written).
+template <Op OP>
+__device__ __forceinline__ int apply_static_late(uint32_t *table, const DevGeom &g, const Req &r, uint32_t P, uint32_t A,
+		uint32_t idx, const Tv &tv)
+{
+	if (OP == OP_DELETE) {
+		apply_static<OP, true, false>(table, r, P, A, nullptr);
+		return 0;
+	}
+	if (try_place<true, false>(table, P, r.sig, r.loc, r.sig, nullptr))
+		return 0;
+	if ((r.aux & kLazyBit) && A != P && later_commit_on(tv, g, A, idx) != kNone) {
+		report_violation(tv, g, P, idx, A);
+		return 1;
+	}
+	if (try_place<true, false>(table, A, r.sig, r.loc, r.sig, nullptr))
+		return 0;
+	if (OP == OP_2CHOICE) {
+		table[sig_word(A, r.sig & 7u)] = r.sig;     // no room: the signature alone replaces slot sig&7 (ref :197-209)
+		return 0;
+	}
+	return 3;
+}
+
 // One request run to completion, eviction chain included, at its place in the canonical
 // order (nothing else of its region runs meanwhile).  Every bucket the chain goes on to is
 // checked for later commits of the grid-wide rounds first (later_commit_on); the chain logs what it overwrites (it may come
@@ -1308,9 +1391,10 @@ __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGe
 {
 	const uint32_t P = r.hash & g.hash_mask;
 	const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
-	if (apply_static<OP, true, false>(table, r, P, A, nullptr))
-		return 0;
-	// cuckoo, P and A full without duplicate (ref :357-423)
+	const int rs = apply_static_late<OP>(table, g, r, P, A, idx, tv);
+	if (rs != 3)
+		return rs;
+	// cuckoo, P and A full without duplicate (ref :357-423); A has been looked at for later commits
 	// (the log lives in this lane's slot of global memory: local arrays would cost the launch its
 	// scratch-free dispatch)
 	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
@@ -1594,6 +1678,12 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 	const unsigned long long mykey = owner_key(stamp, idx);
 	const unsigned long long stamp_field = kStampMax - stamp;
 	const uint32_t v = r.sig & 7u;
+	// (the chain begins with an eviction from A: a request that did not register there in the mark
+	// pass looks at the grid-wide rounds' commits on it first, like apply_static_late)
+	if ((r.aux & kLazyBit) && A != P && later_commit_on(tv, g, A, idx) != kNone) {
+		report_violation(tv, g, P, idx, A);
+		return false;
+	}
 	uint32_t seen[8];
 	uint32_t nseen = 0;
 	for (uint32_t k = 0;; k++) {
@@ -1811,6 +1901,21 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
 					continue;
+				// A request that did not register on its alternate bucket in the mark pass (kLazyBit): a
+				// LATER request may have been committed there by the grid-wide rounds.  Looked at now, in
+				// the first round in which the request is not behind a barrier -- before anything later
+				// than it in its region can commit in the tail, where commits are final: a later commit
+				// there is an order violation (the request is the round's barrier of its region, the
+				// commit is taken back, select_from); none, and the request is an ordinary one from here
+				// on -- it registers on both buckets in every round of the tail.
+				if (OP != OP_DELETE && (rc.w & kLazyBit) && A != P) {
+					if (later_commit_on(tv, g, A, idx) != kNone) {
+						report_violation(tv, g, P, idx, A);
+						atomicMin(&s_rbar[region], idx);
+						continue;
+					}
+					const_cast<uint4 *>(reqc)[idx].w = rc.w & ~kLazyBit;
+				}
 				uint4 lo, hi;
 				load_sig_row<true>(table, P, lo, hi);
 				const unsigned long long key = owner_key(stamp, idx);
@@ -1913,7 +2018,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				}
 			}
 			if (!settled && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
-				done = apply_static<OP, true, false>(table, r, P, A, nullptr);
+				done = apply_static_late<OP>(table, g, r, P, A, idx, tv) == 0;
 			if (done) {
 				state[idx] = ST_DONE;
 				keys[i] = kNone;
@@ -2059,6 +2164,21 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
 					continue;
+				// A request that did not register on its alternate bucket in the mark pass (kLazyBit): a
+				// LATER request may have been committed there by the grid-wide rounds.  Looked at now, in
+				// the first round in which the request is not behind a barrier -- before anything later
+				// than it in its region can commit in the tail, where commits are final: a later commit
+				// there is an order violation (the request is the round's barrier of its region, the
+				// commit is taken back, select_from); none, and the request is an ordinary one from here
+				// on -- it registers on both buckets in every round of the tail.
+				if (OP != OP_DELETE && (rc.w & kLazyBit) && A != P) {
+					if (later_commit_on(tv, g, A, idx) != kNone) {
+						report_violation(tv, g, P, idx, A);
+						atomicMin(&s_rbar[region], idx);
+						continue;
+					}
+					const_cast<uint4 *>(reqc)[idx].w = rc.w & ~kLazyBit;
+				}
 				uint4 lo, hi;
 				load_sig_row<true>(table, P, lo, hi);
 				const unsigned long long key = owner_key(stamp, idx);
@@ -2192,7 +2312,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 				}
 			}
 			if (!settled && ld_agent(&owner[P]) == key && (A == P || ld_agent(&owner[A]) == key))
-				done = apply_static<OP, true, false>(table, r, P, A, nullptr);
+				done = apply_static_late<OP>(table, g, r, P, A, idx, tv) == 0;
 			if (done) {
 				state[idx] = ST_DONE;
 				keys[i] = kNone;
@@ -2628,7 +2748,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			break;                                 // everything is done
 		// -- a chain met an order violation -----------------------------------------------------------
 		uint32_t relisted = kNone;                 // entries of the next work list already in glist (kNone: gather anew)
-		if (OP == OP_CUCKOO && (flags & kTvViolation)) {
+		if (OP != OP_DELETE && (flags & kTvViolation)) {
 			uint32_t nseeds = ld_agent32(&ctl->vlist_n);
 			nseeds = nseeds < (uint32_t)kViolCap ? nseeds : (uint32_t)kViolCap;
 			if (in_lds) {
@@ -3094,7 +3214,7 @@ static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipSt
 		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
 	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)tuning().mark_alone_blocks), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table);
+			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt);
 }
 
 template <Op OP>
@@ -3368,10 +3488,12 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
-				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi,
+				mkv::tuning().lazy_alt);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, in2, out, t4, num_search,
-				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi);
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi,
+				mkv::tuning().lazy_alt);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -3463,7 +3585,7 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), s, tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr,
 				recvbuf, slot_words, (uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks,
 				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (uint4 *)nullptr,
-				(uint8_t *)nullptr, 0u, 0u, self_u, self_out);
+				(uint8_t *)nullptr, 0u, 0u, self_u, self_out, 0);
 		if (done_event && hipEventRecord((hipEvent_t)done_event, s) != hipSuccess)
 			return MKV_EHIP;
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
@@ -3494,11 +3616,11 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 	if (cuckoo)
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out);
+				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out);
+				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
 		mkv::chunk_range(c, ck, &lo, &hi);
