@@ -99,7 +99,8 @@ struct Tuning {
 	int round_blocks;       // work-groups of the round-1 / round-2 launches of an insert or delete
 	int mark_alone_blocks;  // work-groups of the stand-alone mark launch
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)
-	int lazy_alt;           // a request whose primary bucket has room at mark time does not register on its alternate
+	int lazy_alt;           // a request whose primary bucket shows at least this many free slots at mark time does
+	                        // not register on its alternate bucket (0: every request registers on both)
 	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)
 	int debug_skip;      // tests only (results unchanged): how the tail deals with an order violation --
 	                     // 0 as designed, 1 always the general way (resolve_violations), 2 always the

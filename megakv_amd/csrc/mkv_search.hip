@@ -149,7 +149,8 @@ Tuning &tuning()
 		if (v.tail_groups < 1) v.tail_groups = 1;
 		if (v.tail_groups > 64) v.tail_groups = 64;
 		s = getenv("MKV_LAZY_ALT");
-		v.lazy_alt = s ? atoi(s) != 0 : 1;
+		v.lazy_alt = s ? atoi(s) : 2;
+		if (v.lazy_alt < 0 || v.lazy_alt > 8) v.lazy_alt = 2;
 		s = getenv("MKV_INSERT_CHUNK");
 		v.insert_chunk = s ? atoll(s) : 524288;
 		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
@@ -259,7 +260,9 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 	} else if (!strcmp(name, "debug_first_stamp")) {
 		t.debug_first_stamp = value;
 	} else if (!strcmp(name, "lazy_alt")) {
-		t.lazy_alt = value != 0;
+		if (value < 0 || value > 8)
+			return MKV_EINVAL;
+		t.lazy_alt = (int)value;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

@@ -109,8 +109,7 @@ constexpr int kShards = 64;         // statistics counters are spread over this 
 // the mark pass, which runs at the memory side's atomic rate.  Should the primary bucket fill up
 // before the request's turn after all, its late use of the alternate bucket is checked for later
 // commits there like a chain's step (round 2: inline; tail: later_commit_on).
-constexpr uint32_t kLazyFree = 3;
-constexpr uint32_t kLazyBit = 1u;
+constexpr uint32_t kLazyBit = 1u;      // (the number of free slots asked for: Tuning::lazy_alt, 2 by default: 1 / 2 / 3 measured alike)
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
 // (request index in the owner tables, registrant count in the count table).
@@ -758,7 +757,7 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap,
-		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, bool lazy_on)
+		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, uint32_t lazy_free)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
@@ -882,7 +881,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		bool lazy = false;
 		if (OP != OP_DELETE && live && table && (fresh || OP == OP_CUCKOO)) {
 			load_sig_row<false>(table, P, plo, phi);
-			lazy = fresh && lazy_on && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= kLazyFree;
+			lazy = fresh && lazy_free != 0u && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= lazy_free;
 		}
 		if (fresh)
 			reqc[idx] = make_uint4(rq.sig, rq.hash, rq.loc, lazy ? kLazyBit : 0u);
@@ -914,7 +913,7 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 		bool own_ok, const unsigned long long *owner2)
 {
 	// (owner2: in round 2, that round's own table -- a bucket one of ITS requests is registered on is
-	// not free either: a request that did not register on its alternate bucket in the mark pass, kLazyFree,
+	// not free either: a request that did not register on its alternate bucket in the mark pass, Tuning::lazy_alt,
 	// does so there)
 	if (g.max_cuckoo + 1u > (uint32_t)kChainLogWords / 2u)
 		return false;
@@ -1007,7 +1006,7 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
 		uint32_t hi_idx, const uint32_t *table, int lazy_on)
 {
-	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx, table, lazy_on != 0);
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx, table, (uint32_t)lazy_on);
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -1023,7 +1022,7 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table), lazy_on != 0);
+				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on);
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
 }
@@ -1040,7 +1039,7 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table), lazy_on != 0);
+				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on);
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
 				g.blk_mask, chunks_per_slot, self, self_out);
@@ -1199,7 +1198,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			r.loc = e.z;
 			r.aux = 0u;
 			const uint32_t idx = e.w & 0x7fffffffu;
-			const bool lazy = (e.w >> 31) != 0u;        // not registered on A in the mark pass (kLazyFree)
+			const bool lazy = (e.w >> 31) != 0u;        // not registered on A in the mark pass (Tuning::lazy_alt)
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
