@@ -99,6 +99,7 @@ struct Tuning {
 	int round_blocks;       // work-groups of the round-1 / round-2 launches of an insert or delete
 	int mark_alone_blocks;  // work-groups of the stand-alone mark launch
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)
+	int dup_groups;         // duplicates of a key inside one pass are settled as a group in round 2 (kFollowBit); 0: off
 	int lazy_alt;           // a request whose primary bucket shows at least this many free slots at mark time does
 	                        // not register on its alternate bucket (0: every request registers on both)
 	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)

@@ -148,6 +148,8 @@ Tuning &tuning()
 		v.tail_groups = s ? atoi(s) : 32;
 		if (v.tail_groups < 1) v.tail_groups = 1;
 		if (v.tail_groups > 64) v.tail_groups = 64;
+		s = getenv("MKV_DUP_GROUPS");
+		v.dup_groups = s ? atoi(s) != 0 : 1;
 		s = getenv("MKV_LAZY_ALT");
 		v.lazy_alt = s ? atoi(s) : 2;
 		if (v.lazy_alt < 0 || v.lazy_alt > 8) v.lazy_alt = 2;
@@ -259,6 +261,8 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.mark_alone_blocks = (int)value;
 	} else if (!strcmp(name, "debug_first_stamp")) {
 		t.debug_first_stamp = value;
+	} else if (!strcmp(name, "dup_groups")) {
+		t.dup_groups = value != 0;
 	} else if (!strcmp(name, "lazy_alt")) {
 		if (value < 0 || value > 8)
 			return MKV_EINVAL;

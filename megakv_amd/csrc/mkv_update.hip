@@ -100,15 +100,33 @@ constexpr uint8_t ST_PENDING = 0, ST_DONE = 1, ST_ROUND1 = 2, ST_ROUND2 = 3, ST_
 		ST_CHAIN_OK = 8,                // tail rounds: chain walked and all its buckets claimed
 		ST_DUPW = 9,                    // tail rounds: holds a duplicate nothing can evict -- a pure loc write
 		ST_DUPW_OK = 10,                // ... and takes part in this round's last-writer election of its bucket
-		ST_DEFER = 11;                  // tail: a commit taken back because an earlier chain needs its bucket sits
+		ST_DEFER = 11,                  // tail: a commit taken back because an earlier chain needs its bucket sits
 		                                // out one round unregistered (as that round's barrier), so that the chain
 		                                // finds the bucket free
+		ST_SHADOW = 12;                 // round 2: a duplicate of a key whose group's writes one earlier duplicate has
+		                                // made for all of them (undo[idx].word0 = that request; see kFollowBit) --
+		                                // finished as long as that commit stands (shadow_live)
 constexpr int kShards = 64;         // statistics counters are spread over this many words
 // A request whose primary bucket shows at least this many free slots at mark time does not register
 // on its alternate bucket (bit 0 of the request cache's fourth word says so): half the atomics of
 // the mark pass, which runs at the memory side's atomic rate.  Should the primary bucket fill up
 // before the request's turn after all, its late use of the alternate bucket is checked for later
 // commits there like a chain's step (round 2: inline; tail: later_commit_on).
+// Duplicate keys inside one pass (Zipf SET keys: a hot key comes hundreds of times).  Same key -- to
+// the table: same signature and same primary bucket, whatever the hash bits above the bucket index --,
+// same buckets: the first of them -- if it is the lowest registrant of their primary bucket -- runs in
+// round 1, and every later one that finds its own key under the bucket's reservation there is a
+// FOLLOWER (kFollowBit): all it will ever do is overwrite that entry's location, so only the last
+// follower's location matters.  Round 1: the followers elect the last one (atomicMax per bucket).
+// Round 2: the lowest follower -- the bucket's lowest registrant of that round, if no other key's
+// request comes before it -- runs with the LAST follower's location and is the group's one logged
+// commit (kLeadBit, the last follower's index in the upper 24 bits: to whoever asks for later
+// commits on the bucket it counts as that index); the other followers are its shadows, done as
+// long as that commit stands, pending requests like any other the moment it is taken back.
+// (Before: one duplicate per round, the rest -- 37 % of the SETs of a 95/5 Zipf batch -- through the
+// tail's grid-wide rounds with a last-writer election there: 72 - 92 us of a 120 us step.)
+constexpr uint32_t kFollowBit = 2u, kLeadBit = 4u;
+constexpr uint32_t kCheckedBit = 8u;   // tail: the request has looked at the grid-wide rounds' commits on its alternate bucket
 constexpr uint32_t kLazyBit = 1u;      // (the number of free slots asked for: Tuning::lazy_alt, 2 by default: 1 / 2 / 3 measured alike)
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
@@ -834,7 +852,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			// earlier pass are closed here, so that a later roll-back never takes them for
 			// commits of its own pass (it starts at the carry index, like this loop)
 			const uint8_t st = state[idx];
-			live = st == ST_PENDING || st == ST_LOSER || st == ST_TAIL || st >= ST_CHAIN_OK;
+			live = st == ST_PENDING || st == ST_LOSER || st == ST_TAIL || (st >= ST_CHAIN_OK && st != ST_SHADOW);
 			if (live ? st != ST_PENDING : st != ST_DONE)
 				state[idx] = live ? ST_PENDING : ST_DONE;
 			if (live) {
@@ -1050,15 +1068,31 @@ __device__ __forceinline__ bool tag_logged(uint32_t st)
 	return st == ST_ROUND1 || st == ST_ROUND2 || st == ST_CHAIN1 || st == ST_CHAIN2;
 }
 
+__device__ __forceinline__ bool tag_pending(uint32_t st)
+{
+	return st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || (st >= ST_CHAIN_OK && st != ST_SHADOW);
+}
+
+// a shadow whose group commit no longer stands (taken back, or never made): pending again
+__device__ __forceinline__ bool shadow_live(const uint8_t *state, const Undo *undo, const uint4 *reqc, uint32_t idx)
+{
+	const uint32_t c = undo[idx].word0;
+	return !(tag_logged(state[c]) && (reqc[c].w & kLeadBit));
+}
+
+
 // did the grid-wide rounds commit request c, and did that commit use bucket b?  (The primary
 // bucket counts as used even when full: it was examined.)
+// *eff: the index the commit counts as -- its own, or for the one commit of a group of duplicates
+// (kLeadBit) the index of the group's last member, whose write it stands for.
 __device__ __forceinline__ bool round_commit_used(const uint8_t *state, const uint4 *reqc, const Undo *undo,
-		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b)
+		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
 {
 	const uint32_t st = state[c];
 	if (!tag_logged(st))
 		return false;                       // pending, done by the tail, or taken back (or selected already)
-	const uint2 sh = *reinterpret_cast<const uint2 *>(reinterpret_cast<const uint32_t *>(reqc) + (size_t)c * 4u);
+	const uint4 sh = reqc[c];
+	*eff = (sh.w & kLeadBit) ? (sh.w >> 8) : c;
 	const uint32_t P = sh.y & g.hash_mask;
 	if (b == P)
 		return true;
@@ -1087,8 +1121,11 @@ __device__ __forceinline__ bool round_commit_used(const uint8_t *state, const ui
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
-		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint)
+		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
+		unsigned long long *emax)
 {
+	// (emax: a word per bucket -- the followers of a bucket's round-1 owner elect the last of them there,
+	// kFollowBit; the tail's elections use the same words under its own, later stamps)
 	// The first turn's request and tag are fetched before anything is known from the control block
 	// (one round trip less on the critical path of a launch that is all latency); used if the
 	// work-group's first index turns out to be what was guessed (no carried requests).
@@ -1098,6 +1135,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	const uint8_t pre_st = pre_ok ? state[pre_idx] : (uint8_t)ST_DONE;
 	const uint4 pre_rc = pre_ok ? reqc[pre_idx] : make_uint4(0u, 0u, 0u, 0u);
 	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
+	const bool groups_on = (record_hint & 8) == 0;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
 	if (ROUND == 1 && blockIdx.x == 0 && threadIdx.x == 0)
@@ -1119,10 +1157,12 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	// per work-group (or whenever the queue could overflow).  Nothing else changes: a queued
 	// request owns P all along, and nobody may touch A unless he owns it.
 	__shared__ uint4 s_q[kDeferCap];
+	__shared__ uint32_t s_qg[kDeferCap];        // round 2: the last member of the group a queued request leads (kNone: none)
 	__shared__ uint32_t s_qn;
 	if (threadIdx.x == 0)
 		s_qn = 0u;
 	__syncthreads();
+	uint4 *reqw = const_cast<uint4 *>(reqc);    // (the flag word of a request's cache entry is written here)
 	// whole waves go round together (the re-registration folds the atomics of lanes on one
 	// bucket): the loop variable is the work-group's first index
 	uint32_t base = start + blockIdx.x * blockDim.x;
@@ -1142,26 +1182,59 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			// second round trip: reservation of P and the primary bucket -- independent.  The
 			// reservation of A is only read if P cannot take the request: a request needs
 			// exclusive use of exactly the buckets it touches.
-			bool lose = false;
+			bool lose = false, follower = false, shadow = false;
+			uint32_t lead_of = kNone;                   // round 2: the request this one is a shadow of
 			if (pending) {
 				const unsigned long long oP = owner[P];
 				const Bkt kP = load_bucket(table, P);
 				if (oP == key) {
+					// Round 2, a follower at the head of its bucket: it runs with the location of the LAST
+					// follower -- the one write that remains of all of theirs -- and is the group's commit.
+					Req ra = r;
+					uint32_t grp = kNone;
+					if (ROUND == 2 && OP != OP_DELETE && (rc.w & kFollowBit)) {
+						const unsigned long long ev = emax[P];
+						const uint32_t kn = (uint32_t)(ev & ((1ull << kIdxBits) - 1ull));
+						if ((ev >> kIdxBits) == stamp1 && kn >= idx) {
+							const uint4 rk = kn > idx ? reqc[kn] : rc;
+							if (rk.x == r.sig && ((rk.y ^ r.hash) & g.hash_mask) == 0u) {
+								ra.loc = rk.z;
+								grp = kn;
+							}
+						}
+						if (grp == kNone)
+							ctl->any_tail = 1u;     // (cannot happen: it entered the election itself; its
+							                        // shadows would be picked up again by the tail's gather)
+					}
 					Undo u;
 					u.word0 = kNoWord;
 					u.word1 = kNoWord;
 					u.old0 = 0u;
 					u.old1 = 0u;
-					if (apply_primary<OP, OP != OP_DELETE>(table, r, P, kP, &u)) {
+					if (apply_primary<OP, OP != OP_DELETE>(table, ra, P, kP, &u)) {
 						state[idx] = ROUND == 1 ? ST_ROUND1 : ST_ROUND2;
 						if (OP != OP_DELETE)
 							undo[idx] = u;
+						if (grp != kNone)
+							reqw[idx].w = (rc.w & 0xffu) | kLeadBit | (grp << 8);     // (in P: a duplicate's or a new entry's location)
 						ndone++;
 					} else {
-						s_q[atomicAdd(&s_qn, 1u)] = make_uint4(r.sig, r.hash, r.loc, idx | ((rc.w & kLazyBit) << 31));
+						const uint32_t at = atomicAdd(&s_qn, 1u);
+						s_q[at] = make_uint4(r.sig, r.hash, ra.loc, idx | ((rc.w & kLazyBit) << 31));
+						s_qg[at] = grp;
 					}
 				} else {
 					lose = true;
+					// the bucket's lowest registrant holds the same key: round 1, this request is a follower
+					// of it; round 2, a shadow of it if that one is a follower too (it will write for both)
+					const uint32_t c = (uint32_t)(oP & ((1ull << kIdxBits) - 1ull));
+					if (OP != OP_DELETE && groups_on && r.sig != 0u && c < idx && (ROUND == 1 || (rc.w & kFollowBit))) {
+						const uint4 rj = reqc[c];
+						const bool same = rj.x == r.sig && ((rj.y ^ r.hash) & g.hash_mask) == 0u;   // (the table's notion of a key: signature and bucket)
+						follower = ROUND == 1 && same;
+						shadow = ROUND == 2 && same && (rj.w & kFollowBit);
+						lead_of = c;
+					}
 				}
 			}
 			if (ROUND == 1) {
@@ -1172,13 +1245,24 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
 				else if (lose)
 					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+				// ... and the followers elect the last of them
+				if (OP != OP_DELETE && __ballot(follower)) {
+					atomic_max_dedup(emax, P, (stamp1 << kIdxBits) | idx, follower);
+					if (follower)
+						reqw[idx].w = rc.w | kFollowBit;
+				}
 			}
 			if (lose) {
-				state[idx] = ROUND == 1 ? ST_LOSER : ST_TAIL;
-				if (ROUND == 1)
-					ctl->any_loser = 1u;
-				else
-					ctl->any_tail = 1u;
+				if (shadow) {
+					state[idx] = ST_SHADOW;
+					undo[idx].word0 = lead_of;      // (not counted as finished by this round: it may come back)
+				} else {
+					state[idx] = ROUND == 1 ? ST_LOSER : ST_TAIL;
+					if (ROUND == 1)
+						ctl->any_loser = 1u;
+					else
+						ctl->any_tail = 1u;
+				}
 			}
 			base += span;
 			more = base < count && base >= start;
@@ -1199,6 +1283,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			r.aux = 0u;
 			const uint32_t idx = e.w & 0x7fffffffu;
 			const bool lazy = (e.w >> 31) != 0u;        // not registered on A in the mark pass (Tuning::lazy_alt)
+			const uint32_t grp = live ? s_qg[q] : kNone;    // (round 2: r.loc is then the group's last location)
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
@@ -1212,7 +1297,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			if (ROUND == 2 && OP != OP_DELETE && live && lazy && A != P) {
 				const unsigned long long v1 = owner_r1[A];
 				const uint32_t c1 = (v1 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v1 & ((1ull << kIdxBits) - 1ull)) : kNone;
-				late = c1 != kNone && c1 > idx && round_commit_used(state, reqc, undo, chain_logs, g, c1, A);
+				uint32_t e1 = 0;
+				late = c1 != kNone && round_commit_used(state, reqc, undo, chain_logs, g, c1, A, &e1) && e1 > idx;
 			}
 			if (live && !late && (A == P || owner[A] == key)) {
 				Undo u;
@@ -1236,6 +1322,14 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					state[idx] = chained ? (ROUND == 1 ? ST_CHAIN1 : ST_CHAIN2) : (ROUND == 1 ? ST_ROUND1 : ST_ROUND2);
 					if (OP != OP_DELETE)
 						undo[idx] = u;
+					// (not when all that was written is a signature -- the two-choice overflow, ref :197-209:
+					// the group's location has not been stored, its shadows come back as pending requests)
+					if (ROUND == 2 && grp != kNone) {
+						if (chained || u.word1 != kNoWord || (u.word0 & 15u) >= kSlots)
+							reqw[idx].w = (reqc[idx].w & 0xffu) | kLeadBit | (grp << 8);
+						else
+							ctl->any_tail = 1u;         // (work for the tail even if nothing else is)
+					}
 					if (chained)
 						atomicAdd(&ctl->chain_ok, 1u);
 					ndone++;
@@ -1309,9 +1403,29 @@ struct Tv {
 };
 constexpr uint32_t kTvViolation = 1u;
 
-__device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint32_t c, uint32_t b)
+// (debug builds, make EXTRA=-DMKV_TRACE: what the tail did, in the order it did it -- tools/fuzz_debug.py prints it)
+#ifdef MKV_TRACE
+constexpr uint32_t kTraceCap = 1u << 17;
+__device__ uint32_t g_trace[4u * kTraceCap + 4u];
+__device__ __forceinline__ void trace_ev(uint32_t code, uint32_t a, uint32_t b, uint32_t c)
 {
-	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b);
+	const uint32_t at = atomicAdd(&g_trace[0], 1u);
+	if (at < kTraceCap) {
+		uint32_t *e = g_trace + 4u + 4u * at;
+		e[0] = code;
+		e[1] = a;
+		e[2] = b;
+		e[3] = c;
+	}
+}
+#define MKV_TR(code, a, b, c) trace_ev(code, a, b, c)
+#else
+#define MKV_TR(code, a, b, c) ((void)0)
+#endif
+
+__device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
+{
+	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b, eff);
 }
 
 // the two candidates of bucket b from its reservation words (kNone: none of this pass)
@@ -1328,11 +1442,11 @@ __device__ __forceinline__ void candidates_of(const Tv &tv, unsigned long long v
 __device__ __forceinline__ uint32_t later_commit_from(const Tv &tv, const DevGeom &g, uint32_t b, unsigned long long v1,
 		unsigned long long v2, uint32_t idx)
 {
-	uint32_t c1, c2;
+	uint32_t c1, c2, e = 0;
 	candidates_of(tv, v1, v2, c1, c2);
-	if (c1 != kNone && c1 > idx && commit_used(tv, g, c1, b))
+	if (c1 != kNone && commit_used(tv, g, c1, b, &e) && e > idx)
 		return c1;
-	if (c2 != kNone && c2 > idx && c2 != c1 && commit_used(tv, g, c2, b))
+	if (c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx)
 		return c2;
 	return kNone;
 }
@@ -1342,9 +1456,47 @@ __device__ __forceinline__ uint32_t later_commit_on(const Tv &tv, const DevGeom 
 	return later_commit_from(tv, g, b, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), idx);
 }
 
+// A commit on bucket b that has to come after request idx AND does not commute with it: any later
+// commit (`any`: the request did not register on the bucket, or may go on to replace an entry there),
+// or one that carries the request's own signature.  The latter is what a request that stood
+// registered on the bucket all along can meet: the commit of a group of duplicates (kLeadBit) led by
+// an earlier request, which stands for writes up to the group's last member.  Such a commit only
+// ever rewrote the location of ONE entry after its leader's turn; a request that finds its own
+// duplicate, or an empty slot, elsewhere in the bucket writes other words -- unless it takes the
+// group's entry for its duplicate (same signature from another bucket pair).
+__device__ __forceinline__ bool conflict_on(const Tv &tv, const DevGeom &g, uint32_t b, uint32_t idx, uint32_t sig, bool any)
+{
+	uint32_t c1, c2, e = 0;
+	candidates_of(tv, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), c1, c2);
+	if (c1 != kNone && commit_used(tv, g, c1, b, &e) && e > idx && (any || tv.reqc[c1].x == sig))
+		return true;
+	return c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx && (any || tv.reqc[c2].x == sig);
+}
+
+// The check a pending request makes ONCE (kCheckedBit), before anything later than it in its region
+// can commit in the tail: the bucket with a conflicting commit of the grid-wide rounds (the request
+// is then an order violation's seed and the barrier of its region), or kNone.  On P, where every
+// request registers in the mark pass, only a group's commit can be later.  On A any later commit
+// counts for a request that did not register there (kLazyBit) and, two-choice, for every request:
+// it may end up replacing slot sig&7 there (of P, if the two are one bucket), which nobody foresees
+// -- found out at commit time, beside the commits of later requests of the same round, it would be
+// found out too late (cuckoo: a request that may turn hard is a barrier of the rounds anyway, and
+// its chain looks at every bucket it goes on to).
+template <Op OP>
+__device__ __forceinline__ uint32_t early_conflict(const Tv &tv, const DevGeom &g, uint32_t P, uint32_t A, uint32_t idx,
+		uint32_t sig, uint32_t aux)
+{
+	if (conflict_on(tv, g, P, idx, sig, OP == OP_2CHOICE && A == P))    // (A == P: the slot replaced is one of P's)
+		return P;
+	if (A != P && conflict_on(tv, g, A, idx, sig, OP == OP_2CHOICE || (aux & kLazyBit) != 0u))
+		return A;
+	return kNone;
+}
+
 __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g, uint32_t P, uint32_t idx,
 		uint32_t bucket)
 {
+	MKV_TR(3u, idx, bucket, P);
 	atomicMin(&tv.viol[P >> g.region_shift], idx);
 	const uint32_t at = atomicAdd(tv.vlist_n, 1u);
 	if (at < (uint32_t)kViolCap)
@@ -1365,14 +1517,27 @@ __device__ __forceinline__ int apply_static_late(uint32_t *table, const DevGeom 
 		apply_static<OP, true, false>(table, r, P, A, nullptr);
 		return 0;
 	}
+	// (a request that has been through the rounds' early check, kCheckedBit, has looked already)
+	const bool unchecked = !(r.aux & kCheckedBit);
+	if (unchecked && conflict_on(tv, g, P, idx, r.sig, OP == OP_2CHOICE && A == P)) {
+		report_violation(tv, g, P, idx, P);
+		return 1;
+	}
 	if (try_place<true, false>(table, P, r.sig, r.loc, r.sig, nullptr))
 		return 0;
-	if ((r.aux & kLazyBit) && A != P && later_commit_on(tv, g, A, idx) != kNone) {
+	if (unchecked && A != P && conflict_on(tv, g, A, idx, r.sig, OP == OP_2CHOICE || (r.aux & kLazyBit) != 0u)) {
 		report_violation(tv, g, P, idx, A);
 		return 1;
 	}
 	if (try_place<true, false>(table, A, r.sig, r.loc, r.sig, nullptr))
 		return 0;
+	// What follows replaces an entry of A.  The one commit a group of duplicates has (kLeadBit) stands
+	// for writes up to its last member: to a request between the two it is a LATER commit on this
+	// bucket, and the entry about to go may be the group's.
+	if (later_commit_on(tv, g, A, idx) != kNone) {
+		report_violation(tv, g, P, idx, A);
+		return 1;
+	}
 	if (OP == OP_2CHOICE) {
 		table[sig_word(A, r.sig & 7u)] = r.sig;     // no room: the signature alone replaces slot sig&7 (ref :197-209)
 		return 0;
@@ -1394,6 +1559,7 @@ __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGe
 	if (rs != 3)
 		return rs;
 	// cuckoo, P and A full without duplicate (ref :357-423); A has been looked at for later commits
+	// (apply_static_late does before it gives up)
 	// (the log lives in this lane's slot of global memory: local arrays would cost the launch its
 	// scratch-free dispatch)
 	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
@@ -1548,6 +1714,7 @@ __device__ __forceinline__ uint32_t replay_regions(uint32_t *table, const DevGeo
 					rc = apply_serial_checked<OP>(table, g, req_of(reqc[idx]), idx, tv);
 					if (rc == 0) {
 						state[idx] = ST_DONE;
+						MKV_TR(2u, idx, 0u, 0u);
 						d++;
 					}
 				}
@@ -1585,8 +1752,7 @@ __device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const D
 		for (int k = 0; k < 16; k++) {
 			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 			const uint32_t idx = base + (uint32_t)k;
-			c += (idx >= lo_idx && idx < last &&
-					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK)) ? 1u : 0u;
+			c += (idx >= lo_idx && idx < last && (tag_pending(st) || (st == ST_SHADOW && shadow_live(state, tv.undo, reqc, idx)))) ? 1u : 0u;
 		}
 	}
 	scratch1024[t] = c;
@@ -1606,8 +1772,7 @@ __device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const D
 		for (int k = 0; k < 16; k++) {
 			const uint32_t st = (w[k >> 2] >> ((k & 3) * 8)) & 0xffu;
 			const uint32_t idx = base + (uint32_t)k;
-			if (idx >= lo_idx && idx < last &&
-					(st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK))
+			if (idx >= lo_idx && idx < last && (tag_pending(st) || (st == ST_SHADOW && shadow_live(state, tv.undo, reqc, idx))))
 				glist[at++] = idx;
 		}
 	}
@@ -1643,6 +1808,7 @@ __device__ __forceinline__ uint32_t replay_pending_scan(uint32_t *table, const D
 					rc = apply_serial_checked<OP>(table, g, req_of(reqc[ridx]), ridx, tv);
 					if (rc == 0) {
 						state[ridx] = ST_DONE;
+						MKV_TR(2u, ridx, 1u, 0u);
 						d++;
 					}
 				}
@@ -1677,9 +1843,11 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 	const unsigned long long mykey = owner_key(stamp, idx);
 	const unsigned long long stamp_field = kStampMax - stamp;
 	const uint32_t v = r.sig & 7u;
-	// (the chain begins with an eviction from A: a request that did not register there in the mark
-	// pass looks at the grid-wide rounds' commits on it first, like apply_static_late)
-	if ((r.aux & kLazyBit) && A != P && later_commit_on(tv, g, A, idx) != kNone) {
+	// (the chain begins with an eviction from A: the grid-wide rounds' commits there are looked at
+	// first, like apply_static_late does -- a request that did not register on A in the mark pass may
+	// find a later request's there, any request the commit of a group of duplicates that reaches
+	// beyond it)
+	if (later_commit_on(tv, g, A, idx) != kNone) {
 		report_violation(tv, g, P, idx, A);
 		return false;
 	}
@@ -1900,20 +2068,22 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
 					continue;
-				// A request that did not register on its alternate bucket in the mark pass (kLazyBit): a
-				// LATER request may have been committed there by the grid-wide rounds.  Looked at now, in
-				// the first round in which the request is not behind a barrier -- before anything later
-				// than it in its region can commit in the tail, where commits are final: a later commit
-				// there is an order violation (the request is the round's barrier of its region, the
-				// commit is taken back, select_from); none, and the request is an ordinary one from here
-				// on -- it registers on both buckets in every round of the tail.
-				if (OP != OP_DELETE && (rc.w & kLazyBit) && A != P) {
-					if (later_commit_on(tv, g, A, idx) != kNone) {
-						report_violation(tv, g, P, idx, A);
+				// The grid-wide rounds' commits on the request's alternate bucket, looked at ONCE, in the
+				// first round in which the request is not behind a barrier -- before anything later than it
+				// in its region can commit in the tail, where commits are final.  A later commit there is an
+				// order violation (the request is the round's barrier of its region, the commit is taken
+				// back, select_from): a request that did not register on the bucket in the mark pass
+				// (kLazyBit) may find a later request's; any request may find the commit of a group of
+				// duplicates that reaches beyond it (kLeadBit), whose entry it might replace.  None: an
+				// ordinary request from here on -- it registers on both buckets in every round of the tail.
+				if (OP != OP_DELETE && !(rc.w & kCheckedBit)) {
+					const uint32_t vb = early_conflict<OP>(tv, g, P, A, idx, rc.x, rc.w);
+					if (vb != kNone) {
+						report_violation(tv, g, P, idx, vb);
 						atomicMin(&s_rbar[region], idx);
 						continue;
 					}
-					const_cast<uint4 *>(reqc)[idx].w = rc.w & ~kLazyBit;
+					const_cast<uint4 *>(reqc)[idx].w = (rc.w & ~kLazyBit) | kCheckedBit;
 				}
 				uint4 lo, hi;
 				load_sig_row<true>(table, P, lo, hi);
@@ -2020,6 +2190,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				done = apply_static_late<OP>(table, g, r, P, A, idx, tv) == 0;
 			if (done) {
 				state[idx] = ST_DONE;
+				MKV_TR(1u, idx, (uint32_t)round, 0u);
 				keys[i] = kNone;
 				atomicAdd(s_progress, 1u);
 			} else {
@@ -2039,6 +2210,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				const uint32_t region = (r.hash & g.hash_mask) >> g.region_shift;
 				if (s_below[region] == 0u && apply_serial_checked<OP>(table, g, r, idx, tv) == 0) {
 					state[idx] = ST_DONE;
+					MKV_TR(1u, idx, (uint32_t)round, 1u);
 					keys[my_bar] = kNone;
 					atomicAdd(s_progress, 1u);
 				} else {
@@ -2163,20 +2335,22 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 					state[idx] = ST_TAIL;                   // last round's tag
 				if (idx >= s_rbar[region])
 					continue;
-				// A request that did not register on its alternate bucket in the mark pass (kLazyBit): a
-				// LATER request may have been committed there by the grid-wide rounds.  Looked at now, in
-				// the first round in which the request is not behind a barrier -- before anything later
-				// than it in its region can commit in the tail, where commits are final: a later commit
-				// there is an order violation (the request is the round's barrier of its region, the
-				// commit is taken back, select_from); none, and the request is an ordinary one from here
-				// on -- it registers on both buckets in every round of the tail.
-				if (OP != OP_DELETE && (rc.w & kLazyBit) && A != P) {
-					if (later_commit_on(tv, g, A, idx) != kNone) {
-						report_violation(tv, g, P, idx, A);
+				// The grid-wide rounds' commits on the request's alternate bucket, looked at ONCE, in the
+				// first round in which the request is not behind a barrier -- before anything later than it
+				// in its region can commit in the tail, where commits are final.  A later commit there is an
+				// order violation (the request is the round's barrier of its region, the commit is taken
+				// back, select_from): a request that did not register on the bucket in the mark pass
+				// (kLazyBit) may find a later request's; any request may find the commit of a group of
+				// duplicates that reaches beyond it (kLeadBit), whose entry it might replace.  None: an
+				// ordinary request from here on -- it registers on both buckets in every round of the tail.
+				if (OP != OP_DELETE && !(rc.w & kCheckedBit)) {
+					const uint32_t vb = early_conflict<OP>(tv, g, P, A, idx, rc.x, rc.w);
+					if (vb != kNone) {
+						report_violation(tv, g, P, idx, vb);
 						atomicMin(&s_rbar[region], idx);
 						continue;
 					}
-					const_cast<uint4 *>(reqc)[idx].w = rc.w & ~kLazyBit;
+					const_cast<uint4 *>(reqc)[idx].w = (rc.w & ~kLazyBit) | kCheckedBit;
 				}
 				uint4 lo, hi;
 				load_sig_row<true>(table, P, lo, hi);
@@ -2314,6 +2488,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 				done = apply_static_late<OP>(table, g, r, P, A, idx, tv) == 0;
 			if (done) {
 				state[idx] = ST_DONE;
+				MKV_TR(1u, idx, (uint32_t)round, 2u);
 				keys[i] = kNone;
 				my_done++;
 			} else {
@@ -2341,6 +2516,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 					const uint32_t region = (r.hash & g.hash_mask) >> g.region_shift;
 					if (ld_agent32(&ctl->g_below[set][region]) == 0u && apply_serial_checked<OP>(table, g, r, idx, tv) == 0) {
 						state[idx] = ST_DONE;
+						MKV_TR(1u, idx, (uint32_t)round, 3u);
 						keys[my_bar] = kNone;
 						my_done++;
 					} else {
@@ -2383,11 +2559,6 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 	return left;
 }
 
-__device__ __forceinline__ bool tag_pending(uint32_t st)
-{
-	return st == ST_TAIL || st == ST_LOSER || st == ST_PENDING || st >= ST_CHAIN_OK;
-}
-
 // An order violation {j, X}: the chain of the pending request j steps on bucket X, which
 // a LATER commit of the grid-wide rounds has used.  What has to go:
 //   (a) every logged commit k > j on X (at most two: the candidates of its reservation words);
@@ -2401,9 +2572,15 @@ __device__ __forceinline__ bool tag_pending(uint32_t st)
 // the whole region suffix).  Nothing is written to the table here.
 constexpr uint32_t kSelCap = 2048, kLaneStack = 24;
 
+// A group's commit (kLeadBit) by a request BELOW the asking index that reaches beyond it is not taken
+// back -- what lies below the asking index may already have final commits of the tail behind it --
+// but cut: noted in trunc[] as {leader, asking index}; the caller lets the group end before that
+// index (truncate_groups).
+constexpr uint32_t kTruncCap = 128;
+
 __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, const uint4 *reqc, const Undo *undo,
 		const ChainLog *chain_logs, const Tv &tv, uint32_t j, uint32_t X, uint2 *stack, uint32_t *sel,
-		uint32_t *nsel)
+		uint32_t *nsel, uint2 *trunc, uint32_t *ntrunc)
 {
 	uint32_t sp = 0;
 	stack[sp++] = make_uint2(X, j);
@@ -2414,10 +2591,20 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 		candidates_of(tv, ld_agent(&tv.owner1[e.x]), ld_agent(&tv.owner2[e.x]), cand[0], cand[1]);
 		for (int ci = 0; ci < 2; ci++) {
 			const uint32_t u = cand[ci];
-			if (u == kNone || u <= e.y || (ci == 1 && u == cand[0]))
+			uint32_t eff = 0;
+			if (u == kNone || (ci == 1 && u == cand[0]))
 				continue;
-			if (!commit_used(tv, g, u, e.x))
-				continue;                           // no commit there, or selected already (by this lane or another)
+			if (!commit_used(tv, g, u, e.x, &eff) || eff <= e.y)
+				continue;                           // no commit there, not a later one, or selected already
+			if (u < e.y) {                          // a group that begins below the asking index: cut, not taken back
+				const uint32_t at = atomicAdd(ntrunc, 1u);
+				MKV_TR(6u, u, e.y, 0u);
+				if (at < kTruncCap)
+					trunc[at] = make_uint2(u, e.y);
+				else
+					ok = false;
+				continue;
+			}
 			const uint32_t st = state[u];
 			if (!tag_logged(st))
 				continue;
@@ -2474,6 +2661,7 @@ __device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uin
 			table[ur.word0] = ur.old0;
 	}
 	state[u] = ST_DEFER;
+	MKV_TR(4u, u, 0u, 0u);
 }
 
 // Roll back the commits of the grid-wide rounds that are flagged ST_SELECT (select_from)
@@ -2483,8 +2671,10 @@ __device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uin
 // Returns the number this thread rolled back.
 __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
 		const Undo *undo, const ChainLog *chain_logs, const uint32_t *thr, uint32_t lo_idx, uint32_t total,
-		uint32_t wg, uint32_t nwg, uint32_t *sync_counter)
+		uint32_t wg, uint32_t nwg, uint32_t *sync_counter, uint2 *trunc, uint32_t *ntrunc)
 {
+	// (a group's commit by a request below its region's threshold that reaches to or beyond it is cut
+	// there, like select_from cuts it: trunc[], the caller runs truncate_groups)
 	const uint32_t *reqw = reinterpret_cast<const uint32_t *>(reqc);
 	uint32_t undone = 0;
 	for (int pass = 0; pass < 2; pass++) {
@@ -2496,9 +2686,20 @@ __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *t
 			if ((st & 0x7fu) != tag && (st & 0x7fu) != ctag)
 				continue;
 			if (!(st & (uint32_t)ST_SELECT)) {
-				const uint32_t hash = reqw[(size_t)idx * 4u + 1u];
-				if (idx < thr[(hash & g.hash_mask) >> g.region_shift])
+				const uint32_t hash = reqw[(size_t)idx * 4u + 1u], aux = reqw[(size_t)idx * 4u + 3u];
+				// (the one commit of a group of duplicates stands for writes up to the group's last member)
+				const uint32_t eff = (aux & kLeadBit) ? (aux >> 8) : idx;
+				const uint32_t th = thr[(hash & g.hash_mask) >> g.region_shift];
+				if (eff < th)
 					continue;
+				if (idx < th) {                         // (only a group's leader has eff > idx)
+					const uint32_t at = atomicAdd(ntrunc, 1u);
+					if (at < kTruncCap)
+						MKV_TR(6u, idx, th - 1u, 1u);
+						trunc[at] = make_uint2(idx, th - 1u);   // (members at or beyond the threshold are pending again;
+						                                        // beyond kTruncCap: met again in the next turn)
+					continue;
+				}
 			}
 			const Undo u = undo[idx];
 			if ((st & 0x7fu) == ctag) {
@@ -2513,6 +2714,7 @@ __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *t
 					table[u.word0] = u.old0;
 			}
 			state[idx] = ST_TAIL;
+			MKV_TR(5u, idx, thr[(reqw[(size_t)idx * 4u + 1u] & g.hash_mask) >> g.region_shift], st);
 			undone++;
 		}
 		if (pass == 0)
@@ -2525,8 +2727,8 @@ __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *t
 
 // Gather the unfinished requests of [lo_idx, total) into list[] (any order), counting in
 // *counter (LDS for one work-group, the control block for several).
-__device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *list, uint32_t *counter, uint32_t lo_idx,
-		uint32_t total, uint32_t wg, uint32_t nwg)
+__device__ __forceinline__ void gather_pending(uint8_t *state, const Undo *undo, const uint4 *reqc, uint32_t *list,
+		uint32_t *counter, uint32_t lo_idx, uint32_t total, uint32_t wg, uint32_t nwg)
 {
 	const uint32_t t = threadIdx.x;
 	const uint32_t lo16 = lo_idx & ~15u;
@@ -2541,6 +2743,11 @@ __device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *l
 			const uint32_t idx = base + (uint32_t)k;
 			if (idx >= lo_idx && idx < total && tag_pending(st))
 				take |= 1u << k;
+			if (idx >= lo_idx && idx < total && st == ST_SHADOW && shadow_live(state, undo, reqc, idx)) {
+				take |= 1u << k;                    // its group's commit does not stand (any more): a request like any other
+				MKV_TR(9u, idx, undo[idx].word0, 0u);
+				state[idx] = ST_TAIL;
+			}
 		}
 		if (!take)
 			continue;
@@ -2550,6 +2757,64 @@ __device__ __forceinline__ void gather_pending(const uint8_t *state, uint32_t *l
 			if ((take >> k) & 1u)
 				list[at++] = base + (uint32_t)k;
 	}
+}
+
+// The location word a group's commit stored the group's last location in.
+__device__ __forceinline__ uint32_t group_loc_word(const Undo &u, uint32_t st, const ChainLog *chain_logs)
+{
+	if (st == ST_CHAIN1 || st == ST_CHAIN2)
+		return chain_logs[u.word0].word[1];         // (the chain's first eviction put the request itself into A)
+	return u.word1 != kNoWord ? u.word1 : u.word0;  // a new entry: {signature word, location word}; a duplicate: its location word
+}
+
+// Cuts groups of duplicates (select_from, roll-back by region): the group of leader c ends before
+// index `cut` -- its members beyond are pending requests again (tag TAIL: they lie beyond the
+// violation's index, nothing there has been committed by the tail), the entry's location is that
+// of the last member that remains, and the commit counts as that member's index from here on.
+// One work-group; trunc[0 .. n) in LDS, m1[] scratch of n words.
+__device__ __forceinline__ void truncate_groups(uint32_t *table, uint8_t *state, const uint4 *reqc, const Undo *undo,
+		const ChainLog *chain_logs, const uint2 *trunc, uint32_t n, uint32_t *m1, uint32_t lo_idx, uint32_t total)
+{
+	for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
+		m1[k] = trunc[k].x;
+	__syncthreads();
+	for (uint32_t i = lo_idx + threadIdx.x; i < total && i >= lo_idx; i += blockDim.x) {
+		if (state[i] != ST_SHADOW)
+			continue;
+		const uint32_t c = undo[i].word0;
+		uint32_t cut = kNone;
+		for (uint32_t k = 0; k < n; k++)
+			if (trunc[k].x == c && trunc[k].y < cut)
+				cut = trunc[k].y;
+		if (cut == kNone)
+			continue;
+		if (i > cut) {
+			MKV_TR(7u, i, c, cut);
+			state[i] = ST_TAIL;
+		} else {
+			for (uint32_t k = 0; k < n; k++)
+				if (trunc[k].x == c)
+					atomicMax(&m1[k], i);
+		}
+	}
+	__syncthreads();
+	for (uint32_t k = threadIdx.x; k < n; k += blockDim.x) {
+		const uint32_t c = trunc[k].x;
+		bool first = true;                          // (one lane per leader: the first entry that names it)
+		uint32_t last = m1[k];
+		for (uint32_t q = 0; q < n; q++)
+			if (trunc[q].x == c) {
+				first = first && q >= k;
+				last = m1[q] > last ? m1[q] : last;
+			}
+		if (!first)
+			continue;
+		const uint32_t st = state[c] & 0x7fu;
+		MKV_TR(8u, c, last, st);
+		table[group_loc_word(undo[c], st, chain_logs)] = reqc[last].z;
+		const_cast<uint4 *>(reqc)[c].w = (reqc[c].w & 0xffu) | ((uint32_t)last << 8);
+	}
+	__syncthreads();
 }
 
 // ---- the tail launch ----------------------------------------------------------------------
@@ -2570,7 +2835,9 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ __align__(16) uint32_t lkeys[kSortCap];
 	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
 	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
-	__shared__ uint32_t s_dflag, s_nsel;
+	__shared__ uint32_t s_dflag, s_dflag2, s_nsel, s_ntrunc;
+	__shared__ uint2 s_trunc[kTruncCap];        // groups of duplicates to be cut (select_from, roll_back_from)
+	__shared__ uint32_t s_tm1[kTruncCap];
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
@@ -2615,7 +2882,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	bool grid_mode = false;
 	if (work_left) {
 		MKV_PHASE(0);
-		gather_pending(state, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff);
+		gather_pending(state, undo, reqc, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff);
 		MKV_PHASE(6);
 		grid_sync(&ctl->sync[1], nwg_eff);
 		// a launch left with a long list keeps every work-group for its rounds
@@ -2770,6 +3037,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			static_assert((uint32_t)kViolCap * kLaneStack * 2u + kSelCap <= (uint32_t)kSortCap, "LDS of the work list");
 			uint32_t *sel = lkeys + (uint32_t)kViolCap * kLaneStack * 2u;
 			if (t == 0) {
+				s_dflag2 = 0u;
+				s_ntrunc = 0u;
 				s_dflag = dbg_path == 2 ? 1u : 0u;      // (tests: always the region-suffix fall-back)
 				s_nsel = 0;
 				s_viols += nseeds;
@@ -2779,7 +3048,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				const uint32_t *sw = reinterpret_cast<const uint32_t *>(ctl->vlist + t);
 				const uint32_t sj = ld_agent32(sw), sX = ld_agent32(sw + 1);
 				if (!select_from(g, state, reqc, undo, chain_logs, tv, sj, sX,
-						reinterpret_cast<uint2 *>(lkeys) + t * kLaneStack, sel, &s_nsel))
+						reinterpret_cast<uint2 *>(lkeys) + t * kLaneStack, sel, &s_nsel, s_trunc, &s_ntrunc))
 					s_dflag = 1u;
 			}
 			wg_sync();
@@ -2796,11 +3065,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 						if (st != tag && st != ctag)
 							continue;
 						take_back(g, table, state, reqc, undo, chain_logs, k, st == ctag);
+						if (reqc[k].w & kLeadBit)
+							s_dflag2 = 1u;                  // its shadows are pending again: the tags are gathered anew
 						u++;
 					}
 					wg_sync();
 				}
-				if (relisted != kNone) {
+				if (relisted != kNone && !s_dflag2) {
 					for (uint32_t i = t; i < nsel; i += blockDim.x)
 						glist[relisted + i] = sel[i];
 					relisted += nsel;
@@ -2814,7 +3085,20 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				if (t < kMaxRegions)
 					s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[t]) : kNone;
 				__syncthreads();
-				u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr);
+				if (t == 0)
+					s_ntrunc = 0u;                      // (what select_from noted is found again by index)
+				__syncthreads();
+				u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr, s_trunc,
+						&s_ntrunc);
+			}
+			// groups of duplicates that begin below a violation's index and reach beyond it: cut there
+			__syncthreads();
+			{
+				const uint32_t ntr = s_ntrunc < kTruncCap ? s_ntrunc : kTruncCap;
+				if (ntr) {
+					truncate_groups(table, state, reqc, undo, chain_logs, s_trunc, ntr, s_tm1, lo_idx, total);
+					relisted = kNone;                   // (their members beyond the cut are pending again: gathered anew)
+				}
 			}
 			if (u)
 				atomicAdd(&s_undone, u);
@@ -2831,7 +3115,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		}
 		__syncthreads();
 		if (relisted == kNone)
-			gather_pending(state, glist, &s_n, lo_idx, total, 0u, 1u);
+			gather_pending(state, undo, reqc, glist, &s_n, lo_idx, total, 0u, 1u);
 		else if (t == 0)
 			s_n = relisted;
 		wg_sync();
@@ -3356,10 +3640,10 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 		tail_rounds = kMaxTailRounds;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			tuning().debug_skip & 4);
+			(tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8), w->cnt + ((size_t)g.hash_mask + 1u));
 	hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			tuning().debug_skip & 4);
+			(tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8), w->cnt + ((size_t)g.hash_mask + 1u));
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
 			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
@@ -3778,6 +4062,50 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->tail_rounds = h.last.tail_rounds;
 	return MKV_OK;
 }
+
+// diagnostics (tools/streams_probe.py): what the workspace holds for request idx after the last
+// pass -- out[0] = tag, out[1..4] = request cache {sig, hash, loc, flags}, out[5..8] = undo record
+extern "C" int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9])
+{
+	int dev = 0;
+	if (!out || hipGetDevice(&dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+		return MKV_EINVAL;
+	mkv::Workspace *w = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+		auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
+		if (it == mkv::g_ws.end() || !it->second->ctl || (int64_t)idx >= it->second->req_cap)
+			return MKV_EINVAL;
+		w = it->second;
+	}
+	uint8_t st = 0;
+	if (hipMemcpy(&st, w->state + idx, 1, hipMemcpyDeviceToHost) != hipSuccess ||
+			hipMemcpy(out + 1, w->reqc + idx, 16, hipMemcpyDeviceToHost) != hipSuccess ||
+			hipMemcpy(out + 5, w->undo + idx, 16, hipMemcpyDeviceToHost) != hipSuccess)
+		return MKV_EHIP;
+	out[0] = st;
+	return MKV_OK;
+}
+
+#ifdef MKV_TRACE
+// debug builds: the tail's trace (words 0..3: count; then {code, a, b, c} per event); reset != 0 clears it
+extern "C" int mkv_debug_trace(uint32_t *out, uint32_t cap_words, int reset)
+{
+	if (hipDeviceSynchronize() != hipSuccess)
+		return MKV_EHIP;
+	size_t n = sizeof(mkv::g_trace);
+	if ((size_t)cap_words * 4u < n)
+		n = (size_t)cap_words * 4u;
+	if (out && hipMemcpyFromSymbol(out, HIP_SYMBOL(mkv::g_trace), n) != hipSuccess)
+		return MKV_EHIP;
+	if (reset) {
+		const uint32_t z = 0;
+		if (hipMemcpyToSymbol(HIP_SYMBOL(mkv::g_trace), &z, 4) != hipSuccess)
+			return MKV_EHIP;
+	}
+	return MKV_OK;
+}
+#endif
 
 // diagnostics: how often this stream's workspace cleared its reservation tables because
 // the round stamps ran low (-1: no such workspace)

@@ -249,12 +249,20 @@ def test_insert_tail_fallback_beyond_lds_sort():
     """> 8192 leftovers after the parallel rounds: the in-order tail walks the
     request state array instead of sorting in LDS."""
     set_tuning("tail_rounds", 0)
-    g = Geometry(mem_p=16)
-    rng = np.random.default_rng(8)
-    e = random_requests(g, rng, 20000, 1 << 30, hot=1.0)      # 4 keys, 20000 requests
+    set_tuning("dup_groups", 0)                               # (round 2 would settle the duplicates as four groups)
+    try:
+        g = Geometry(mem_p=16)
+        rng = np.random.default_rng(8)
+        e = random_requests(g, rng, 20000, 1 << 30, hot=1.0)      # 4 keys, 20000 requests
+        got, exp, info = run_insert_case(g, np.zeros((g.nbuckets, 16), np.uint32), [e])
+        assert np.array_equal(got, exp), (first_diff(got, exp), info)
+        assert info["tail_serial"] > 8192
+    finally:
+        set_tuning("dup_groups", 1)
+    # the same batch with the duplicates settled as groups in round 2: nothing left for the tail
     got, exp, info = run_insert_case(g, np.zeros((g.nbuckets, 16), np.uint32), [e])
     assert np.array_equal(got, exp), (first_diff(got, exp), info)
-    assert info["tail_serial"] > 8192
+    assert info["tail_serial"] == 0 and info["tail_parallel"] < 64
 
 
 def test_insert_many_batches_grow_load_factor():

@@ -72,7 +72,11 @@ with torch.cuda.stream(stream):
         O.insert(og, exp, blocks)
         stream.synchronize()
         got = idx.table_numpy()
-        print("step", step, dict(nq=nq, nd=nd, ni=ni, how=how, hint=hint), idx.last_update_info(stream, cycle_insert=True))
+        try:
+            info = idx.last_update_info(stream, cycle_insert=(overlap != "none" and ni > 0))
+        except Exception as ex:                       # (no insert half ran through that workspace yet)
+            info = str(ex)
+        print("step", step, dict(nq=nq, nd=nd, ni=ni, how=how, hint=hint), info)
         if not np.array_equal(got, exp):
             bad = np.argwhere((got != exp).any(axis=1))[:, 0]
             print("differing buckets", bad[:10], "of", len(bad))
@@ -83,7 +87,13 @@ with torch.cuda.stream(stream):
             for b in bad[:2]:
                 print("bucket", b, "\n before ", before[b], "\n deleted", after_delete[b], "\n oracle ", exp[b], "\n gpu    ", got[b])
                 sel = np.flatnonzero((P == b) | (A == b))
-                for i in sel[:60]:
+                print("   requests on it:", len(sel), "first", sel[:5], "last", sel[-5:])
+                for sl in range(8):
+                    if got[b][8 + sl] != exp[b][8 + sl]:
+                        print("   slot", sl, "oracle loc from idx", np.flatnonzero(allreq[:, 2] == exp[b][8 + sl]), "gpu loc from idx", np.flatnonzero(allreq[:, 2] == got[b][8 + sl]))
+                bounds = np.cumsum([0] + [len(x) for x in blocks])
+                print("   block bounds", bounds.tolist())
+                for i in sel[-12:]:
                     freeP = int((after_delete[P[i], :8] == 0).sum())
                     freeP0 = int((before[P[i], :8] == 0).sum())
                     print(f"   idx {i} sig {allreq[i,0]} P {P[i]} A {A[i]} loc {allreq[i,2]} free(P) before {freeP0} after-delete {freeP}")

@@ -28,8 +28,16 @@ def main():
     og = ogeom(g)
     L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 1, 3, 48])))
     L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 2048, 8192, 65536])))
+    rng2 = np.random.default_rng(5000 + seed)        # (as tests/test_gpu_fuzz.py::_run draws them)
+    L.mkv_set_tuning(b"tail_groups", int(rng2.choice([1, 2, 5, 32])))
+    L.mkv_set_tuning(b"grid_min", int(rng2.choice([0, 0, 64, 2048])))
+    L.mkv_set_tuning(b"calm_factor", int(rng2.choice([1, 4])))
+    rng3 = np.random.default_rng(11000 + seed)
+    L.mkv_set_tuning(b"debug_skip", int(rng3.choice([0, 0, 1, 2])) + int(rng3.choice([0, 0, 0, 4])))
+    L.mkv_set_tuning(b"round_blocks", int(rng3.choice([1, 3, 64, 512, 512])))
     for k, v in over.items():
         L.mkv_set_tuning(k.encode(), int(v))
+    shape = str(np.random.default_rng(7000 + seed).choice(["random", "random", "random", "ref", "cluster"]))
     fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
     sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
     exp = random_table(g, rng, fill, sig_space)
@@ -41,7 +49,7 @@ def main():
         op = rng.choice(["insert", "insert", "delete", "search"])
         n = int(rng.integers(1, max(2, min(40000, nslots))))
         e = random_requests(g, rng, n, sig_space, hot=float(rng.choice([0.0, 0.1, 0.6])),
-                            zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])))
+                            zero_low=float(rng.choice([0.0, 0.1])), zeros=float(rng.choice([0.0, 0.03])), shape=shape)
         if op == "insert":
             how = str(rng.choice(["single", "region", "app", "uneven"]))
             if iblock_p == 0 and how == "app":
@@ -49,6 +57,8 @@ def main():
             blocks = split_blocks(e, g, rng, how)
             before = exp.copy()
             O.insert(og, exp, blocks)
+            if hasattr(L, "mkv_debug_trace"):
+                L.mkv_debug_trace(None, 0, 1)
             idx.insert([dev(b.reshape(-1, 3)) for b in blocks], hint=None if rng.random() < 0.7 else 0)
             got = idx.table_numpy()
             print("step", step, op, n, how, idx.last_update_info())
@@ -68,6 +78,24 @@ def main():
                         for (b0, s0) in src.tolist():
                             for i in np.argwhere((P == b0) | (A == b0))[:, 0]:
                                 print("      touches origin bucket", b0, ": idx", i, "sig", allreq[i, 0], "sig&7", allreq[i, 0] & 7, "P", P[i], "A", A[i])
+                if hasattr(L, "mkv_debug_trace"):
+                    import ctypes
+                    cap = 4 * (1 << 17) + 4
+                    buf = (ctypes.c_uint32 * cap)()
+                    L.mkv_debug_trace(buf, cap, 0)
+                    ev = np.frombuffer(buf, dtype=np.uint32)
+                    ne = min(int(ev[0]), 1 << 17)
+                    ev = ev[4:4 + 4 * ne].reshape(-1, 4)
+                    nb = g.nbuckets
+                    per = nb >> iblock_p
+                    reg_of = lambda i: int(P[i]) // per
+                    R = int(bad[0]) // per
+                    names = {1: "round-commit", 2: "replay-commit", 3: "VIOLATION", 4: "take-back", 5: "roll-back",
+                             6: "trunc-note", 7: "revive(cut)", 8: "cut-done", 9: "revive(gather)"}
+                    print("trace:", ne, "events; region", R, "of the differing bucket:")
+                    for code, a, b, c in ev.tolist():
+                        if a < len(allreq) and reg_of(a) == R:
+                            print("   %-14s idx %d  (%d, %d)  sig %d P %d A %d w %s" % (names.get(code, code), a, b, c, allreq[a, 0], P[a], A[a], ""))
                 for B in bad[:3]:
                     print("bucket", B, "\n before", before[B], "\n oracle", exp[B], "\n gpu   ", got[B])
                     for i in np.argwhere((P == B) | (A == B))[:, 0]:
