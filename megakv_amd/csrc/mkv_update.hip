@@ -160,6 +160,8 @@ struct Ctl {
 	uint32_t overflow;
 	uint32_t any_loser;              // plain flags, set by whoever produces such work
 	uint32_t any_tail;
+	uint32_t loose;                  // round 2: a follower at the head of its bucket did not get to lead -- its
+	                                 // shadows are pending requests (the tail's first gather looks for them)
 	uint32_t first_hard;
 	uint32_t chain_n;                // chain-log entries handed out this call
 	uint32_t chain_ok;               // chains committed optimistically
@@ -731,6 +733,34 @@ __device__ __forceinline__ void fold_min_dedup(const Fold &f, unsigned long long
 		atomicMin(&owner[b], key);
 }
 
+// ... and atomic_max_dedup with the fold table behind it
+template <int LOG2>
+__device__ __forceinline__ void fold_max_dedup(const Fold &f, unsigned long long *words, uint32_t b,
+		unsigned long long key, bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		unsigned long long k = same ? key : 0ull;
+		if (__popcll(__ballot(same)) > 1) {
+			for (int off = 32; off > 0; off >>= 1) {
+				const unsigned long long o = __shfl_xor(k, off);
+				k = o > k ? o : k;
+			}
+		}
+		if ((int)(threadIdx.x & 63u) == first && !fold_enter<true, LOG2>(f, fb, k, false, false))
+			atomicMax(&words[fb], k);
+		active = active && !same;
+	}
+	if (active && !fold_enter<true, LOG2>(f, b, key, false, false))
+		atomicMax(&words[b], key);
+}
+
 // statistics: one atomic per wave, spread over kShards words
 __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 {
@@ -1159,8 +1189,32 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	__shared__ uint4 s_q[kDeferCap];
 	__shared__ uint32_t s_qg[kDeferCap];        // round 2: the last member of the group a queued request leads (kNone: none)
 	__shared__ uint32_t s_qn;
-	if (threadIdx.x == 0)
+	// Round 1, batches with many duplicates of a few keys (SETs drawn from a Zipf law: 36 000 of one key
+	// in 2^19): the losers' registrations for round 2 and the followers' election all aim at the words of
+	// those keys' buckets -- 226 us of queueing on a handful of addresses.  Waves with many losers
+	// send theirs through a hash table in LDS, flushed once per turn: one atomic per bucket and
+	// work-group (fold_min_dedup, as the mark pass does).
+	constexpr uint32_t kRFold = ROUND == 1 ? (1u << kMarkFoldLog2) : 1u;
+	__shared__ uint32_t s_ftb[2u * kRFold];
+	__shared__ unsigned long long s_ftk[2u * kRFold];
+	__shared__ uint32_t s_fused;
+	Fold fmin, fmax;
+	fmin.tb = s_ftb;
+	fmin.tc = nullptr;
+	fmin.tk = s_ftk;
+	fmax.tb = s_ftb + kRFold;
+	fmax.tc = nullptr;
+	fmax.tk = s_ftk + kRFold;
+	if (threadIdx.x == 0) {
 		s_qn = 0u;
+		s_fused = 0u;
+	}
+	if (ROUND == 1) {
+		for (uint32_t q = threadIdx.x; q < 2u * kRFold; q += blockDim.x) {
+			s_ftb[q] = kNone;
+			s_ftk[q] = q < kRFold ? ~0ull : 0ull;
+		}
+	}
 	__syncthreads();
 	uint4 *reqw = const_cast<uint4 *>(reqc);    // (the flag word of a request's cache entry is written here)
 	// whole waves go round together (the re-registration folds the atomics of lanes on one
@@ -1203,7 +1257,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 							}
 						}
 						if (grp == kNone)
-							ctl->any_tail = 1u;     // (cannot happen: it entered the election itself; its
+							ctl->loose = ctl->any_tail = 1u;     // (cannot happen: it entered the election itself; its
 							                        // shadows would be picked up again by the tail's gather)
 					}
 					Undo u;
@@ -1241,13 +1295,21 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				// Losers register for round 2.  (Every lane comes by here.  Many in one wave mean
 				// duplicates of a hot key: their atomics on one bucket are folded; the usual two or
 				// three go one atomic each.)
-				if (__popcll(__ballot(lose)) >= 8)
-					reserve_wave(owner_next, P, A, owner_key(stamp + 1, idx), lose);
-				else if (lose)
+				const bool heavy = __popcll(__ballot(lose)) >= 8;
+				if (heavy) {
+					fold_min_dedup<kMarkFoldLog2>(fmin, owner_next, P, owner_key(stamp + 1, idx), lose);
+					fold_min_dedup<kMarkFoldLog2>(fmin, owner_next, A, owner_key(stamp + 1, idx), lose && A != P);
+					if ((threadIdx.x & 63u) == 0u)
+						s_fused = 1u;
+				} else if (lose) {
 					reserve(owner_next, P, A, owner_key(stamp + 1, idx));
+				}
 				// ... and the followers elect the last of them
 				if (OP != OP_DELETE && __ballot(follower)) {
-					atomic_max_dedup(emax, P, (stamp1 << kIdxBits) | idx, follower);
+					if (heavy)
+						fold_max_dedup<kMarkFoldLog2>(fmax, emax, P, (stamp1 << kIdxBits) | idx, follower);
+					else
+						atomic_max_dedup(emax, P, (stamp1 << kIdxBits) | idx, follower);
 					if (follower)
 						reqw[idx].w = rc.w | kFollowBit;
 				}
@@ -1268,6 +1330,13 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			more = base < count && base >= start;
 		}
 		__syncthreads();
+		if (ROUND == 1 && s_fused) {
+			fold_flush<false, false, kMarkFoldLog2>(fmin, owner_next, nullptr, 0ull);
+			fold_flush<true, true, kMarkFoldLog2>(fmax, emax, nullptr, 0ull);
+			if (threadIdx.x == 0)
+				s_fused = 0u;
+			__syncthreads();
+		}
 		const uint32_t qn = s_qn;
 		if (more && qn + blockDim.x <= (uint32_t)kDeferCap)
 			continue;                                   // room for another turn's worth
@@ -1328,7 +1397,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 						if (chained || u.word1 != kNoWord || (u.word0 & 15u) >= kSlots)
 							reqw[idx].w = (reqc[idx].w & 0xffu) | kLeadBit | (grp << 8);
 						else
-							ctl->any_tail = 1u;         // (work for the tail even if nothing else is)
+							ctl->loose = ctl->any_tail = 1u;    // (work for the tail even if nothing else is)
 					}
 					if (chained)
 						atomicAdd(&ctl->chain_ok, 1u);
@@ -1354,6 +1423,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			if (to_tail) {
 				state[idx] = ST_TAIL;
 				ctl->any_tail = 1u;
+				if (ROUND == 2 && grp != kNone)
+					ctl->loose = 1u;                    // (its shadows are on their own)
 				if (hard) {
 					ctl->any_hard = 1u;
 					atomicAdd(&ctl->hard_tail, 1u);
@@ -1626,6 +1697,7 @@ __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 	ctl->sync[0] = ctl->sync[1] = 0;
 	ctl->g_sync = 0;
 	ctl->glist_n = 0;
+	ctl->loose = 0;
 	ctl->carry_next = kNone;
 	ctl->undone_acc = 0;
 	ctl->g_progress[0] = ctl->g_progress[1] = 0;
@@ -2715,6 +2787,11 @@ __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *t
 			}
 			state[idx] = ST_TAIL;
 			MKV_TR(5u, idx, thr[(reqw[(size_t)idx * 4u + 1u] & g.hash_mask) >> g.region_shift], st);
+			if (reqw[(size_t)idx * 4u + 3u] & kLeadBit) {       // its shadows are requests of their own again
+				const uint32_t at = atomicAdd(ntrunc, 1u);
+				if (at < kTruncCap)
+					trunc[at] = make_uint2(idx, idx);
+			}
 			undone++;
 		}
 		if (pass == 0)
@@ -2727,8 +2804,9 @@ __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *t
 
 // Gather the unfinished requests of [lo_idx, total) into list[] (any order), counting in
 // *counter (LDS for one work-group, the control block for several).
+// (shadows: only looked at when a leader may have let its shadows down without reviving them itself)
 __device__ __forceinline__ void gather_pending(uint8_t *state, const Undo *undo, const uint4 *reqc, uint32_t *list,
-		uint32_t *counter, uint32_t lo_idx, uint32_t total, uint32_t wg, uint32_t nwg)
+		uint32_t *counter, uint32_t lo_idx, uint32_t total, uint32_t wg, uint32_t nwg, bool shadows)
 {
 	const uint32_t t = threadIdx.x;
 	const uint32_t lo16 = lo_idx & ~15u;
@@ -2743,7 +2821,7 @@ __device__ __forceinline__ void gather_pending(uint8_t *state, const Undo *undo,
 			const uint32_t idx = base + (uint32_t)k;
 			if (idx >= lo_idx && idx < total && tag_pending(st))
 				take |= 1u << k;
-			if (idx >= lo_idx && idx < total && st == ST_SHADOW && shadow_live(state, undo, reqc, idx)) {
+			if (shadows && idx >= lo_idx && idx < total && st == ST_SHADOW && shadow_live(state, undo, reqc, idx)) {
 				take |= 1u << k;                    // its group's commit does not stand (any more): a request like any other
 				MKV_TR(9u, idx, undo[idx].word0, 0u);
 				state[idx] = ST_TAIL;
@@ -2769,32 +2847,67 @@ __device__ __forceinline__ uint32_t group_loc_word(const Undo &u, uint32_t st, c
 
 // Cuts groups of duplicates (select_from, roll-back by region): the group of leader c ends before
 // index `cut` -- its members beyond are pending requests again (tag TAIL: they lie beyond the
-// violation's index, nothing there has been committed by the tail), the entry's location is that
-// of the last member that remains, and the commit counts as that member's index from here on.
-// One work-group; trunc[0 .. n) in LDS, m1[] scratch of n words.
+// violation's index, nothing there has been committed by the tail; appended to list[] if given,
+// counted in *revived), the entry's location is that of the last member that remains, and the
+// commit counts as that member's index from here on.  An entry {c, c}: the leader's commit itself
+// has been taken back, all its shadows are on their own.
+// One work-group; trunc[0 .. n) in LDS, m1[] scratch of n words.  A thread takes 16 tags per load
+// and issues the loads of their leaders together (a Zipf batch is half shadows).
 __device__ __forceinline__ void truncate_groups(uint32_t *table, uint8_t *state, const uint4 *reqc, const Undo *undo,
-		const ChainLog *chain_logs, const uint2 *trunc, uint32_t n, uint32_t *m1, uint32_t lo_idx, uint32_t total)
+		const ChainLog *chain_logs, const uint2 *trunc, uint32_t n, uint32_t *m1, uint32_t lo_idx, uint32_t total,
+		uint32_t *list, uint32_t *revived)
 {
 	for (uint32_t k = threadIdx.x; k < n; k += blockDim.x)
 		m1[k] = trunc[k].x;
 	__syncthreads();
-	for (uint32_t i = lo_idx + threadIdx.x; i < total && i >= lo_idx; i += blockDim.x) {
-		if (state[i] != ST_SHADOW)
+	const uint32_t lo16 = lo_idx & ~15u;
+	const uint4 *st4 = reinterpret_cast<const uint4 *>(state);
+	for (uint32_t base = lo16 + threadIdx.x * 16u; base < total && base >= lo16; base += blockDim.x * 16u) {
+		const uint4 v = st4[base >> 4];
+		const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+		uint32_t sh = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			const uint32_t idx = base + (uint32_t)k;
+			if (((w[k >> 2] >> ((k & 3) * 8)) & 0xffu) == (uint32_t)ST_SHADOW && idx >= lo_idx && idx < total)
+				sh |= 1u << k;
+		}
+		if (!sh)
 			continue;
-		const uint32_t c = undo[i].word0;
-		uint32_t cut = kNone;
-		for (uint32_t k = 0; k < n; k++)
-			if (trunc[k].x == c && trunc[k].y < cut)
-				cut = trunc[k].y;
-		if (cut == kNone)
-			continue;
-		if (i > cut) {
-			MKV_TR(7u, i, c, cut);
-			state[i] = ST_TAIL;
-		} else {
-			for (uint32_t k = 0; k < n; k++)
-				if (trunc[k].x == c)
-					atomicMax(&m1[k], i);
+		uint32_t lead[16];
+#pragma unroll
+		for (int k = 0; k < 16; k++)
+			lead[k] = ((sh >> k) & 1u) ? undo[base + (uint32_t)k].word0 : kNone;
+		uint32_t take = 0;
+#pragma unroll
+		for (int k = 0; k < 16; k++) {
+			if (!((sh >> k) & 1u))
+				continue;
+			const uint32_t i = base + (uint32_t)k, c = lead[k];
+			uint32_t cut = kNone;
+			for (uint32_t q = 0; q < n; q++)
+				if (trunc[q].x == c && trunc[q].y < cut)
+					cut = trunc[q].y;
+			if (cut == kNone)
+				continue;
+			if (i > cut) {
+				MKV_TR(7u, i, c, cut);
+				state[i] = ST_TAIL;
+				take |= 1u << k;
+			} else {
+				for (uint32_t q = 0; q < n; q++)
+					if (trunc[q].x == c)
+						atomicMax(&m1[q], i);
+			}
+		}
+		if (take) {
+			uint32_t at = atomicAdd(revived, (uint32_t)__popc(take));
+			if (list) {
+#pragma unroll
+				for (int k = 0; k < 16; k++)
+					if ((take >> k) & 1u)
+						list[at++] = base + (uint32_t)k;
+			}
 		}
 	}
 	__syncthreads();
@@ -2807,9 +2920,9 @@ __device__ __forceinline__ void truncate_groups(uint32_t *table, uint8_t *state,
 				first = first && q >= k;
 				last = m1[q] > last ? m1[q] : last;
 			}
-		if (!first)
-			continue;
 		const uint32_t st = state[c] & 0x7fu;
+		if (!first || !tag_logged(st))              // (not logged: the leader's commit is gone altogether)
+			continue;
 		MKV_TR(8u, c, last, st);
 		table[group_loc_word(undo[c], st, chain_logs)] = reqc[last].z;
 		const_cast<uint4 *>(reqc)[c].w = (reqc[c].w & 0xffu) | ((uint32_t)last << 8);
@@ -2835,7 +2948,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ __align__(16) uint32_t lkeys[kSortCap];
 	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
 	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
-	__shared__ uint32_t s_dflag, s_dflag2, s_nsel, s_ntrunc;
+	__shared__ uint32_t s_dflag, s_nsel, s_ntrunc;
+	__shared__ uint32_t s_loose, s_revived;
 	__shared__ uint2 s_trunc[kTruncCap];        // groups of duplicates to be cut (select_from, roll_back_from)
 	__shared__ uint32_t s_tm1[kTruncCap];
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
@@ -2859,6 +2973,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		s_par = 0;
 		s_serial = 0;
 		s_viols = 0;
+		s_loose = 0;
+		s_revived = 0;
 	}
 	// The scans over the request tags can be shared by all work-groups of the launch;
 	// everything after them is work-group 0's (unless much is left).  The helpers only stay when
@@ -2882,7 +2998,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	bool grid_mode = false;
 	if (work_left) {
 		MKV_PHASE(0);
-		gather_pending(state, undo, reqc, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff);
+		gather_pending(state, undo, reqc, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff, ctl->loose != 0u);
 		MKV_PHASE(6);
 		grid_sync(&ctl->sync[1], nwg_eff);
 		// a launch left with a long list keeps every work-group for its rounds
@@ -3037,7 +3153,6 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			static_assert((uint32_t)kViolCap * kLaneStack * 2u + kSelCap <= (uint32_t)kSortCap, "LDS of the work list");
 			uint32_t *sel = lkeys + (uint32_t)kViolCap * kLaneStack * 2u;
 			if (t == 0) {
-				s_dflag2 = 0u;
 				s_ntrunc = 0u;
 				s_dflag = dbg_path == 2 ? 1u : 0u;      // (tests: always the region-suffix fall-back)
 				s_nsel = 0;
@@ -3065,18 +3180,19 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 						if (st != tag && st != ctag)
 							continue;
 						take_back(g, table, state, reqc, undo, chain_logs, k, st == ctag);
-						if (reqc[k].w & kLeadBit)
-							s_dflag2 = 1u;                  // its shadows are pending again: the tags are gathered anew
+						if (reqc[k].w & kLeadBit) {         // its shadows are requests of their own again
+							const uint32_t at = atomicAdd(&s_ntrunc, 1u);
+							if (at < kTruncCap)
+								s_trunc[at] = make_uint2(k, k);
+						}
 						u++;
 					}
 					wg_sync();
 				}
-				if (relisted != kNone && !s_dflag2) {
+				if (relisted != kNone) {
 					for (uint32_t i = t; i < nsel; i += blockDim.x)
 						glist[relisted + i] = sel[i];
 					relisted += nsel;
-				} else {
-					relisted = kNone;
 				}
 			} else {
 				relisted = kNone;
@@ -3095,10 +3211,20 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			__syncthreads();
 			{
 				const uint32_t ntr = s_ntrunc < kTruncCap ? s_ntrunc : kTruncCap;
-				if (ntr) {
-					truncate_groups(table, state, reqc, undo, chain_logs, s_trunc, ntr, s_tm1, lo_idx, total);
-					relisted = kNone;                   // (their members beyond the cut are pending again: gathered anew)
+				if (t == 0) {
+					s_loose = s_ntrunc > kTruncCap ? 1u : 0u;   // (not all noted: the gather looks at every shadow's leader)
+					s_revived = 0u;
 				}
+				__syncthreads();
+				if (ntr) {
+					// (their members beyond the cut are pending again: appended to the next work list)
+					truncate_groups(table, state, reqc, undo, chain_logs, s_trunc, ntr, s_tm1, lo_idx, total,
+							relisted != kNone ? glist + relisted : nullptr, &s_revived);
+					if (relisted != kNone)
+						relisted += s_revived;
+				}
+				if (s_loose)
+					relisted = kNone;
 			}
 			if (u)
 				atomicAdd(&s_undone, u);
@@ -3115,7 +3241,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		}
 		__syncthreads();
 		if (relisted == kNone)
-			gather_pending(state, undo, reqc, glist, &s_n, lo_idx, total, 0u, 1u);
+			gather_pending(state, undo, reqc, glist, &s_n, lo_idx, total, 0u, 1u, s_loose != 0u);
 		else if (t == 0)
 			s_n = relisted;
 		wg_sync();
