@@ -2070,6 +2070,65 @@ __device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom
 	return reqc[w].x == r.sig ? 1 : 0;
 }
 
+// The same election inside ONE work-group (in-group rounds), per ENTRY instead of per bucket: a hash
+// table in LDS keyed by {bucket, slot of the duplicate}, the value the highest index entered.  Every
+// key of a bucket with pending duplicates is settled in one round -- the per-bucket word settles one
+// key per round, and a bucket that holds two hot keys of a Zipf batch sends four rounds' worth of
+// requests round the loop.  (A request that finds no slot in two probes stays tagged DUPW: next round.)
+constexpr uint32_t kElectSlots = 1024;       // (keys and values share the 8 KB of the replay's region bytes)
+__device__ __forceinline__ void elect_entry_lds(uint32_t *etb, uint32_t *etv, uint32_t *table, const DevGeom &g,
+		const unsigned long long *owner, const uint4 *reqc, uint8_t *state, uint32_t idx, uint32_t bar)
+{
+	if (state[idx] != ST_DUPW || idx >= bar)
+		return;
+	const uint4 rc = reqc[idx];
+	const uint32_t P = rc.y & g.hash_mask;
+	const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
+	const uint8_t so = state[o];
+	if (so != ST_DUPW && so != ST_DUPW_OK)
+		return;
+	uint4 lo, hi;
+	load_sig_row<true>(table, P, lo, hi);
+	const uint32_t m = eq_mask(lo, hi, rc.x);
+	if (!m)
+		return;                                     // (cannot happen: the duplicate was stable)
+	const uint32_t key = (P << 3) | ((uint32_t)__ffs((int)m) - 1u);
+	uint32_t slot = (key * 2654435761u) >> 22;
+	for (int probe = 0; probe < 2; probe++) {
+		const uint32_t old = atomicCAS(&etb[slot], kNone, key);
+		if (old == kNone || old == key) {
+			atomicMax(&etv[slot], idx);
+			state[idx] = ST_DUPW_OK;
+			return;
+		}
+		slot = (slot + 1u) & (kElectSlots - 1u);
+	}
+}
+
+// commit of a request tagged DUPW_OK by elect_entry_lds: the entry's highest index writes, the
+// others' writes are dead (same bucket and slot: the same key).  1 = done, 0 = try again
+__device__ __forceinline__ int commit_entry_lds(const uint32_t *etb, const uint32_t *etv, uint32_t *table,
+		const Req &r, uint32_t P, uint32_t idx)
+{
+	uint4 lo, hi;
+	load_sig_row<true>(table, P, lo, hi);
+	const uint32_t m = eq_mask(lo, hi, r.sig);
+	if (!m)
+		return 0;
+	const uint32_t sl = (uint32_t)__ffs((int)m) - 1u;
+	const uint32_t key = (P << 3) | sl;
+	uint32_t slot = (key * 2654435761u) >> 22;
+	for (int probe = 0; probe < 2; probe++) {
+		if (etb[slot] == key) {
+			if (etv[slot] == idx)
+				table[loc_word(P, sl)] = r.loc;
+			return 1;
+		}
+		slot = (slot + 1u) & (kElectSlots - 1u);
+	}
+	return 0;
+}
+
 // Reservation rounds inside the tail work-group over keys[0..m) (kNone = done).
 // Same rule as the grid-wide rounds, with decide-then-commit separated by
 // work-group barriers.  A region whose lowest pending request is itself the
@@ -2081,11 +2140,11 @@ template <Op OP>
 __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint32_t *table, unsigned long long *owner,
 		unsigned long long *cnt, unsigned long long *altmin, const uint4 *reqc, uint8_t *state, uint32_t *keys, uint32_t m,
 		uint32_t *s_rbar, uint32_t *s_rmin, uint32_t *s_below, uint32_t *s_progress, uint32_t *s_par, uint32_t *s_left,
-		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used, const Tv &tv, uint32_t stamp_skip)
+		uint32_t *s_dupw, int max_rounds, uint32_t *rounds_used, const Tv &tv, uint32_t stamp_skip, uint32_t *etb)
 {
 	const uint32_t t = threadIdx.x;
 	const unsigned long long stamp0 = ctl->stamp_base + 2 + stamp_skip;   // (stamps earlier calls of this launch used)
-	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
+	uint32_t *etv = etb + kElectSlots;          // the duplicates' election (elect_entry_lds)
 	uint32_t left = m, recent = 0;
 	for (int round = 0; round < max_rounds && left != 0; round++) {
 		*rounds_used = (uint32_t)round + 1u;
@@ -2205,13 +2264,16 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			wg_sync();
 			// the duplicate writers below the round's barrier elect the last one per bucket
 			if (*s_dupw) {
-				for (uint32_t base = 0; base < m; base += blockDim.x) {
-					const uint32_t i = base + t;
-					const uint32_t idx = i < m ? keys[i] : kNone;
-					const bool live = idx != kNone;
-					const uint32_t P = live ? reqc[idx].y & g.hash_mask : 0u;
-					elect_last_writer(g, owner, emax, reqc, state, live ? idx : 0u, P, s_rbar[P >> g.region_shift],
-							stamp, live);
+				for (uint32_t q = t; q < kElectSlots; q += blockDim.x) {
+					etb[q] = kNone;
+					etv[q] = 0u;
+				}
+				__syncthreads();
+				for (uint32_t i = t; i < m; i += blockDim.x) {
+					const uint32_t idx = keys[i];
+					if (idx != kNone)
+						elect_entry_lds(etb, etv, table, g, owner, reqc, state, idx,
+								s_rbar[(reqc[idx].y & g.hash_mask) >> g.region_shift]);
 				}
 				wg_sync();
 			}
@@ -2252,7 +2314,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 						state[idx] = ST_TAIL;           // an earlier chain took one of its buckets over
 					settled = true;
 				} else if (st == ST_DUPW_OK) {
-					done = commit_last_writer(table, g, emax, reqc, r, P, idx) != 0;
+					done = commit_entry_lds(etb, etv, table, r, P, idx) != 0;
 					if (!done)
 						state[idx] = ST_TAIL;
 					settled = true;
@@ -2946,7 +3008,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		int dbg_path)
 {
 	__shared__ __align__(16) uint32_t lkeys[kSortCap];
-	__shared__ uint8_t lreg[kSortCap];          // region of a listed request (in-order replay)
+	__shared__ __align__(16) uint8_t lreg[kSortCap];    // region of a listed request (in-order replay); in-group rounds: the duplicates' election
+	static_assert(2u * kElectSlots * sizeof(uint32_t) <= (size_t)kSortCap, "the election table lives in lreg");
 	__shared__ uint32_t s_thr[kMaxRegions];     // roll-back thresholds when a violation takes a whole region suffix
 	__shared__ uint32_t s_dflag, s_nsel, s_ntrunc;
 	__shared__ uint32_t s_loose, s_revived;
@@ -3070,7 +3133,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				used = 0;
 				wg_sync();
 				left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, lkeys, m2, s_rbar, s_rmin, s_below, &s_progress,
-						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total);
+						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total, reinterpret_cast<uint32_t *>(lreg));
 			}
 		} else {
 			// work list: LDS when it fits, else the global list it was gathered into
@@ -3087,7 +3150,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			wg_sync();
 			// a handful of requests: the in-order replay is done before a round would be
 			left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
-					&s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &used, tv, rounds_total);
+					&s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &used, tv, rounds_total,
+					reinterpret_cast<uint32_t *>(lreg));
 		}
 		rounds_total += used;
 		MKV_PHASE(4);
