@@ -77,6 +77,7 @@ constexpr uint32_t kMinRoundProgress = 24;   // in-work-group round: ~4 us again
 constexpr uint32_t kGridHandover = 1024;  // grid-wide rounds hand a list this short over to work-group 0's in-group rounds
 constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with a long list
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
+constexpr uint32_t kTlCap = 1024;   // requests the grid-wide rounds list for the tail themselves (beyond: the tail scans the tags)
 constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished requests in order without trying rounds
 constexpr int kTailAloneSpan = 131072; // ... or beyond this many request tags to scan
 constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
@@ -160,6 +161,8 @@ struct Ctl {
 	uint32_t overflow;
 	uint32_t any_loser;              // plain flags, set by whoever produces such work
 	uint32_t any_tail;
+	uint32_t tl_n;                   // requests rounds 1 and 2 have left to the tail, counted; the first kTlCap of them
+	uint32_t tl[1024];               // listed: a tail with few to do need not look for them (tail_list_add)
 	uint32_t loose;                  // round 2: a follower at the head of its bucket did not get to lead -- its
 	                                 // shadows are pending requests (the tail's first gather looks for them)
 	uint32_t first_hard;
@@ -1148,6 +1151,29 @@ __device__ __forceinline__ bool round_commit_used(const uint8_t *state, const ui
 // to the tail -- still registered, so that nothing later passes it on its own buckets.
 // No request waits for a request it shares no bucket with: an order violation between a
 // pending chain and something committed here is found when that chain walks (tail).
+// A request the grid-wide rounds leave to the tail is noted in a short list in the control block
+// (one atomic per wave that has any).  The usual pass leaves a handful: the tail then starts on them
+// at once instead of scanning the pass's tags for them with all its work-groups (5 - 7 us of a
+// launch that takes 20).  Once the count is over the list's capacity nobody adds any more -- the
+// tail sees the count and gathers by the tags as before.  Every lane of the wave calls this.
+__device__ __forceinline__ void tail_list_add(Ctl *ctl, uint32_t idx, bool add)
+{
+	const unsigned long long m = __ballot(add);
+	if (!m)
+		return;
+	const uint32_t lane = threadIdx.x & 63u;
+	const int first = __ffsll((long long)m) - 1;
+	uint32_t base = kNone;
+	if ((int)lane == first && ld_agent32(&ctl->tl_n) <= kTlCap)
+		base = atomicAdd(&ctl->tl_n, (uint32_t)__popcll(m));
+	base = __shfl(base, first);
+	if (add && base != kNone) {
+		const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+		if (at < kTlCap)
+			ctl->tl[at] = idx;
+	}
+}
+
 template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
@@ -1326,6 +1352,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 						ctl->any_tail = 1u;
 				}
 			}
+			if (ROUND == 2)
+				tail_list_add(ctl, idx, lose && !shadow);
 			base += span;
 			more = base < count && base >= start;
 		}
@@ -1430,6 +1458,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					atomicAdd(&ctl->hard_tail, 1u);
 				}
 			}
+			tail_list_add(ctl, idx, to_tail);
 		}
 		if (!more)
 			break;
@@ -3026,6 +3055,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	const uint32_t total_all = ctl->total;
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
 	const uint32_t carry_in = ctl->carry_lo;
+	// what the grid-wide rounds left, listed by themselves (tail_list_add) -- unless they left more than
+	// the list holds, shadows without a leader are about (not listed), or the call runs in several passes
+	const uint32_t tln = ctl->tl_n;
+	const bool listed = first_chunk && last_chunk && carry_in >= lo_idx && tln <= kTlCap && ctl->loose == 0u;
 	if (carry_in < lo_idx)
 		lo_idx = carry_in;                        // this pass also covered the carried requests
 	const bool work_left = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
@@ -3053,13 +3086,21 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__syncthreads();
 	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
 	const uint32_t pending_est = span > s_done12 ? span - s_done12 : 0u;
-	const bool use_helpers = nwg > 1u && (pending_est > (uint32_t)kTailAloneMax || span > (uint32_t)kTailAloneSpan);
+	const bool use_helpers = !listed && nwg > 1u && (pending_est > (uint32_t)kTailAloneMax || span > (uint32_t)kTailAloneSpan);
 			// (a long tag range is worth sharing even if little is left in it)
 	if (wg != 0 && (!work_left || !use_helpers))
 		return;
 	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
 	bool grid_mode = false;
-	if (work_left) {
+	if (work_left && listed) {
+		MKV_PHASE(0);
+		for (uint32_t i = t; i < tln; i += blockDim.x)
+			glist[i] = ctl->tl[i];
+		if (t == 0)
+			s_n = tln;
+		MKV_PHASE(6);
+		wg_sync();
+	} else if (work_left) {
 		MKV_PHASE(0);
 		gather_pending(state, undo, reqc, glist, &ctl->glist_n, lo_idx, total, wg, nwg_eff, ctl->loose != 0u);
 		MKV_PHASE(6);
@@ -3374,6 +3415,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
 		ctl->any_tail = 0;
+		ctl->tl_n = 0;
 		ctl->any_hard = 0;
 		ctl->first_hard = kNone;
 		ctl->total = 0;
@@ -3396,6 +3438,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->total = 0;
 		ctl->overflow = 0;
 		ctl->any_loser = ctl->any_tail = 0;
+		ctl->tl_n = 0;
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k] = ctl->committed[1][k] = 0;
 		ctl->first_hard = kNone;

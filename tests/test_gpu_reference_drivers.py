@@ -39,7 +39,7 @@ def test_reference_insert_test_runs_clean(elems, threads):
     p1 = re.findall(r"not found insertion", out)
     p2 = re.findall(r"(?<!not )found insertion", out)
     # rand() may produce signature 0 (the empty marker) about once per 2^31 draws: allow a stray line
-    assert len(p1) <= 2 and len(p2) <= 2, (len(p1), len(p2), out[-1500:])
+    assert len(p1) <= 1 and len(p2) <= 1, (len(p1), len(p2), out[-1500:])
     speeds = [float(x) for x in re.findall(r"speed is ([0-9.]+) Mops", out)]
     assert speeds and min(speeds) > 0
 

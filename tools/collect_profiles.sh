@@ -21,6 +21,7 @@ run() { # name, rocprof args...
 BENCH_ARGS=("$@")
 run stats --kernel-trace --stats
 BENCH_ARGS=("$@" --no-cpu --no-pcie)
+if [ "${PMC:-1}" = "0" ]; then tail -1 $raw/stats.json | cut -c1-300; exit 0; fi   # PMC=0: the stats run only
 run pmc_fetch --kernel-trace --pmc FETCH_SIZE
 run pmc_write --kernel-trace --pmc WRITE_SIZE
 run pmc_l2 --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum

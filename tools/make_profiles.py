@@ -41,7 +41,7 @@ def main():
     raw = os.path.join(ROOT, "gpurun_out", "profiles_raw", tag)
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
-    dom = "k_search_mark" if "get100" not in key else "k_search<"
+    dom = "k_search_slots_mark" if "sharded" in tag else ("k_search_mark" if "get100" not in key else "k_search<")
     # --- kernel stats summary of the command as run
     f = find(raw, "stats", "kernel_stats.csv")
     rows = list(csv.DictReader(open(f)))
