@@ -124,9 +124,18 @@ extern "C" int mkv_pipe_create(mkv_pipe **out, const mkv_geom_t *geom, bucket_t 
 	p->max_set = max_set;
 	p->nblk = num_blks;
 	p->depth = depth;
-	PIPE_HIP(p, hipStreamCreateWithFlags(&p->s_in, hipStreamNonBlocking));
+	// The runtime multiplexes streams over a handful of hardware queues (four by default), least
+	// loaded first -- how many streams the host has made before decides whether two of these three
+	// end up on one queue, and a copy-in that shares a queue with the cycles' kernels runs in turn
+	// with them instead of beside them (258 instead of 190 us per 2^20-request step, measured when
+	// the benchmark's stream count changed; GPU_MAX_HW_QUEUES=6 restored it).  The copy streams are
+	// therefore made with the highest priority: queues are pooled per priority, so they never share
+	// one with the compute stream (nor with each other: made one after the other in their pool).
+	int prio_least = 0, prio_greatest = 0;
+	PIPE_HIP(p, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+	PIPE_HIP(p, hipStreamCreateWithPriority(&p->s_in, hipStreamNonBlocking, prio_greatest));
 	PIPE_HIP(p, hipStreamCreateWithFlags(&p->s_comp, hipStreamNonBlocking));
-	PIPE_HIP(p, hipStreamCreateWithFlags(&p->s_out, hipStreamNonBlocking));
+	PIPE_HIP(p, hipStreamCreateWithPriority(&p->s_out, hipStreamNonBlocking, prio_greatest));
 	p->hdr_bytes = ((size_t)num_blks * (sizeof(ielem_t *) + sizeof(int)) + 63) & ~(size_t)63;
 	for (int k = 0; k < depth; k++) {
 		Slot &s = p->slot[k];

@@ -28,7 +28,10 @@ def find(raw, name, suffix):
 
 
 def short(n):
-    return n.split("(")[0].replace("void ", "")
+    s = n.split("(")[0].replace("void ", "")
+    if "k_round<" in n:          # rounds 1 and 2 are instances of one template: keep them apart
+        s += "round " + n.split("k_round<")[1].split(">")[0].split(",")[-1].strip() + ">"
+    return s
 
 
 def steps_of(rows, key="k_search_mark"):
