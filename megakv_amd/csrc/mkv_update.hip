@@ -77,7 +77,8 @@ constexpr uint32_t kMinRoundProgress = 24;   // in-work-group round: ~4 us again
 constexpr uint32_t kGridHandover = 1024;  // grid-wide rounds hand a list this short over to work-group 0's in-group rounds
 constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with a long list
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
-constexpr uint32_t kTlCap = 1024;   // requests the grid-wide rounds list for the tail themselves (beyond: the tail scans the tags)
+constexpr uint32_t kTlGroups = 512;  // the grid-wide rounds list what they leave to the tail: per work-group of a round
+constexpr uint32_t kTlPer = 8;       // ... this many entries (a work-group with more, or more work-groups: the tail scans the tags)
 constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished requests in order without trying rounds
 constexpr int kTailAloneSpan = 131072; // ... or beyond this many request tags to scan
 constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
@@ -161,8 +162,6 @@ struct Ctl {
 	uint32_t overflow;
 	uint32_t any_loser;              // plain flags, set by whoever produces such work
 	uint32_t any_tail;
-	uint32_t tl_n;                   // requests rounds 1 and 2 have left to the tail, counted; the first kTlCap of them
-	uint32_t tl[1024];               // listed: a tail with few to do need not look for them (tail_list_add)
 	uint32_t loose;                  // round 2: a follower at the head of its bucket did not get to lead -- its
 	                                 // shadows are pending requests (the tail's first gather looks for them)
 	uint32_t first_hard;
@@ -196,6 +195,14 @@ struct Ctl {
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
+	// Requests rounds 1 and 2 have left to the tail, listed per round and work-group (tail_list_add /
+	// tail_list_flush): a tail with few to do need not look for them.  No atomics on global memory: a
+	// first version with ONE counter (an atomic per wave that had any) made round 2 of a 50/50 Zipf-SET
+	// batch 23 -> 52 us with 650 entries -- returning atomics on one word, beside the words every wave
+	// reads when it starts.
+	uint32_t tl_groups[2];               // work-groups of round 1 / round 2 of this pass
+	uint32_t tl_cnt[2][kTlGroups];       // entries a work-group left (may exceed kTlPer: not all listed)
+	uint32_t tl[2][kTlGroups][kTlPer];
 };
 
 struct Req {
@@ -1151,26 +1158,31 @@ __device__ __forceinline__ bool round_commit_used(const uint8_t *state, const ui
 // to the tail -- still registered, so that nothing later passes it on its own buckets.
 // No request waits for a request it shares no bucket with: an order violation between a
 // pending chain and something committed here is found when that chain walks (tail).
-// A request the grid-wide rounds leave to the tail is noted in a short list in the control block
-// (one atomic per wave that has any).  The usual pass leaves a handful: the tail then starts on them
-// at once instead of scanning the pass's tags for them with all its work-groups (5 - 7 us of a
-// launch that takes 20).  Once the count is over the list's capacity nobody adds any more -- the
-// tail sees the count and gathers by the tags as before.  Every lane of the wave calls this.
-__device__ __forceinline__ void tail_list_add(Ctl *ctl, uint32_t idx, bool add)
+// A request the grid-wide rounds leave to the tail is noted by its work-group (LDS), which writes its
+// entries and their count into its own place in the control block when it is through.  The usual
+// pass leaves a handful: the tail then starts on them at once instead of scanning the pass's tags
+// for them with all its work-groups (5 - 7 us of a launch that takes 20).
+__device__ __forceinline__ void tail_list_add(uint32_t *s_tl, uint32_t *s_tln, uint32_t idx, bool add)
 {
-	const unsigned long long m = __ballot(add);
-	if (!m)
-		return;
-	const uint32_t lane = threadIdx.x & 63u;
-	const int first = __ffsll((long long)m) - 1;
-	uint32_t base = kNone;
-	if ((int)lane == first && ld_agent32(&ctl->tl_n) <= kTlCap)
-		base = atomicAdd(&ctl->tl_n, (uint32_t)__popcll(m));
-	base = __shfl(base, first);
-	if (add && base != kNone) {
-		const uint32_t at = base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-		if (at < kTlCap)
-			ctl->tl[at] = idx;
+	if (add) {
+		const uint32_t at = atomicAdd(s_tln, 1u);
+		if (at < kTlPer)
+			s_tl[at] = idx;
+	}
+}
+
+template <int ROUND>
+__device__ __forceinline__ void tail_list_flush(Ctl *ctl, const uint32_t *s_tl, const uint32_t *s_tln)
+{
+	__syncthreads();
+	if (blockIdx.x == 0 && threadIdx.x == 0)
+		ctl->tl_groups[ROUND - 1] = gridDim.x;
+	if (blockIdx.x < kTlGroups) {
+		const uint32_t n = *s_tln;
+		if (threadIdx.x < kTlPer && threadIdx.x < n)
+			ctl->tl[ROUND - 1][blockIdx.x][threadIdx.x] = s_tl[threadIdx.x];
+		if (threadIdx.x == 0)
+			ctl->tl_cnt[ROUND - 1][blockIdx.x] = n;
 	}
 }
 
@@ -1231,9 +1243,11 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	fmax.tb = s_ftb + kRFold;
 	fmax.tc = nullptr;
 	fmax.tk = s_ftk + kRFold;
+	__shared__ uint32_t s_tl[kTlPer], s_tln;    // what this work-group leaves to the tail (tail_list_add)
 	if (threadIdx.x == 0) {
 		s_qn = 0u;
 		s_fused = 0u;
+		s_tln = 0u;
 	}
 	if (ROUND == 1) {
 		for (uint32_t q = threadIdx.x; q < 2u * kRFold; q += blockDim.x) {
@@ -1353,7 +1367,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 				}
 			}
 			if (ROUND == 2)
-				tail_list_add(ctl, idx, lose && !shadow);
+				tail_list_add(s_tl, &s_tln, idx, lose && !shadow);
 			base += span;
 			more = base < count && base >= start;
 		}
@@ -1458,7 +1472,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 					atomicAdd(&ctl->hard_tail, 1u);
 				}
 			}
-			tail_list_add(ctl, idx, to_tail);
+			tail_list_add(s_tl, &s_tln, idx, to_tail);
 		}
 		if (!more)
 			break;
@@ -1468,6 +1482,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 		__syncthreads();
 	}
 	count_add(ctl->committed[ROUND - 1], ndone);
+	tail_list_flush<ROUND>(ctl, s_tl, &s_tln);
 }
 
 // ---- order validation of eviction chains that run late ------------------------------
@@ -3055,10 +3070,35 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	const uint32_t total_all = ctl->total;
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
 	const uint32_t carry_in = ctl->carry_lo;
-	// what the grid-wide rounds left, listed by themselves (tail_list_add) -- unless they left more than
-	// the list holds, shadows without a leader are about (not listed), or the call runs in several passes
-	const uint32_t tln = ctl->tl_n;
-	const bool listed = first_chunk && last_chunk && carry_in >= lo_idx && tln <= kTlCap && ctl->loose == 0u;
+	// what the grid-wide rounds left, listed by themselves (tail_list_add) -- unless a work-group left
+	// more than its place holds, shadows without a leader are about (not listed), or the call runs in
+	// several passes.  Every work-group of this launch reads the counts and decides alike.
+	static_assert(kTailThreads == 2 * (int)kTlGroups, "a lane of the tail's first work-group per round and work-group of the rounds");
+	__shared__ uint32_t s_tl_total, s_tl_over;
+	if (t == 0) {
+		s_tl_total = 0u;
+		s_tl_over = 0u;
+	}
+	__syncthreads();
+	const bool list_ok = first_chunk && last_chunk && carry_in >= lo_idx && ctl->loose == 0u && ctl->any_tail != 0u;
+	const uint32_t tl_g1 = list_ok ? ctl->tl_groups[0] : 0u;
+	const uint32_t tl_g2 = list_ok && ctl->any_loser != 0u ? ctl->tl_groups[1] : 0u;    // (round 2 leaves at once without losers)
+	uint32_t my_cnt = 0, my_base = 0;
+	const uint32_t my_round = t < kTlGroups ? 0u : 1u, my_wg = t & (kTlGroups - 1u);
+	if (list_ok) {
+		if (tl_g1 > kTlGroups || tl_g2 > kTlGroups) {
+			s_tl_over = 1u;
+		} else if (my_wg < (my_round ? tl_g2 : tl_g1)) {
+			my_cnt = ctl->tl_cnt[my_round][my_wg];
+			if (my_cnt > kTlPer)
+				s_tl_over = 1u;
+			else if (my_cnt)
+				my_base = atomicAdd(&s_tl_total, my_cnt);
+		}
+	}
+	__syncthreads();
+	const bool listed = list_ok && s_tl_over == 0u;
+	const uint32_t tln = s_tl_total;
 	if (carry_in < lo_idx)
 		lo_idx = carry_in;                        // this pass also covered the carried requests
 	const bool work_left = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
@@ -3094,8 +3134,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	bool grid_mode = false;
 	if (work_left && listed) {
 		MKV_PHASE(0);
-		for (uint32_t i = t; i < tln; i += blockDim.x)
-			glist[i] = ctl->tl[i];
+		for (uint32_t k = 0; k < my_cnt; k++)
+			glist[my_base + k] = ctl->tl[my_round][my_wg][k];
 		if (t == 0)
 			s_n = tln;
 		MKV_PHASE(6);
@@ -3415,7 +3455,6 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		ctl->chain_ok = 0;
 		ctl->any_loser = 0;
 		ctl->any_tail = 0;
-		ctl->tl_n = 0;
 		ctl->any_hard = 0;
 		ctl->first_hard = kNone;
 		ctl->total = 0;
@@ -3438,7 +3477,6 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->total = 0;
 		ctl->overflow = 0;
 		ctl->any_loser = ctl->any_tail = 0;
-		ctl->tl_n = 0;
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k] = ctl->committed[1][k] = 0;
 		ctl->first_hard = kNone;
