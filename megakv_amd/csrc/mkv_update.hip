@@ -19,8 +19,10 @@
 // {round stamp, canonical index}; stamps make stale entries lose, the table is
 // never cleared), committed optimistically:
 //
-//   K1 mark     every request registers on P and A (two atomics) and is copied
-//               into a 16-byte request cache.  A cuckoo request that looks hard
+//   K1 mark     every request registers on P -- and on A unless P has room to spare (a
+//               new key with two free slots in P registers once; its late use of A is
+//               checked like a chain's step) -- and is copied into a 16-byte request
+//               cache.  A cuckoo request that looks hard
 //               in the table as it stands also registers on the buckets its chain
 //               would go on to (read-only walk): later requests of the batch on
 //               those buckets then line up behind it.
@@ -29,7 +31,11 @@
 //               request runs its chain if every further bucket is its own or
 //               nobody's.  Losers re-register for round 2.  A hard request whose
 //               chain meets somebody else is left to the tail -- nobody waits for it.
-//   K3 round 2  the same over the losers, who registered in a second owner table.
+//               Losers whose bucket's lowest registrant holds the SAME key (followers)
+//               elect the last of them: only its location survives.
+//   K3 round 2  the same over the losers, who registered in a second owner table.  The
+//               first follower of a key commits the last one's location for all of
+//               them (a group; the others are its shadows).
 //   K4 tail     one launch of 32 work-groups of 1024 lanes (the helpers leave at
 //               once unless there is much to scan).  Reservation rounds over what
 //               is left (register / decide / commit with work-group barriers; the
@@ -39,10 +45,14 @@
 //
 // Rounds 1 and 2 commit without asking whether an EARLIER pending request will
 // turn hard and walk its chain into the same bucket.  That is checked when the
-// chain walks (tail): a bucket with a later commit on its list is an order
-// violation, and exactly the commits involved -- those later ones on that
-// bucket, and what ran after them on their buckets -- are taken back from their
-// logs and run again behind the chain (select_from / take_back).
+// chain walks (tail): WHO can have committed on a bucket is in the two owner
+// tables (its lowest registrant of either round: two candidates, two loads);
+// a later commit there is an order violation, and exactly the commits involved
+// -- those later ones on that bucket, and what ran after them on their buckets
+// -- are taken back from their logs and run again behind the chain
+// (select_from / take_back).  A group's commit counts with the index of its last
+// member; it is never taken back for a request above its leader but cut there
+// (truncate_groups).
 //
 // "Holds a duplicate" only counts as "cannot turn hard" while nothing can evict
 // that duplicate before the request's turn: never for signature 0 (which matches
