@@ -2131,11 +2131,10 @@ __device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom
 // requests round the loop.  (A request that finds no slot in two probes stays tagged DUPW: next round.)
 constexpr uint32_t kElectSlots = 1024;       // (keys and values share the 8 KB of the replay's region bytes)
 __device__ __forceinline__ void elect_entry_lds(uint32_t *etb, uint32_t *etv, uint32_t *table, const DevGeom &g,
-		const unsigned long long *owner, const uint4 *reqc, uint8_t *state, uint32_t idx, uint32_t bar)
+		const unsigned long long *owner, const uint4 &rc, uint8_t *state, uint32_t idx, uint32_t bar)
 {
 	if (state[idx] != ST_DUPW || idx >= bar)
 		return;
-	const uint4 rc = reqc[idx];
 	const uint32_t P = rc.y & g.hash_mask;
 	const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
 	const uint8_t so = state[o];
@@ -2200,6 +2199,14 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 	const unsigned long long stamp0 = ctl->stamp_base + 2 + stamp_skip;   // (stamps earlier calls of this launch used)
 	uint32_t *etv = etb + kElectSlots;          // the duplicates' election (elect_entry_lds)
 	uint32_t left = m, recent = 0;
+	// A list of at most one request per lane (the usual case): the lane keeps its request's cache
+	// entry in registers over the phases and rounds -- every phase otherwise begins with that load,
+	// one dependent round trip of the three or four a phase consists of.  (Only the lane itself
+	// writes the entry's flag word in here; list positions do not move.)
+	const bool one = m <= blockDim.x;
+	uint4 rc0 = make_uint4(0u, 0u, 0u, 0u);
+	if (one && max_rounds > 0 && t < m && keys[t] != kNone)
+		rc0 = reqc[keys[t]];
 	for (int round = 0; round < max_rounds && left != 0; round++) {
 		*rounds_used = (uint32_t)round + 1u;
 		const unsigned long long stamp = stamp0 + (unsigned)round;
@@ -2220,7 +2227,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint32_t i = base + t;
 			const uint32_t idx = i < m ? keys[i] : kNone;
 			const bool live = idx != kNone;
-			const uint4 rc = live ? reqc[idx] : make_uint4(0u, 0u, 0u, 0u);
+			const uint4 rc = !live ? make_uint4(0u, 0u, 0u, 0u) : one ? rc0 : reqc[idx];
 			const uint32_t P = rc.y & g.hash_mask;
 			const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 			const bool reg = live && state[idx] != ST_DEFER;      // (a deferred request sits this round out)
@@ -2240,7 +2247,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				const uint32_t idx = keys[i];
 				if (idx == kNone)
 					continue;
-				const uint4 rc = reqc[idx];
+				const uint4 rc = one ? rc0 : reqc[idx];
 				const uint32_t P = rc.y & g.hash_mask;
 				const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 				const uint32_t region = P >> g.region_shift;
@@ -2269,6 +2276,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 						continue;
 					}
 					const_cast<uint4 *>(reqc)[idx].w = (rc.w & ~kLazyBit) | kCheckedBit;
+					rc0.w = one ? (rc.w & ~kLazyBit) | kCheckedBit : rc0.w;
 				}
 				uint4 lo, hi;
 				load_sig_row<true>(table, P, lo, hi);
@@ -2325,9 +2333,11 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 				__syncthreads();
 				for (uint32_t i = t; i < m; i += blockDim.x) {
 					const uint32_t idx = keys[i];
-					if (idx != kNone)
-						elect_entry_lds(etb, etv, table, g, owner, reqc, state, idx,
-								s_rbar[(reqc[idx].y & g.hash_mask) >> g.region_shift]);
+					if (idx != kNone) {
+						const uint4 rc = one ? rc0 : reqc[idx];
+						elect_entry_lds(etb, etv, table, g, owner, rc, state, idx,
+								s_rbar[(rc.y & g.hash_mask) >> g.region_shift]);
+					}
 				}
 				wg_sync();
 			}
@@ -2338,7 +2348,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			const uint32_t idx = keys[i];
 			if (idx == kNone)
 				continue;
-			const Req r = req_of(reqc[idx]);
+			const Req r = req_of(one ? rc0 : reqc[idx]);
 			const uint32_t P = r.hash & g.hash_mask;
 			const uint32_t A = alt_bucket(r.hash, r.sig, g.hash_mask, g.blk_mask);
 			const unsigned long long key = owner_key(stamp, idx);
@@ -2394,7 +2404,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			wg_sync();
 			if (my_bar != kNone) {
 				const uint32_t idx = keys[my_bar];
-				const Req r = req_of(reqc[idx]);
+				const Req r = req_of(one ? rc0 : reqc[idx]);
 				const uint32_t region = (r.hash & g.hash_mask) >> g.region_shift;
 				if (s_below[region] == 0u && apply_serial_checked<OP>(table, g, r, idx, tv) == 0) {
 					state[idx] = ST_DONE;
