@@ -121,7 +121,9 @@ Tuning &tuning()
 		if (v.req_cap < 1024) v.req_cap = 1024;
 		v.debug_skip = 0;
 		v.debug_first_stamp = 0;
-		v.round_blocks = 512;
+		s = getenv("MKV_ROUND_BLOCKS");
+		v.round_blocks = s ? atoi(s) : 512;
+		if (v.round_blocks < 1 || v.round_blocks > 65536) v.round_blocks = 512;
 		v.grid_progress = 96;
 		v.mark_alone_blocks = 1024;
 		s = getenv("MKV_MARK_BLOCKS");
