@@ -451,8 +451,22 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	}
 	for (int k = 0; k < (e->sched_cs ? e->nsvc : 0); k++)
 		SH_HIP(e, hipStreamCreateWithFlags(&e->svc[k], hipStreamNonBlocking));
-	if (e->one_compute_stream)
-		SH_HIP(e, hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+	if (e->one_compute_stream) {
+		// The local phases are the critical path.  Their stream gets the highest priority: the
+		// runtime pools its hardware queues per priority, so this stream never shares a queue with a
+		// service stream (which would make pack, exchange and un-pack take turns with the local
+		// kernels instead of running beside them) however many streams the host and RCCL have made
+		// before -- on a one-GPU box the counts happen to fall right, with torch.distributed's own
+		// streams in the process they need not (the host-buffer pipeline lost 35 % that way,
+		// mkv_pipe.hip).  MKV_SHARD_CPRIO=0: normal priority.
+		const char *v = getenv("MKV_SHARD_CPRIO");
+		int prio_least = 0, prio_greatest = 0;
+		SH_HIP(e, hipDeviceGetStreamPriorityRange(&prio_least, &prio_greatest));
+		if (v && atoi(v) == 0)
+			SH_HIP(e, hipStreamCreateWithFlags(&e->cstream, hipStreamNonBlocking));
+		else
+			SH_HIP(e, hipStreamCreateWithPriority(&e->cstream, hipStreamNonBlocking, prio_greatest));
+	}
 	SH_HIP(e, hipEventCreateWithFlags(&e->ev_cdone, hipEventDisableTiming));
 	if (cap_set && e->one_compute_stream) {
 		const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, e->cstream);
