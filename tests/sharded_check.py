@@ -20,28 +20,59 @@ def free_port():
         return s.getsockname()[1]
 
 
-def run_and_check(world, mode, mem_p_local, scheme, seed, steps=4, timeout=600):
-    port = free_port()
-    with tempfile.TemporaryDirectory() as d:
-        env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
-        # worker output goes to files: a full pipe on one rank would stall every rank at the next collective
+def launch_ranks(world, argv_of, d, env, timeout):
+    """Starts the ranks (output to files: a full pipe on one rank would stall every rank at the next
+    collective) and waits for ALL of them together: a rank that dies takes the others down at once
+    with its log in the failure -- waiting for them one after the other would sit out the whole
+    time limit on a survivor blocked in a collective and report nothing of the rank that failed.
+    A run whose ranks never got together (the rendezvous port taken between choosing and binding it,
+    a rank that could not start) is started once more on another port."""
+    import time
+    for attempt in range(2):
+        port = free_port()
         logs = [open(os.path.join(d, f"rank{r}.log"), "w") for r in range(world)]
-        procs = [subprocess.Popen([sys.executable, "-m", "tests.sharded_worker", str(r), str(world), str(port),
-                                   mode, d, str(mem_p_local), str(scheme), str(seed)], cwd=ROOT, env=env,
-                                  stdout=logs[r], stderr=subprocess.STDOUT)
+        procs = [subprocess.Popen(argv_of(r, port), cwd=ROOT, env=env, stdout=logs[r], stderr=subprocess.STDOUT)
                  for r in range(world)]
+        t0 = time.time()
+        bad = None
         try:
-            for p in procs:
-                p.wait(timeout=timeout)
+            while True:
+                codes = [p.poll() for p in procs]
+                failed = [r for r, c in enumerate(codes) if c not in (None, 0)]
+                if failed:
+                    bad = failed[0]
+                    break
+                if all(c == 0 for c in codes):
+                    break
+                if time.time() - t0 > timeout:
+                    bad = -1
+                    break
+                time.sleep(0.05)
         finally:
             for p in procs:
                 if p.poll() is None:
                     p.kill()
+            for p in procs:
+                p.wait()
             for f in logs:
                 f.close()
-        for r, p in enumerate(procs):
-            tail = open(os.path.join(d, f"rank{r}.log")).read()[-3000:]
-            assert p.returncode == 0, f"rank {r} failed:\n{tail}"
+        if bad is None:
+            return
+        tails = {r: open(os.path.join(d, f"rank{r}.log")).read()[-3000:] for r in range(world)}
+        early = time.time() - t0 < 120 and not any(os.path.exists(os.path.join(d, f"rank{r}.npz")) for r in range(world))
+        if attempt == 0 and early and bad >= 0:
+            continue                    # (died before any rank produced anything: once more)
+        if bad < 0:
+            raise AssertionError(f"ranks still running after {timeout} s:\n" +
+                                 "\n".join(f"--- rank {r}\n{t[-800:]}" for r, t in tails.items()))
+        raise AssertionError(f"rank {bad} failed:\n{tails[bad]}")
+
+
+def run_and_check(world, mode, mem_p_local, scheme, seed, steps=4, timeout=600):
+    with tempfile.TemporaryDirectory() as d:
+        env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1")
+        launch_ranks(world, lambda r, port: [sys.executable, "-m", "tests.sharded_worker", str(r), str(world), str(port),
+                                             mode, d, str(mem_p_local), str(scheme), str(seed)], d, env, timeout)
         data = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
         k = world.bit_length() - 1
         og = O.geom(mem_p=mem_p_local + k, scheme=scheme)          # aggregate table, IBLOCK_P = 3
@@ -64,27 +95,11 @@ def run_and_check_zipf(world, mem_p_local, batch_log2, steps, timeout=900, schem
     Checked against ONE aggregate oracle table of MEM_P = mem_p_local + log2(world)."""
     import bench
     import workload as W
-    port = free_port()
     with tempfile.TemporaryDirectory() as d:
         env = dict(os.environ, PYTHONPATH=ROOT, MASTER_ADDR="127.0.0.1", MKV_ZIPF_BATCH_LOG2=str(batch_log2),
                    MKV_ZIPF_STEPS=str(steps))
-        logs = [open(os.path.join(d, f"rank{r}.log"), "w") for r in range(world)]
-        procs = [subprocess.Popen([sys.executable, "-m", "tests.sharded_worker", str(r), str(world), str(port),
-                                   "gpu-zipf", d, str(mem_p_local), str(scheme), "0"], cwd=ROOT, env=env,
-                                  stdout=logs[r], stderr=subprocess.STDOUT)
-                 for r in range(world)]
-        try:
-            for p in procs:
-                p.wait(timeout=timeout)
-        finally:
-            for p in procs:
-                if p.poll() is None:
-                    p.kill()
-            for f in logs:
-                f.close()
-        for r, p in enumerate(procs):
-            tail = open(os.path.join(d, f"rank{r}.log")).read()[-3000:]
-            assert p.returncode == 0, f"rank {r} failed:\n{tail}"
+        launch_ranks(world, lambda r, port: [sys.executable, "-m", "tests.sharded_worker", str(r), str(world), str(port),
+                                             "gpu-zipf", d, str(mem_p_local), str(scheme), "0"], d, env, timeout)
         data = [np.load(os.path.join(d, f"rank{r}.npz")) for r in range(world)]
     k = world.bit_length() - 1
     mem_p_agg = mem_p_local + k

@@ -166,4 +166,4 @@ def test_config4_eight_shards_on_one_gpu():
     exchange staged through host memory; RCCL needs a GPU per rank), two batches in flight,
     against ONE aggregate oracle table of MEM_P = 24 + 3."""
     from tests.sharded_check import run_and_check_zipf
-    run_and_check_zipf(world=8, mem_p_local=24, batch_log2=16, steps=4, timeout=900)
+    run_and_check_zipf(world=8, mem_p_local=24, batch_log2=16, steps=4, timeout=420)
