@@ -2131,10 +2131,32 @@ __device__ __forceinline__ int commit_last_writer(uint32_t *table, const DevGeom
 // requests round the loop.  (A request that finds no slot stays tagged DUPW: next round.)
 constexpr uint32_t kElectSlots = 1024;       // (keys and values share the 8 KB of the replay's region bytes)
 constexpr int kElectProbes = 16;             // (linear probing: with two probes one entry in twenty found no slot at 650 requests)
-__device__ __forceinline__ void elect_entry_lds(uint32_t *etb, uint32_t *etv, uint32_t *table, const DevGeom &g,
-		const unsigned long long *owner, const uint4 &rc, uint8_t *state, uint32_t idx, uint32_t *rbar)
+// the slot of entry {P, slot of the duplicate} in the election table, claimed if it is not there yet
+// (kNone: the request's signature is not in P -- cannot happen, the duplicate was stable -- or no
+// room in the table)
+__device__ __forceinline__ uint32_t elect_claim(uint32_t *etb, const uint32_t *table, uint32_t P, uint32_t sig)
 {
-	const uint32_t bar = *rbar;
+	uint4 lo, hi;
+	load_sig_row<true>(table, P, lo, hi);
+	const uint32_t m = eq_mask(lo, hi, sig);
+	if (!m)
+		return kNone;
+	const uint32_t key = (P << 3) | ((uint32_t)__ffs((int)m) - 1u);
+	uint32_t slot = (key * 2654435761u) >> 22;
+	for (int probe = 0; probe < kElectProbes; probe++) {
+		const uint32_t old = atomicCAS(&etb[slot], kNone, key);
+		if (old == kNone || old == key)
+			return slot;
+		slot = (slot + 1u) & (kElectSlots - 1u);
+	}
+	return kNone;
+}
+
+// (the region's barrier is final when this runs: every request entered is below it, so the entry's
+// writer commits in this round and the others' writes are dead in this round)
+__device__ __forceinline__ void elect_entry_lds(uint32_t *etb, uint32_t *etv, uint32_t *table, const DevGeom &g,
+		const unsigned long long *owner, const uint4 &rc, uint8_t *state, uint32_t idx, uint32_t bar)
+{
 	if (state[idx] != ST_DUPW || idx >= bar)
 		return;
 	const uint32_t P = rc.y & g.hash_mask;
@@ -2142,28 +2164,11 @@ __device__ __forceinline__ void elect_entry_lds(uint32_t *etb, uint32_t *etv, ui
 	const uint8_t so = state[o];
 	if (so != ST_DUPW && so != ST_DUPW_OK)
 		return;
-	uint4 lo, hi;
-	load_sig_row<true>(table, P, lo, hi);
-	const uint32_t m = eq_mask(lo, hi, rc.x);
-	if (!m) {                                       // (cannot happen: the duplicate was stable)
-		if (!(rc.w & kCheckedBit))
-			atomicMin(rbar, idx);
-		return;
-	}
-	const uint32_t key = (P << 3) | ((uint32_t)__ffs((int)m) - 1u);
-	uint32_t slot = (key * 2654435761u) >> 22;
-	for (int probe = 0; probe < kElectProbes; probe++) {
-		const uint32_t old = atomicCAS(&etb[slot], kNone, key);
-		if (old == kNone || old == key) {
-			atomicMax(&etv[slot], idx);
-			state[idx] = ST_DUPW_OK;
-			return;
-		}
-		slot = (slot + 1u) & (kElectSlots - 1u);
-	}
-	// (no slot: not through this round.  If it has not looked at A yet, nothing above it may commit.)
-	if (!(rc.w & kCheckedBit))
-		atomicMin(rbar, idx);
+	const uint32_t slot = elect_claim(etb, table, P, rc.x);
+	if (slot == kNone)
+		return;                                     // (a request that has not looked at A yet holds its slot already)
+	atomicMax(&etv[slot], idx);
+	state[idx] = ST_DUPW_OK;
 }
 
 // commit of a request tagged DUPW_OK by elect_entry_lds: the entry's highest index writes, the
@@ -2352,11 +2357,17 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 			if (*s_dupw) {
 				// Second pass of the check: a duplicate holder that has not looked at A yet and will NOT be
 				// through by the end of this round -- it is beyond its region's barrier as it stands now,
-				// or the head of its bucket is no duplicate writer, so it will not take part in the
-				// election -- looks now, and is the barrier of its region if it finds a later commit there:
-				// a pending request that has not looked must never see anything above it commit.  (One that
-				// is beyond a barrier set in THIS pass stays as it is: nothing at or above that barrier
-				// commits either.)
+				// the head of its bucket is no duplicate writer, or the election table has no room for its
+				// entry, so it will not take part in the election -- looks now, and is the barrier of its
+				// region if it finds a later commit there: a pending request that has not looked must never
+				// see anything above it commit.  (One that is beyond a barrier set in THIS pass stays as it
+				// is: nothing at or above that barrier commits either.  No barrier moves after this pass:
+				// whoever enters the election is below the final one.)
+				for (uint32_t q = t; q < kElectSlots; q += blockDim.x) {
+					etb[q] = kNone;
+					etv[q] = 0u;
+				}
+				__syncthreads();
 				for (uint32_t i = t; i < m; i += blockDim.x) {
 					const uint32_t idx = keys[i];
 					if (idx == kNone || state[idx] != ST_DUPW)
@@ -2368,8 +2379,10 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					const uint32_t A = alt_bucket(rc.y, rc.x, g.hash_mask, g.blk_mask);
 					const uint32_t region = P >> g.region_shift;
 					const uint32_t o = (uint32_t)(ld_agent(&owner[P]) & ((1ull << kIdxBits) - 1ull));
-					if (idx < s_rbar[region] && state[o] == ST_DUPW)
-						continue;                           // it takes part in the election: through this round
+					// (it takes part in the election -- its entry's slot in the table is claimed here and now,
+					// the election only has to find it -- and is through this round)
+					if (idx < s_rbar[region] && state[o] == ST_DUPW && elect_claim(etb, table, P, rc.x) != kNone)
+						continue;
 					if (A != P && conflict_on(tv, g, A, idx, rc.x, OP == OP_2CHOICE || (rc.w & kLazyBit) != 0u)) {
 						report_violation(tv, g, P, idx, A);
 						atomicMin(&s_rbar[region], idx);
@@ -2379,17 +2392,12 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					rc0.w = one ? (rc.w & ~kLazyBit) | kCheckedBit : rc0.w;
 				}
 				wg_sync();
-				for (uint32_t q = t; q < kElectSlots; q += blockDim.x) {
-					etb[q] = kNone;
-					etv[q] = 0u;
-				}
-				__syncthreads();
 				for (uint32_t i = t; i < m; i += blockDim.x) {
 					const uint32_t idx = keys[i];
 					if (idx != kNone) {
 						const uint4 rc = one ? rc0 : reqc[idx];
 						elect_entry_lds(etb, etv, table, g, owner, rc, state, idx,
-								&s_rbar[(rc.y & g.hash_mask) >> g.region_shift]);
+								s_rbar[(rc.y & g.hash_mask) >> g.region_shift]);
 					}
 				}
 				wg_sync();
