@@ -1528,7 +1528,7 @@ struct Tv {
 };
 constexpr uint32_t kTvViolation = 1u;
 
-// (debug builds, make EXTRA=-DMKV_TRACE: what the tail did, in the order it did it -- tools/fuzz_debug.py prints it)
+// (debug builds, make EXTRA=-DMKV_TRACE: what the tail did, in the order it did it -- tests/debug/fuzz_debug.py prints it)
 #ifdef MKV_TRACE
 constexpr uint32_t kTraceCap = 1u << 17;
 __device__ uint32_t g_trace[4u * kTraceCap + 4u];
@@ -4415,7 +4415,7 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	return MKV_OK;
 }
 
-// diagnostics (tools/streams_probe.py): what the workspace holds for request idx after the last
+// diagnostics (tests/debug/streams_probe.py): what the workspace holds for request idx after the last
 // pass -- out[0] = tag, out[1..4] = request cache {sig, hash, loc, flags}, out[5..8] = undo record
 extern "C" int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9])
 {

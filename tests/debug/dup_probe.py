@@ -3,7 +3,7 @@
 mkv_insert and mkv_cycle, one block or sixteen: which location ends up in the table?"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from megakv_amd import Geometry, HashIndex
 from oracle import oracle as O

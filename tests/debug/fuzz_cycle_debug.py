@@ -7,7 +7,7 @@ import sys
 import numpy as np
 import torch
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from megakv_amd import Geometry, HashIndex  # noqa: E402
 from megakv_amd.lib import load_library  # noqa: E402

@@ -3,7 +3,7 @@
 usage: streams_probe.py <nstreams> [tuning=value ...]"""
 import os, sys
 import numpy as np, torch
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import megakv_amd as M
 from megakv_amd.lib import load_library

@@ -1,8 +1,8 @@
 #!/bin/bash
 # groups: whole GPU suite, the probes, SET-updates workloads with and without groups, a longer campaign
 timeout 1500 python -m pytest tests -x -q -m gpu --deselect tests/test_gpu_fuzz.py 2>&1 | tail -5
-timeout 120 python tools/streams_probe.py 2>&1 | tail -3
-timeout 120 python tools/dup_probe.py 2>&1 | tail -6
+timeout 120 python tests/debug/streams_probe.py 2>&1 | tail -3
+timeout 120 python tests/debug/dup_probe.py 2>&1 | tail -6
 B="python bench.py --no-cpu --no-pcie --steps 20 --warmup 5"
 for dg in 1 0; do
   for w in "--workload zipf95 --sets upd" "--workload zipf50 --sets upd" "--workload zipf50 --sets upd --scheme 2choice" "--workload zipf95" "--workload zipf50"; do
