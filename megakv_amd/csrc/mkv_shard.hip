@@ -936,7 +936,23 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 // Everything is enqueued (no host synchronisation); the lanes start after what is queued
 // on `stream` and `stream` waits for them at the end.  timer (mkv_timer_*) brackets the
 // local search launch of every timer_every-th batch, slot = i / timer_every.
+static int shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
+		int timer_every);
+
+// Every way out of a failed run drains the device first: kernels and exchanges on the caller's
+// request and result buffers may still be in flight on the engine's streams.
 extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
+		int timer_every)
+{
+	const int rc = shard_run(e, nbatches, gets, n_get, sets, n_set, outs, stream, timer, timer_every);
+	if (rc != MKV_OK && e && e->comm)
+		(void)hipDeviceSynchronize();
+	return rc;
+}
+
+static int shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
 		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
 		int timer_every)
 {
