@@ -3789,6 +3789,16 @@ struct UpdateOrder {
 };
 static std::unordered_map<int, UpdateOrder> g_order;   // key: device
 
+// An update call enqueues several kernels that share the device's workspace, between order_updates
+// and updates_issued.  Host threads that update concurrently (each on its own stream) take turns
+// for that stretch -- microseconds of enqueueing; the kernels themselves are ordered by the event.
+// (The reference's scheduler issues from one thread, src/mega_scheduler.c:306-532; recursive: the
+// cycle calls the delete entry point.)
+static std::recursive_mutex g_call_mutex;
+struct CallGuard {
+	std::lock_guard<std::recursive_mutex> lock{g_call_mutex};
+};
+
 static int order_updates(hipStream_t stream)
 {
 	int dev = 0;
@@ -3934,6 +3944,7 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		return MKV_ETOOBIG;
 	if (hint > kMaxReqCap)
 		return MKV_ETOOBIG;
+	CallGuard call;
 	int rc = order_updates(stream);
 	if (rc != MKV_OK)
 		return rc;
@@ -4059,6 +4070,7 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *ta
 	hipStream_t s = (hipStream_t)stream;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
+	mkv::CallGuard call;
 	int rc = mkv::order_updates(s);
 	if (rc != MKV_OK)
 		return rc;
@@ -4100,6 +4112,7 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	hipStream_t s = (hipStream_t)stream;
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
+	mkv::CallGuard call;
 	int rc = mkv::order_updates(s);
 	if (rc != MKV_OK)
 		return rc;

@@ -182,3 +182,62 @@ def test_updates_of_one_table_from_several_streams_keep_issue_order():
             idx.insert_staged(ptrs, cnts, 1, stream=s, hint=len(e))
     torch.cuda.synchronize()
     assert np.array_equal(idx.table_numpy(), exp)
+
+
+def test_host_threads_updating_their_own_tables_share_the_workspace():
+    """Four host threads, each with a stream and a table of its own, insert and delete at the same time:
+    the device's one update workspace is shared, so the library lets the threads take turns for the
+    stretch in which a call enqueues its kernels (ctypes releases the GIL during the calls: the host
+    side really runs in parallel).  Every table equals the oracle's for its own calls."""
+    import threading
+    import torch
+    import megakv_amd as M
+    from oracle import oracle as O
+    nthreads, calls = 4, 16
+    g = M.Geometry(mem_p=18)
+    og = O.geom(mem_p=18)
+    idxs = [M.HashIndex(g) for _ in range(nthreads)]
+    streams = [torch.cuda.Stream() for _ in range(nthreads)]
+    plans, keep = [], [[] for _ in range(nthreads)]
+    for th in range(nthreads):
+        rng = np.random.default_rng(100 + th)
+        pool = rng.integers(1, 2**32, size=(9000, 3), dtype=np.uint64).astype(np.uint32)
+        plan = []
+        for call in range(calls):
+            e = pool[rng.integers(0, len(pool), size=6000)].copy()
+            e[:, 2] = rng.integers(1, 2**32, size=len(e), dtype=np.uint64)
+            plan.append(("delete" if call % 5 == 4 else "insert", np.ascontiguousarray(e)))
+        plans.append(plan)
+        for _, e in plan:                                   # staged before the threads start: only library calls race
+            t = torch.from_numpy(e.view(np.int32)).cuda()
+            keep[th].append((t, idxs[th].stage_blocks([t])))
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def work(th):
+        try:
+            start.wait()
+            for (op, e), (t, (ptrs, cnts, _)) in zip(plans[th], keep[th]):
+                if op == "delete":
+                    idxs[th].delete(t, stream=streams[th])
+                else:
+                    idxs[th].insert_staged(ptrs, cnts, 1, stream=streams[th], hint=len(e))
+        except Exception as ex:                             # noqa: BLE001
+            errors.append((th, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(th,)) for th in range(nthreads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for th in range(nthreads):
+        exp = O.new_table(og)
+        for op, e in plans[th]:
+            if op == "delete":
+                O.delete(og, exp, e)
+            else:
+                O.insert(og, exp, [e])
+        assert np.array_equal(idxs[th].table_numpy(), exp), f"thread {th}: table differs"
