@@ -75,6 +75,10 @@ def parse(argv=None):
     ap.add_argument("--comm", default="nccl", choices=["nccl", "staged"],
                     help="staged: gloo collectives through host memory, all ranks on cuda:0 -- only to exercise "
                          "the multi-rank flow of this script on a one-GPU box")
+    ap.add_argument("--strict-engine", action="store_true",
+                    help="N > 1: exit non-zero if the C shard engine cannot be set up or fails its warm-up check "
+                         "(default: report the phase that failed, fall back to the Python-driven step and tag the "
+                         'line "engine": "python-fallback")')
     ap.add_argument("--no-native", action="store_true",
                     help="sharded path: drive the step from Python/torch.distributed instead of the C engine")
     ap.add_argument("--no-pipeline", action="store_true",
@@ -240,6 +244,7 @@ def main():
                               StagedComm(dist) if args.comm == "staged" else NcclComm(dist),
                               cap_factor=slot_factor)
     native = False
+    engine_error = None               # why the C shard engine is not what ran (phase and message), if it is not
     if sharded and args.comm == "nccl" and not args.no_native and not args.no_pipeline:
         # the step as ONE library call per run (own RCCL communicator); all ranks agree, or all
         # fall back to the Python-driven step over torch.distributed
@@ -252,7 +257,9 @@ def main():
         try:
             engine.enable_native(dist)
         except Exception as ex:                                   # noqa: BLE001
-            print(f"[rank {rank}] native sharded engine unavailable, falling back: {ex}", file=sys.stderr)
+            engine_error = f"set-up: {ex}"
+            print(f"[rank {rank}] C shard engine FAILED during set-up (create / connect / first exchange): {ex}",
+                  file=sys.stderr, flush=True)
             ok = 0
         wd.cancel()
         flag = torch.tensor([ok], dtype=torch.int32, device=device)
@@ -261,6 +268,13 @@ def main():
             if engine.native is not None:
                 engine.native.close()
             engine.native = None
+            engine_error = engine_error or "set-up: another rank failed (see its message)"
+            if args.strict_engine:
+                print(f"[rank {rank}] --strict-engine: giving up ({engine_error})", file=sys.stderr, flush=True)
+                dist.destroy_process_group()
+                os._exit(21)
+            print(f"[rank {rank}] falling back to the Python-driven step over torch.distributed; the line will say "
+                  f'"engine": "python-fallback"', file=sys.stderr, flush=True)
         native = engine.native is not None
 
     # ---- pre-load: keys 1 .. P-1, loc = key, through the insert kernel ----------
@@ -324,7 +338,14 @@ def main():
                                 dtype=torch.int32, device=device)
             dist.all_reduce(good, op=dist.ReduceOp.MIN)
             if int(good.item()) == 0:
-                print(f"[rank {rank}] native sharded engine gave wrong results, falling back", file=sys.stderr)
+                engine_error = "warm-up check: GETs of pre-loaded keys did not all come back with their key (on some rank)"
+                print(f"[rank {rank}] C shard engine FAILED its warm-up check (hit rate of pre-loaded keys "
+                      f"{float((res0 == check_keys).mean()):.4f} on this rank)", file=sys.stderr, flush=True)
+                if args.strict_engine:
+                    dist.destroy_process_group()
+                    os._exit(22)
+                print(f"[rank {rank}] falling back to the Python-driven step; the line will say "
+                      f'"engine": "python-fallback"', file=sys.stderr, flush=True)
                 engine.native.close()
                 engine.native = None
                 native = False
@@ -497,6 +518,9 @@ def main():
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else
                        ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
+            "engine": ("single table (mkv_cycle)" if not sharded else "C shard engine (mkv_shard_run)" if native else
+                       "python-fallback" if engine_error else "python-driven step"),
+            "engine_error": engine_error,
             "get_hit_rate": hit_rate, "get_loc_correct": loc_ok, "get_loc_correct_last_timed": loc_ok_last,
             "set_loc_correct_last_timed": set_ok, "table_entries": entries,
             "table_entries_ok": entries.get("ok") if isinstance(entries, dict) else None,

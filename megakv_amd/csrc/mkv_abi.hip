@@ -114,6 +114,8 @@ extern "C" void mkv_timer_destroy(void *timer)
 }
 
 extern "C" int mkv_tuning_is_default_search(void);
+extern "C" void mkv_call_lock(void);
+extern "C" void mkv_call_unlock(void);
 extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
 extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
@@ -139,6 +141,12 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 	MkvTimer *tm = reinterpret_cast<MkvTimer *>(timer);
 	if (tm && (slot < 0 || slot >= tm->slots))
 		return MKV_EINVAL;
+	// host threads that run cycles at once (each on its own stream) take turns for the whole call: the
+	// parts below share the device's cycle workspace from the fused launch to the rounds
+	struct Turn {
+		Turn() { mkv_call_lock(); }
+		~Turn() { mkv_call_unlock(); }
+	} turn;
 	// The insert's mark pass never writes the table (its pre-walk reads it: a hint only, so a
 	// delete of the same cycle running beside it is harmless).  Default: it rides in the
 	// search launch (extra work-groups of one kernel).  MKV_CYCLE_SIDE_STREAM: it

@@ -705,6 +705,33 @@ extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const 
 		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
 		int self, uint32_t *self_slot, void *stream);
 
+// Will the pack of a batch with n_set SETs (any number of GETs) over nshards shards be ONE launch
+// (k_pack_tiles) -- the form that can write a rank's own slot elsewhere (mkv_pack_requests_self)?
+// The SET tiles of that launch meet once (they spin on an arrival counter): every one of them must
+// be resident at the same time.  They are the first work-groups of the grid, so it is enough that
+// the device can hold that many -- asked once per device (a CU-masked or partitioned device holds
+// fewer); beyond that, and with the tuning "pack_three_pass", the three-pass pack is used.  A batch
+// with fewer SETs than one that fits also fits (the sharded engine settles its form once, for its
+// largest batch).
+extern "C" int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_bytes)
+{
+	static int resident_cap[64] = {0};
+	int dev = 0;
+	(void)hipGetDevice(&dev);
+	if (dev >= 0 && dev < 64 && resident_cap[dev] == 0) {
+		int per_cu = 0, cus = 0;
+		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8>, mkv::kPackThreads, 0) != hipSuccess ||
+				hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+			per_cu = cus = 0;
+		resident_cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+	}
+	const int64_t set_tiles = ((n_set > 0 ? n_set : 0) + mkv::kSetTile - 1) / mkv::kSetTile;
+	const int64_t set_tiles_max = (dev >= 0 && dev < 64 && resident_cap[dev] > 0) ?
+			(resident_cap[dev] < 1024 ? resident_cap[dev] : 1024) : 128;
+	return nshards >= 1 && nshards <= mkv::kPackBins && set_tiles <= set_tiles_max && !mkv::tuning().pack_three_pass &&
+			scratch_bytes >= (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4;
+}
+
 extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
 		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
 		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
@@ -743,24 +770,7 @@ extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const 
 	const int64_t get_tile = mkv::kPackThreads * (r8 ? 8 : 4);
 	const int64_t set_tiles = (n_set + mkv::kSetTile - 1) / mkv::kSetTile;
 	const int64_t get_tiles = (n_get + get_tile - 1) / get_tile;
-	// The SET tiles of the one-launch pack meet once (they spin on an arrival counter): every one
-	// of them must be resident at the same time.  They are the first work-groups of the grid, so
-	// it is enough that the device can hold that many -- asked once per device (a CU-masked or
-	// partitioned device holds fewer); beyond that the three-pass pack is used.
-	static int resident_cap[64] = {0};
-	int dev = 0;
-	(void)hipGetDevice(&dev);
-	if (dev >= 0 && dev < 64 && resident_cap[dev] == 0) {
-		int per_cu = 0, cus = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8>, mkv::kPackThreads, 0) != hipSuccess ||
-				hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
-			per_cu = cus = 0;
-		resident_cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
-	}
-	const int64_t set_tiles_max = (dev >= 0 && dev < 64 && resident_cap[dev] > 0) ?
-			(resident_cap[dev] < 1024 ? resident_cap[dev] : 1024) : 128;
-	if (nshards <= mkv::kPackBins && set_tiles <= set_tiles_max && !mkv::tuning().pack_three_pass &&
-			scratch_bytes >= (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4) {
+	if (mkv_pack_one_launch(n_set, nshards, scratch_bytes)) {
 		// one launch; its control words (the head of `scratch`) are zero between calls: zeroed
 		// by the caller once, cleared again by the kernel's last work-group
 		const int64_t blocks = set_tiles + get_tiles ? set_tiles + get_tiles : 1;

@@ -1,15 +1,15 @@
 // megakv_amd -- sharded index, one rank's engine in C.
 //
-// A step of the sharded index is  pack -> all-to-all -> search+insert of the
-// received slots -> all-to-all of the results -> unpack  (mkv_route.hip,
-// mkv_update.hip).  This file drives that sequence for a whole run of batches from
-// one C call: a few lanes (buffers + stream each) keep as many batches in flight, so the
-// exchanges of one batch overlap the local kernels of its neighbour; local phases
-// are chained by events, i.e. results are those of the batches run one after the
-// other.  Collectives go straight to RCCL (ncclAllToAll on the lane's stream) over
-// a communicator of its own; the library is opened with dlopen -- the C ABI of the
-// hot path (libgpuhash.a) does not depend on it.  Collectives are issued in the same
-// order on every rank (2 lanes): fwd(0), fwd(1), back(0), fwd(2), back(1), ...
+// A step of the sharded index is  pack -> exchange -> search+insert of the received
+// slots -> exchange of the results -> unpack  (mkv_route.hip, mkv_update.hip).  This file
+// drives that sequence for a whole run of batches from one C call, with ONE schedule
+// (run_batches): the local phases, which update one table in batch order, run back to
+// back on a compute stream of their own; everything else of a batch runs on a service
+// stream; B buffer sets keep as many batches in flight.  Exchanges go straight to RCCL
+// (grouped ncclSend / ncclRecv per peer, or ncclAllToAll) over a communicator of the
+// engine's own; the library is opened with dlopen -- the C ABI of the hot path
+// (libgpuhash.a) does not depend on it.  Collectives are issued in the same order on every
+// rank: fwd(0) .. fwd(B-1), {back(0), fwd(B)}, {back(1), fwd(B+1)}, ...
 //
 // New design: the reference is single-GPU.
 #include <dlfcn.h>
@@ -23,6 +23,8 @@
 #include <new>
 
 #include "megakv_hip.h"
+
+extern "C" int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_bytes);
 
 namespace {
 
@@ -39,22 +41,20 @@ struct Rccl {
 	ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
 };
 
+// one buffer set: a batch in flight
 struct Lane {
-	hipStream_t stream = nullptr;
 	uint32_t *sendbuf = nullptr, *recvbuf = nullptr;
-	loc_t *out_slots = nullptr, *back_slots = nullptr;
-	int32_t *perm = nullptr;
+	loc_t *out_slots = nullptr;
+	// Returned results and the batch's `where` array, one of each per parity of the set's use: the
+	// local phase of batch i+B writes this rank's own answers straight into the results buffer while
+	// the un-pack of batch i, which nobody waits for, may still be reading the other one.
+	loc_t *back_slots[2] = {nullptr, nullptr};
+	int32_t *perm2[2] = {nullptr, nullptr};
 	uint32_t *scratch = nullptr;
 	ielem_t **set_ptrs = nullptr;
 	hipEvent_t ev_local[2] = {nullptr, nullptr};   // alternated so a pending wait keeps its event
+	hipEvent_t ev_recv[2] = {nullptr, nullptr};    // the set's requests have arrived (and its result slots have been sent)
 	hipEvent_t ev_done = nullptr;
-	// fused-exchange schedule: packs run on a stream of their own, into alternating `where` arrays
-	hipStream_t aux = nullptr;
-	int32_t *perm2[2] = {nullptr, nullptr};
-	hipEvent_t ev_xchg[2] = {nullptr, nullptr};    // the exchange that carried the lane's requests is done
-	hipEvent_t ev_pack[2] = {nullptr, nullptr};    // the lane's next batch is packed
-	hipEvent_t ev_recv[2] = {nullptr, nullptr};    // the lane's requests have arrived (and its result slots are read)
-	hipEvent_t ev_aux_done = nullptr;
 };
 
 }  // namespace
@@ -67,27 +67,24 @@ struct mkv_shard {
 	uint32_t agg_mask = 0, shift = 0;
 	int *overflow = nullptr;
 	int loopback = 0;               // rccl_path "loopback": the exchanges are local copies (tests)
-	int fused = 0;                  // one grouped collective per batch (run_fused): default with several ranks,
-	                                // MKV_SHARD_FUSED=0/1 overrides
-	long long packed = 0;           // batches packed so far
-	int self_direct = 0;            // plain schedule: what a rank sends to itself bypasses the exchange (the pack
-	                                // writes that slot into the receive buffer, the slot search its results into the
-	                                // buffer of returned results); the peers' slots go by grouped send / receive.
+	int self_direct = 0;            // what a rank sends to itself bypasses the exchange (the pack writes that slot
+	                                // into the receive buffer, the slot search its results into the buffer of
+	                                // returned results); the peers' slots go by grouped send / receive.  Settled
+	                                // when the engine is created, from its sizes alone: alike on every rank.
 	                                // MKV_SHARD_SELF=0: everything through ncclAllToAll (which copies the own slot itself)
-	int nlanes = 2;                 // batches in flight (MKV_SHARD_LANES = 2..4; more did not help on MI355X)
+	int nlanes = 2;                 // buffer sets = batches in flight (MKV_SHARD_LANES = 2..4)
 	Lane lane[4];
 	hipEvent_t ev_start = nullptr;
-	hipStream_t cstream = nullptr;  // fused schedule: every local phase, one after the other (no hand-over between streams)
+	hipStream_t cstream = nullptr;  // every local phase, one after the other
 	hipEvent_t ev_cdone = nullptr;
-	int one_compute_stream = 0;     // MKV_SHARD_CSTREAM=1
-	int sched_cs = 0;               // the default schedule (run_cs): local phases on `cstream`, everything else of
-	                                // a batch on a service stream; MKV_SHARD_SCHED=plain|fused selects the older two
-	int host_paced = 1;             // run_cs: the host, not the stream, waits for a local phase's requests (MKV_SHARD_PACED=0)
-	int nsvc = 1;                   // service streams of run_cs (MKV_SHARD_SVC = 1..3; default 1 rank: 1, else 2)
+	int host_paced = 1;             // the host, not the stream, waits for a local phase's requests (MKV_SHARD_PACED=0)
+	int nsvc = 1;                   // service streams (MKV_SHARD_SVC = 1..3; default 1 rank: 1, else 2)
 	hipStream_t svc[3] = {nullptr, nullptr, nullptr};
+	int delay_unpack_us = 0;        // tests (MKV_SHARD_DELAY_UNPACK_US): every un-pack starts that much later
+	const char *phase = "idle";     // what the engine was doing when a call failed (mkv_shard_error)
 	Rccl api;
 	ncclComm_t comm = nullptr;
-	char err[256] = {0};
+	char err[320] = {0};
 };
 
 // MKV_SHARD_TRACE=n (diagnostics): device timestamps around every operation of n batches
@@ -231,7 +228,8 @@ Rccl loopback_api()
 
 static int fail(mkv_shard *e, int code, const char *what, const char *detail)
 {
-	snprintf(e->err, sizeof(e->err), "%s%s%s", what, detail ? ": " : "", detail ? detail : "");
+	snprintf(e->err, sizeof(e->err), "[rank %d of %d, %s] %s%s%s", e->rank, e->world, e->phase, what, detail ? ": " : "",
+			detail ? detail : "");
 	return code;
 }
 
@@ -265,31 +263,20 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 		if (sv)
 			(void)hipStreamDestroy(sv);
 	for (Lane &l : e->lane) {
-		if (!l.sendbuf)
-			continue;
 		if (l.sendbuf) (void)hipFree(l.sendbuf);
 		if (l.recvbuf) (void)hipFree(l.recvbuf);
 		if (l.out_slots) (void)hipFree(l.out_slots);
-		if (l.back_slots) (void)hipFree(l.back_slots);
-		if (l.perm) (void)hipFree(l.perm);
+		for (loc_t *b : l.back_slots)
+			if (b) (void)hipFree(b);
+		for (int32_t *w : l.perm2)
+			if (w) (void)hipFree(w);
 		if (l.scratch) (void)hipFree(l.scratch);
 		if (l.set_ptrs) (void)hipFree(l.set_ptrs);
 		for (hipEvent_t ev : l.ev_local)
 			if (ev) (void)hipEventDestroy(ev);
-		if (l.ev_done) (void)hipEventDestroy(l.ev_done);
-		if (l.perm2[1]) (void)hipFree(l.perm2[1]);
-		for (hipEvent_t ev : l.ev_xchg)
-			if (ev) (void)hipEventDestroy(ev);
-		for (hipEvent_t ev : l.ev_pack)
-			if (ev) (void)hipEventDestroy(ev);
 		for (hipEvent_t ev : l.ev_recv)
 			if (ev) (void)hipEventDestroy(ev);
-		if (l.ev_aux_done) (void)hipEventDestroy(l.ev_aux_done);
-		if (l.aux) (void)hipStreamDestroy(l.aux);
-		if (l.stream) {
-			mkv_forget_stream(l.stream);
-			(void)hipStreamDestroy(l.stream);
-		}
+		if (l.ev_done) (void)hipEventDestroy(l.ev_done);
 	}
 	if (e->overflow) (void)hipFree(e->overflow);
 	if (e->ev_start) (void)hipEventDestroy(e->ev_start);
@@ -327,51 +314,34 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		k++;
 	e->agg_mask = (uint32_t)((1ull << (geom->mem_p + k - 6)) - 1ull);
 	e->shift = (uint32_t)(geom->mem_p - 6);
+	e->phase = "create";
+	// buffer sets = batches in flight: two with one rank (67.9 - 69.7 us per step against 70.3 - 71.7
+	// with three), three with several (the exchanges take their time on the service streams)
+	e->nlanes = world > 1 ? 3 : 2;
 	if (const char *v = getenv("MKV_SHARD_LANES")) {
 		const int n = atoi(v);
 		if (n >= 2 && n <= 4)
 			e->nlanes = n;
 	}
-	// Schedules.  Default: run_cs.  MKV_SHARD_SCHED=plain / fused: the two older ones (lanes with a
-	// stream each; fused = one grouped collective per batch, packs on streams of their own), kept
-	// for comparison; MKV_SHARD_FUSED=0/1 selects between those two as before.
-	const char *sched = getenv("MKV_SHARD_SCHED");
-	e->sched_cs = !sched || !strcmp(sched, "cs");
-	e->fused = sched && !strcmp(sched, "fused");
-	if (const char *v = getenv("MKV_SHARD_FUSED")) {
-		e->fused = atoi(v) != 0;
-		e->sched_cs = 0;
+	if (const char *v = getenv("MKV_SHARD_PACED"))
+		e->host_paced = atoi(v) != 0;
+	e->nsvc = world > 1 ? 2 : 1;
+	if (const char *v = getenv("MKV_SHARD_SVC")) {
+		const int n = atoi(v);
+		if (n >= 1 && n <= 3)
+			e->nsvc = n;
 	}
-	if (e->sched_cs) {
-		e->fused = 0;
-		// buffer sets = batches in flight: two with one rank (67.9 - 69.7 us per step against 70.3 - 71.7
-		// with three), three with several (the exchanges take their time on the service streams)
-		e->nlanes = world > 1 ? 3 : 2;
-		if (const char *v = getenv("MKV_SHARD_LANES")) {
-			const int n = atoi(v);
-			if (n >= 2 && n <= 4)
-				e->nlanes = n;
-		}
-		e->one_compute_stream = 1;
-		if (const char *v = getenv("MKV_SHARD_PACED"))
-			e->host_paced = atoi(v) != 0;
-		e->nsvc = world > 1 ? 2 : 1;
-		if (const char *v = getenv("MKV_SHARD_SVC")) {
-			const int n = atoi(v);
-			if (n >= 1 && n <= 3)
-				e->nsvc = n;
-		}
-	} else {
-		e->one_compute_stream = 0;
-		if (const char *v = getenv("MKV_SHARD_CSTREAM"))
-			e->one_compute_stream = atoi(v) != 0;
-	}
-	// what a rank sends to itself bypasses the exchange (not in the fused schedule)
-	e->self_direct = !e->fused && world <= 16;      // (the one-launch pack handles up to 16 shards)
-	if (const char *v = getenv("MKV_SHARD_SELF"))
-		e->self_direct = atoi(v) != 0 && !e->fused && world <= 16;
+	if (const char *v = getenv("MKV_SHARD_DELAY_UNPACK_US"))
+		e->delay_unpack_us = atoi(v);
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);
 	e->scratch_bytes = mkv_pack_scratch_bytes(n_get ? n_get : 1, n_set ? n_set : 1, world);
+	// What a rank sends to itself bypasses the exchange -- if the one-launch pack, which alone can
+	// write the own slot elsewhere, will do for the LARGEST batch the engine is made for (a smaller one
+	// has fewer tiles): settled here once, from arguments every rank passes alike, so that no rank
+	// changes the form of its exchanges in the middle of a run or apart from its peers.
+	e->self_direct = mkv_pack_one_launch(n_set, world, e->scratch_bytes) != 0;
+	if (const char *v = getenv("MKV_SHARD_SELF"))
+		e->self_direct = e->self_direct && atoi(v) != 0;
 
 	if (rccl_path && !strcmp(rccl_path, "loopback")) {
 		// test shape (tests/test_gpu_sharded.py): every peer is this process -- see loopback_api()
@@ -407,19 +377,19 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	const size_t res_bytes = (size_t)world * (size_t)(cap_get ? cap_get : 1) * sizeof(loc_t) * 2u;
 	for (int li = 0; li < e->nlanes; li++) {
 		Lane &l = e->lane[li];
-		if (!e->sched_cs)
-			SH_HIP(e, hipStreamCreateWithFlags(&l.stream, hipStreamNonBlocking));
 		SH_HIP(e, hipMalloc(&l.sendbuf, slot_bytes));
 		SH_HIP(e, hipMalloc(&l.recvbuf, slot_bytes));
 		SH_HIP(e, hipMalloc(&l.out_slots, res_bytes));
-		SH_HIP(e, hipMalloc(&l.back_slots, res_bytes));
-		const size_t where_bytes = (size_t)(n_get ? n_get : 1) * sizeof(int32_t);
-		SH_HIP(e, hipMalloc(&l.perm, where_bytes));   // where each GET went
-		SH_HIP(e, hipMalloc(&l.scratch, (size_t)e->scratch_bytes + 64));
 		SH_HIP(e, hipMemset(l.sendbuf, 0, slot_bytes));
 		SH_HIP(e, hipMemset(l.recvbuf, 0, slot_bytes));
 		SH_HIP(e, hipMemset(l.out_slots, 0, res_bytes));
-		SH_HIP(e, hipMemset(l.back_slots, 0, res_bytes));
+		const size_t where_bytes = (size_t)(n_get ? n_get : 1) * sizeof(int32_t);
+		for (int k2 = 0; k2 < 2; k2++) {
+			SH_HIP(e, hipMalloc(&l.back_slots[k2], res_bytes));
+			SH_HIP(e, hipMemset(l.back_slots[k2], 0, res_bytes));
+			SH_HIP(e, hipMalloc(&l.perm2[k2], where_bytes));   // where each GET went
+		}
+		SH_HIP(e, hipMalloc(&l.scratch, (size_t)e->scratch_bytes + 64));
 		SH_HIP(e, hipMemset(l.scratch, 0, (size_t)e->scratch_bytes + 64));   // the pack's control words start at zero
 		SH_HIP(e, hipMalloc(&l.set_ptrs, (size_t)world * sizeof(ielem_t *)));
 		ielem_t *ptrs[64];
@@ -428,30 +398,15 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		SH_HIP(e, hipMemcpy(l.set_ptrs, ptrs, (size_t)world * sizeof(ielem_t *), hipMemcpyHostToDevice));
 		for (hipEvent_t &ev : l.ev_local)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-		SH_HIP(e, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
-		// (streams are multiplexed over a handful of hardware queues: two streams that share one wait
-		// for each other's kernels -- only the streams a schedule uses are created)
-		if (e->fused)
-			SH_HIP(e, hipStreamCreateWithFlags(&l.aux, hipStreamNonBlocking));
-		l.perm2[0] = l.perm;
-		if (e->fused || e->sched_cs)
-			SH_HIP(e, hipMalloc(&l.perm2[1], where_bytes));
-		for (hipEvent_t &ev : l.ev_xchg)
-			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-		for (hipEvent_t &ev : l.ev_pack)
-			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
 		for (hipEvent_t &ev : l.ev_recv)
 			SH_HIP(e, hipEventCreateWithFlags(&ev, hipEventDisableTiming));
-		SH_HIP(e, hipEventCreateWithFlags(&l.ev_aux_done, hipEventDisableTiming));
-		if (cap_set && l.stream) {
-			const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, l.stream);
-			if (rc != MKV_OK)
-				return fail(e, rc, "mkv_reserve", nullptr);
-		}
+		SH_HIP(e, hipEventCreateWithFlags(&l.ev_done, hipEventDisableTiming));
 	}
-	for (int k = 0; k < (e->sched_cs ? e->nsvc : 0); k++)
-		SH_HIP(e, hipStreamCreateWithFlags(&e->svc[k], hipStreamNonBlocking));
-	if (e->one_compute_stream) {
+	// (streams are multiplexed over a handful of hardware queues: two streams that share one wait
+	// for each other's kernels -- only the streams the schedule uses are created)
+	for (int k2 = 0; k2 < e->nsvc; k2++)
+		SH_HIP(e, hipStreamCreateWithFlags(&e->svc[k2], hipStreamNonBlocking));
+	{
 		// The local phases are the critical path.  Their stream gets the highest priority: the
 		// runtime pools its hardware queues per priority, so this stream never shares a queue with a
 		// service stream (which would make pack, exchange and un-pack take turns with the local
@@ -468,58 +423,13 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 			SH_HIP(e, hipStreamCreateWithPriority(&e->cstream, hipStreamNonBlocking, prio_greatest));
 	}
 	SH_HIP(e, hipEventCreateWithFlags(&e->ev_cdone, hipEventDisableTiming));
-	if (cap_set && e->one_compute_stream) {
+	if (cap_set) {
 		const int rc = mkv_reserve(&e->geom, (long long)world * cap_set + 1024, e->cstream);
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_reserve", nullptr);
 	}
 	SH_HIP(e, hipDeviceSynchronize());
-	return MKV_OK;
-}
-
-// rank 0 makes the 128-byte id; the host framework hands it to every rank
-extern "C" int mkv_shard_unique_id(mkv_shard *e, void *id128)
-{
-	if (!e || !id128)
-		return MKV_EINVAL;
-	ncclUniqueId id;
-	SH_NCCL(e, e->api.GetUniqueId(&id));
-	memcpy(id128, &id, sizeof(id));
-	return MKV_OK;
-}
-
-// collective over all ranks of the job
-extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
-{
-	if (!e || !id128 || e->comm)
-		return MKV_EINVAL;
-	ncclUniqueId id;
-	memcpy(&id, id128, sizeof(id));
-	SH_NCCL(e, e->api.CommInitRank(&e->comm, e->world, id, e->rank));
-	if (e->loopback)
-		return MKV_OK;                 // (block j comes back as block j: nothing to check)
-	// Self-check of the exchange before anything relies on it: block j of rank i must arrive
-	// as block i of rank j.  (With one rank every layout looks right, so this is the only
-	// place a wrong assumption about the collective would show before the results do.)
-	const int w = e->world;
-	uint32_t host[64 * 4], *dsend = nullptr, *drecv = nullptr;
-	for (int j = 0; j < w; j++)
-		for (int k = 0; k < 4; k++)
-			host[j * 4 + k] = ((uint32_t)e->rank << 16) | ((uint32_t)j << 8) | (uint32_t)k;
-	SH_HIP(e, hipMalloc(&dsend, (size_t)w * 16));
-	SH_HIP(e, hipMalloc(&drecv, (size_t)w * 16));
-	SH_HIP(e, hipMemcpy(dsend, host, (size_t)w * 16, hipMemcpyHostToDevice));
-	SH_HIP(e, hipMemset(drecv, 0xff, (size_t)w * 16));
-	hipStream_t cs0 = e->lane[0].stream ? e->lane[0].stream : e->svc[0];
-	SH_NCCL(e, e->api.AllToAll(dsend, drecv, 4, ncclInt32, e->comm, cs0));
-	SH_HIP(e, hipStreamSynchronize(cs0));
-	SH_HIP(e, hipMemcpy(host, drecv, (size_t)w * 16, hipMemcpyDeviceToHost));
-	(void)hipFree(dsend);
-	(void)hipFree(drecv);
-	for (int i = 0; i < w; i++)
-		for (int k = 0; k < 4; k++)
-			if (host[i * 4 + k] != (((uint32_t)i << 16) | ((uint32_t)e->rank << 8) | (uint32_t)k))
-				return fail(e, MKV_EHIP, "all-to-all self-check", "block from a peer is not where it belongs");
+	e->phase = "created";
 	return MKV_OK;
 }
 
@@ -527,6 +437,7 @@ extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const 
 		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
 		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
 		int self, uint32_t *self_slot, void *stream);
+extern "C" int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_bytes);
 extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots, int64_t cap_get,
 		int64_t cap_set, loc_t *out_slots, bucket_t *table, ielem_t **set_ptrs, long long size_hint,
 		void *stream, void *timer, int slot, int self, loc_t *self_out, void *done_event);
@@ -556,66 +467,75 @@ static int exchange_peers(mkv_shard *e, const void *send, void *recv, size_t cou
 	return MKV_OK;
 }
 
-static int forward(mkv_shard *e, Lane &l, const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
-		int lane, int batch, bool tr)
+// rank 0 makes the 128-byte id; the host framework hands it to every rank
+extern "C" int mkv_shard_unique_id(mkv_shard *e, void *id128)
 {
-	if (n_get > e->n_get || n_set > e->n_set)
-		return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
-	int rc;
-	{
-		Span sp("pack", lane, batch, l.stream, tr);
-		if (e->self_direct) {
-			rc = mkv_pack_requests_self(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
-					e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, e->rank,
-					l.recvbuf + (size_t)e->rank * (size_t)e->slot_words, l.stream);
-			if (rc == MKV_EINVAL) {
-				if (e->packed)
-					return fail(e, MKV_EINVAL, "the pack changed its form in the middle of a run", nullptr);
-				e->self_direct = 0;           // (the pack fell back to its three-pass form: everything by all-to-all)
-				rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
-						e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
-			}
-		} else {
-			rc = mkv_pack_requests(gets, n_get, sets, n_set, e->agg_mask, e->shift, e->world, l.sendbuf,
-					e->cap_get, e->cap_set, l.perm, l.scratch, e->scratch_bytes, e->overflow, l.stream);
-		}
-	}
-	if (rc != MKV_OK)
-		return fail(e, rc, "mkv_pack_requests", nullptr);
-	e->packed++;
-	if (e->self_direct) {
-		if (e->world > 1) {
-			Span sp("xchg-fwd", lane, batch, l.stream, tr);
-			rc = exchange_peers(e, l.sendbuf, l.recvbuf, (size_t)e->slot_words, l.stream);
-			fake_xfer(l.stream);
-		}
-		return rc;
-	}
-	Span sp("a2a-fwd", lane, batch, l.stream, tr);
-	SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
-	fake_xfer(l.stream);
+	if (!e || !id128)
+		return MKV_EINVAL;
+	ncclUniqueId id;
+	SH_NCCL(e, e->api.GetUniqueId(&id));
+	memcpy(id128, &id, sizeof(id));
 	return MKV_OK;
 }
 
-static int backward(mkv_shard *e, Lane &l, loc_t *out, int64_t n_get, int lane, int batch, bool tr)
+// collective over all ranks of the job
+extern "C" int mkv_shard_connect(mkv_shard *e, const void *id128)
 {
-	if (e->self_direct) {
-		if (e->world > 1) {
-			Span sp("xchg-back", lane, batch, l.stream, tr);
-			const int rc = exchange_peers(e, l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, l.stream);
-			if (rc != MKV_OK)
-				return rc;
-			fake_xfer(l.stream);
-		}
-	} else {
-		Span sp("a2a-back", lane, batch, l.stream, tr);
-		SH_NCCL(e, e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, l.stream));
-		fake_xfer(l.stream);
+	if (!e || !id128 || e->comm)
+		return MKV_EINVAL;
+	ncclUniqueId id;
+	memcpy(&id, id128, sizeof(id));
+	e->phase = "connect (ncclCommInitRank)";
+	SH_NCCL(e, e->api.CommInitRank(&e->comm, e->world, id, e->rank));
+	e->phase = "connected";
+	if (e->loopback)
+		return MKV_OK;                 // (block j comes back as block j: nothing to check)
+	e->phase = "first exchange (all-to-all self-check)";
+	// Self-check of the exchange before anything relies on it: block j of rank i must arrive
+	// as block i of rank j.  (With one rank every layout looks right, so this is the only
+	// place a wrong assumption about the collective would show before the results do.)
+	const int w = e->world;
+	uint32_t host[64 * 4], *dsend = nullptr, *drecv = nullptr;
+	for (int j = 0; j < w; j++)
+		for (int k = 0; k < 4; k++)
+			host[j * 4 + k] = ((uint32_t)e->rank << 16) | ((uint32_t)j << 8) | (uint32_t)k;
+	SH_HIP(e, hipMalloc(&dsend, (size_t)w * 16));
+	SH_HIP(e, hipMalloc(&drecv, (size_t)w * 16));
+	SH_HIP(e, hipMemcpy(dsend, host, (size_t)w * 16, hipMemcpyHostToDevice));
+	SH_HIP(e, hipMemset(drecv, 0xff, (size_t)w * 16));
+	hipStream_t cs0 = e->svc[0];
+	SH_NCCL(e, e->api.AllToAll(dsend, drecv, 4, ncclInt32, e->comm, cs0));
+	SH_HIP(e, hipStreamSynchronize(cs0));
+	SH_HIP(e, hipMemcpy(host, drecv, (size_t)w * 16, hipMemcpyDeviceToHost));
+	(void)hipFree(dsend);
+	(void)hipFree(drecv);
+	for (int i = 0; i < w; i++)
+		for (int k = 0; k < 4; k++)
+			if (host[i * 4 + k] != (((uint32_t)i << 16) | ((uint32_t)e->rank << 8) | (uint32_t)k))
+				return fail(e, MKV_EHIP, "all-to-all self-check", "block from a peer is not where it belongs");
+	// ... and the grouped send / receive form the runs use for the peers' slots, once, the same way
+	if (e->self_direct && w > 1) {
+		e->phase = "first exchange (grouped send / receive self-check)";
+		SH_HIP(e, hipMalloc(&dsend, (size_t)w * 16));
+		SH_HIP(e, hipMalloc(&drecv, (size_t)w * 16));
+		for (int j = 0; j < w; j++)
+			for (int k = 0; k < 4; k++)
+				host[j * 4 + k] = 0x5a000000u | ((uint32_t)e->rank << 16) | ((uint32_t)j << 8) | (uint32_t)k;
+		SH_HIP(e, hipMemcpy(dsend, host, (size_t)w * 16, hipMemcpyHostToDevice));
+		SH_HIP(e, hipMemset(drecv, 0xff, (size_t)w * 16));
+		const int rc = exchange_peers(e, dsend, drecv, 4, cs0);
+		if (rc != MKV_OK)
+			return rc;
+		SH_HIP(e, hipStreamSynchronize(cs0));
+		SH_HIP(e, hipMemcpy(host, drecv, (size_t)w * 16, hipMemcpyDeviceToHost));
+		(void)hipFree(dsend);
+		(void)hipFree(drecv);
+		for (int i = 0; i < w; i++)
+			for (int k = 0; k < 4 && i != e->rank; k++)
+				if (host[i * 4 + k] != (0x5a000000u | ((uint32_t)i << 16) | ((uint32_t)e->rank << 8) | (uint32_t)k))
+					return fail(e, MKV_EHIP, "send / receive self-check", "block from a peer is not where it belongs");
 	}
-	Span sp("unpack", lane, batch, l.stream, tr);
-	const int rc = mkv_unpack_results(l.back_slots, l.perm, n_get, out, l.stream);
-	if (rc != MKV_OK)
-		return fail(e, rc, "mkv_unpack_results", nullptr);
+	e->phase = "connected";
 	return MKV_OK;
 }
 
@@ -639,133 +559,24 @@ static void print_trace()
 	}
 }
 
-// The schedule with ONE collective launch per batch: behind the local phase of batch i a
-// group of two all-to-alls carries the results of batch i back and the requests of batch
-// i+2 out (same lane).  The requests of batch i+1 went out a step earlier, so between two
-// local phases nothing but the event chain remains; exchange, un-pack and the pack of the
-// batch after next (on a stream of its own) all run beside the other lane's local phase.
-// Collective order on every rank: fwd(0), fwd(1), {back(0), fwd(2)}, {back(1), fwd(3)}, ...
-static int run_fused(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
-		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, hipStream_t main, void *timer,
-		int timer_every, int trace_from)
-{
-	const int L = e->nlanes;                          // batches in flight
-	SH_HIP(e, hipEventRecord(e->ev_start, main));
-	for (int li = 0; li < L; li++) {
-		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
-		SH_HIP(e, hipStreamWaitEvent(e->lane[li].aux, e->ev_start, 0));
-	}
-	// MKV_SHARD_CSTREAM=1: the local phases -- which update ONE table in batch order -- run on a
-	// stream of their own instead of the lanes' streams chained by events (a hand-over between
-	// streams costs 10 - 14 us here, once per batch, on the critical path); what a local phase
-	// then waits for is the exchange that brought its requests, L - 1 local phases earlier.
-	const bool cs = e->one_compute_stream != 0;
-	hipStream_t C = e->cstream;
-	if (cs)
-		SH_HIP(e, hipStreamWaitEvent(C, e->ev_start, 0));
-	auto pack = [&](Lane &l, int j, hipStream_t s, int lane, bool tr) -> int {
-		if (n_get[j] > e->n_get || n_set[j] > e->n_set)
-			return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
-		Span sp("pack", lane, j, s, tr);
-		const int rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world,
-				l.sendbuf, e->cap_get, e->cap_set, l.perm2[(j / L) & 1], l.scratch, e->scratch_bytes, e->overflow, s);
-		return rc == MKV_OK ? MKV_OK : fail(e, rc, "mkv_pack_requests", nullptr);
-	};
-	int rc = MKV_OK;
-	for (int j = 0; j < L && j < nbatches; j++) {
-		Lane &l = e->lane[j];
-		if ((rc = pack(l, j, l.stream, j, false)) != MKV_OK)
-			return rc;
-		SH_NCCL(e, e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, l.stream));
-		SH_HIP(e, hipEventRecord(l.ev_xchg[0], l.stream));
-		SH_HIP(e, hipEventRecord(l.ev_recv[0], l.stream));
-	}
-	hipEvent_t prev_local = nullptr;
-	for (int i = 0; i < nbatches; i++) {
-		Lane &l = e->lane[i % L];
-		const int lane = i % L, k = (i / L) & 1, k2 = k ^ 1;
-		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
-		const bool more = i + L < nbatches;
-		if (more) {
-			// the lane's send buffers are free once the exchange that carried batch i is done
-			SH_HIP(e, hipStreamWaitEvent(l.aux, l.ev_xchg[k], 0));
-			if ((rc = pack(l, i + L, l.aux, lane, tr)) != MKV_OK)
-				return rc;
-			SH_HIP(e, hipEventRecord(l.ev_pack[k2], l.aux));
-		}
-		hipStream_t ls = cs ? C : l.stream;           // where this batch's local phase runs
-		if (cs)
-			SH_HIP(e, hipStreamWaitEvent(C, l.ev_recv[k], 0));   // requests in recvbuf, result slots of batch i-L sent
-		else if (prev_local)
-			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
-		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
-		{
-			Span sp("local", lane, i, ls, tr);
-			rc = mkv_slots_cycle(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
-					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, ls, timed ? timer : nullptr,
-					timed ? i / timer_every : 0);
-		}
-		if (rc != MKV_OK)
-			return fail(e, rc, "mkv_slots_cycle", nullptr);
-		prev_local = l.ev_local[k];
-		SH_HIP(e, hipEventRecord(prev_local, ls));
-		if (cs)
-			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
-		if (more)
-			SH_HIP(e, hipStreamWaitEvent(l.stream, l.ev_pack[k2], 0));
-		{
-			Span sp("exchange", lane, i, l.stream, tr);
-			SH_NCCL(e, e->api.GroupStart());
-			ncclResult_t r1 = e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm,
-					l.stream);
-			ncclResult_t r2 = more ? e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32,
-					e->comm, l.stream) : ncclSuccess;
-			SH_NCCL(e, e->api.GroupEnd());
-			SH_NCCL(e, r1);
-			SH_NCCL(e, r2);
-			fake_xfer(l.stream);
-		}
-		SH_HIP(e, hipEventRecord(l.ev_recv[k2], l.stream));
-		{
-			Span sp("unpack", lane, i, l.stream, tr);
-			rc = mkv_unpack_results(l.back_slots, l.perm2[k], n_get[i], outs[i], l.stream);
-		}
-		if (rc != MKV_OK)
-			return fail(e, rc, "mkv_unpack_results", nullptr);
-		// Recorded AFTER the un-pack: the pack of batch i+4 (two iterations on, on the aux stream)
-		// waits for this event and then writes perm2[k], which the un-pack above is reading --
-		// and the send buffer, which the exchange above has read.
-		SH_HIP(e, hipEventRecord(l.ev_xchg[k2], l.stream));
-	}
-	for (int li = 0; li < L; li++) {
-		Lane &l = e->lane[li];
-		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
-		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
-		SH_HIP(e, hipEventRecord(l.ev_aux_done, l.aux));
-		SH_HIP(e, hipStreamWaitEvent(main, l.ev_aux_done, 0));
-	}
-	if (cs) {
-		SH_HIP(e, hipEventRecord(e->ev_cdone, C));
-		SH_HIP(e, hipStreamWaitEvent(main, e->ev_cdone, 0));
-	}
-	return MKV_OK;
-}
-
-// The default schedule.  The local phases update ONE table in batch order: they run back to
-// back on a stream of their own (`cstream`) and never wait for an event that has not long been
-// signalled.  Everything else of a batch -- pack, exchanges, un-pack -- runs on a service stream;
-// B buffer sets (3) keep as many batches in flight.  For batch i (set b = i mod B, which always
-// uses the same service stream) the service stream does, once local(i) is done:
+// The schedule.  The local phases update ONE table in batch order: they run back to back on a
+// stream of their own (`cstream`) and never wait for an event that has not long been signalled.
+// Everything else of a batch -- pack, exchanges, un-pack -- runs on a service stream; B buffer sets
+// keep as many batches in flight.  For batch i (set b = i mod B, which always uses the same service
+// stream, parity k = (i / B) mod 2 of the set's use) the service stream does, once local(i) is done:
 //     pack(i+B) -> { results of batch i back, requests of batch i+B out } -> un-pack(i)
-// the exchange as ONE grouped launch (or nothing at all with one rank), the pack of batch i+B
-// ahead of it into the set's other `where` array, so that what local(i+B) needs is on its way
-// first and the un-pack, which nobody waits for, comes last.  Streams are multiplexed over a
-// handful of hardware queues, and two streams sharing one wait for each other's kernels
-// (MKV_SHARD_TRACE showed 20 - 60 us holes between local phases with 3 lanes x 2 streams + 1):
-// this schedule keeps 2 streams busy with one rank, 3 with several.
-// Collective order on every rank: fwd(0) .. fwd(B-1), {back(0), fwd(B)}, {back(1), fwd(B+1)}, ...
-static int exchange_pair(mkv_shard *e, Lane &l, bool back, bool fwd, hipStream_t s)
+// the exchange as ONE grouped launch (or nothing at all with one rank), the pack of batch i+B ahead of
+// it into the set's other `where` array, so that what local(i+B) needs is on its way first, and the
+// un-pack, which nobody waits for, last.  What local(i+B) may write while un-pack(i) still reads --
+// this rank's own answers, which bypass the exchange -- goes into the returned-results buffer of the
+// other parity; the buffers of parity k are next written by local(i+2B) and the exchange behind it,
+// both behind un-pack(i) in the order of the service stream.  Streams are multiplexed over a handful
+// of hardware queues, and two streams sharing one wait for each other's kernels (MKV_SHARD_TRACE
+// showed 20 - 60 us holes between local phases with 3 lanes x 2 streams + 1): the schedule keeps 2
+// streams busy with one rank, 3 with several.
+static int exchange_pair(mkv_shard *e, Lane &l, int k, bool back, bool fwd, hipStream_t s)
 {
+	// (k: parity of the batch whose results come back)
 	if (!back && !fwd)
 		return MKV_OK;
 	if (e->self_direct && e->world == 1)
@@ -780,7 +591,7 @@ static int exchange_pair(mkv_shard *e, Lane &l, bool back, bool fwd, hipStream_t
 			if (back) {
 				const size_t c = (size_t)e->cap_get * 2u;
 				note(e->api.Send(l.out_slots + (size_t)p * c, c, ncclInt32, p, e->comm, s));
-				note(e->api.Recv(l.back_slots + (size_t)p * c, c, ncclInt32, p, e->comm, s));
+				note(e->api.Recv(l.back_slots[k] + (size_t)p * c, c, ncclInt32, p, e->comm, s));
 			}
 			if (fwd) {
 				const size_t c = (size_t)e->slot_words;
@@ -790,7 +601,7 @@ static int exchange_pair(mkv_shard *e, Lane &l, bool back, bool fwd, hipStream_t
 		}
 	} else {
 		if (back)
-			note(e->api.AllToAll(l.out_slots, l.back_slots, (size_t)e->cap_get * 2u, ncclInt32, e->comm, s));
+			note(e->api.AllToAll(l.out_slots, l.back_slots[k], (size_t)e->cap_get * 2u, ncclInt32, e->comm, s));
 		if (fwd)
 			note(e->api.AllToAll(l.sendbuf, l.recvbuf, (size_t)e->slot_words, ncclInt32, e->comm, s));
 	}
@@ -807,7 +618,7 @@ static double host_us()
 	return ts.tv_sec * 1e6 + ts.tv_nsec * 1e-3;
 }
 
-static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
+static int run_batches(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
 		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, hipStream_t main, void *timer,
 		int timer_every, int trace_from)
 {
@@ -818,6 +629,7 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 	const double h0 = host_trace ? host_us() : 0.0;
 	double h_pro = 0, h_first = 0, h_sync_sum = 0, h_sync_max = 0;
 	hipStream_t C = e->cstream;
+	e->phase = "run: prologue (first packs and exchanges)";
 	SH_HIP(e, hipEventRecord(e->ev_start, main));
 	SH_HIP(e, hipStreamWaitEvent(C, e->ev_start, 0));
 	for (int k = 0; k < K; k++)
@@ -826,24 +638,15 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 		if (n_get[j] > e->n_get || n_set[j] > e->n_set)
 			return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
 		Span sp("pack", set, j, s, tr);
-		int rc;
 		int32_t *where = l.perm2[(j / B) & 1];
-		if (e->self_direct) {
-			rc = mkv_pack_requests_self(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
-					e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, e->rank,
-					l.recvbuf + (size_t)e->rank * (size_t)e->slot_words, s);
-			if (rc == MKV_EINVAL && !e->packed) {
-				e->self_direct = 0;           // (the pack fell back to its three-pass form: everything by all-to-all)
-				rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
+		const int rc = e->self_direct ?
+				mkv_pack_requests_self(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
+						e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, e->rank,
+						l.recvbuf + (size_t)e->rank * (size_t)e->slot_words, s) :
+				mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
 						e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, s);
-			}
-		} else {
-			rc = mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
-					e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, s);
-		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_pack_requests", nullptr);
-		e->packed++;
 		return MKV_OK;
 	};
 	int rc = MKV_OK;
@@ -852,12 +655,13 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 		hipStream_t S = e->svc[j % K];
 		if ((rc = pack(l, j, S, j, false)) != MKV_OK)
 			return rc;
-		if ((rc = exchange_pair(e, l, false, true, S)) != MKV_OK)
+		if ((rc = exchange_pair(e, l, 0, false, true, S)) != MKV_OK)
 			return rc;
 		SH_HIP(e, hipEventRecord(l.ev_recv[0], S));
 	}
 	if (host_trace)
 		h_pro = host_us();
+	e->phase = "run: batches";
 	for (int i = 0; i < nbatches; i++) {
 		const int b = i % B, k = (i / B) & 1, k2 = k ^ 1;
 		Lane &l = e->lane[b];
@@ -889,7 +693,7 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 			rc = mkv_slots_cycle_self(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
 					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, C, timed ? timer : nullptr,
 					timed ? i / timer_every : 0, e->self_direct ? e->rank : -1,
-					l.back_slots + (size_t)e->rank * (size_t)e->cap_get * 2u, tr ? nullptr : l.ev_local[k]);
+					l.back_slots[k] + (size_t)e->rank * (size_t)e->cap_get * 2u, tr ? nullptr : l.ev_local[k]);
 		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_slots_cycle", nullptr);
@@ -901,19 +705,21 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 			return rc;
 		{
 			Span sp("exchange", b, i, S, tr);
-			if ((rc = exchange_pair(e, l, true, more, S)) != MKV_OK)
+			if ((rc = exchange_pair(e, l, k, true, more, S)) != MKV_OK)
 				return rc;
 		}
 		if (more)
 			SH_HIP(e, hipEventRecord(l.ev_recv[k2], S));
+		if (e->delay_unpack_us > 0)
+			hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, S, (unsigned)e->delay_unpack_us);
 		{
 			Span sp("unpack", b, i, S, tr);
-			rc = mkv_unpack_results(l.back_slots, l.perm2[k], n_get[i], outs[i], S);
+			rc = mkv_unpack_results(l.back_slots[k], l.perm2[k], n_get[i], outs[i], S);
 		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_unpack_results", nullptr);
-		SH_HIP(e, hipEventRecord(l.ev_xchg[k], S));      // the set's result buffers are free again
 	}
+	e->phase = "run: epilogue";
 	for (int k = 0; k < K; k++) {
 		SH_HIP(e, hipEventRecord(e->lane[k].ev_done, e->svc[k]));
 		SH_HIP(e, hipStreamWaitEvent(main, e->lane[k].ev_done, 0));
@@ -924,35 +730,22 @@ static int run_cs(mkv_shard *e, int nbatches, const selem_t *const *gets, const 
 		const double h1 = host_us();
 		(void)hipStreamSynchronize(main);
 		const double h2 = host_us();
-		fprintf(stderr, "run_cs %d batches: prologue enqueued %.0f us, first requests in %.0f us, loop done %.0f us, "
+		fprintf(stderr, "run %d batches: prologue enqueued %.0f us, first requests in %.0f us, loop done %.0f us, "
 				"device done %.0f us; host waits %.0f us in all, longest %.0f us\n", nbatches, h_pro - h0, h_first - h0,
 				h1 - h0, h2 - h0, h_sync_sum, h_sync_max);
 	}
+	e->phase = "idle";
 	return MKV_OK;
 }
 
 // nbatches batches of this rank: gets[i] (n_get[i] x selem_t), sets[i] (n_set[i] x ielem_t),
 // outs[i] (n_get[i] x 2 loc_t, request order) -- all device pointers, host arrays of them.
-// Everything is enqueued (no host synchronisation); the lanes start after what is queued
-// on `stream` and `stream` waits for them at the end.  timer (mkv_timer_*) brackets the
-// local search launch of every timer_every-th batch, slot = i / timer_every.
-static int shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
-		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
-		int timer_every);
-
+// The service and compute streams start after what is queued on `stream` and `stream` waits for
+// them at the end; the host paces the local phases (see run_batches).  timer (mkv_timer_*)
+// brackets the local search launch of every timer_every-th batch, slot = i / timer_every.
 // Every way out of a failed run drains the device first: kernels and exchanges on the caller's
 // request and result buffers may still be in flight on the engine's streams.
 extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
-		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
-		int timer_every)
-{
-	const int rc = shard_run(e, nbatches, gets, n_get, sets, n_set, outs, stream, timer, timer_every);
-	if (rc != MKV_OK && e && e->comm)
-		(void)hipDeviceSynchronize();
-	return rc;
-}
-
-static int shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, const int64_t *n_get,
 		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
 		int timer_every)
 {
@@ -960,97 +753,18 @@ static int shard_run(mkv_shard *e, int nbatches, const selem_t *const *gets, con
 		return MKV_EINVAL;
 	if (nbatches == 0)
 		return MKV_OK;
-	hipStream_t main = (hipStream_t)stream;
-	const int L = e->nlanes;
 	if (g_trace.on < 0) {
 		const char *v = getenv("MKV_SHARD_TRACE");
 		g_trace.on = v ? atoi(v) : 0;
 	}
 	const int trace_from = g_trace.on > 0 && nbatches > g_trace.on + 16 ? nbatches - g_trace.on - 8 : nbatches + 1;
 	g_trace.n = 0;
-	int rc = MKV_OK;
-	if (e->sched_cs) {
-		rc = run_cs(e, nbatches, gets, n_get, sets, n_set, outs, main, timer, timer_every, trace_from);
-		if (rc == MKV_OK)
-			print_trace();
-		return rc;
-	}
-	if (e->fused) {
-		rc = run_fused(e, nbatches, gets, n_get, sets, n_set, outs, main, timer, timer_every, trace_from);
-		if (rc == MKV_OK)
-			print_trace();
-		return rc;
-	}
-	SH_HIP(e, hipEventRecord(e->ev_start, main));
-	for (int li = 0; li < L; li++)
-		SH_HIP(e, hipStreamWaitEvent(e->lane[li].stream, e->ev_start, 0));
-	// The local phases update ONE table in batch order.  On the lanes' own streams each would wait
-	// for the one before it through an event of ANOTHER stream -- 12 - 20 us of hand-over per batch
-	// on the critical path (MKV_SHARD_TRACE).  By default they all run on one stream of their own,
-	// back to back; what a local phase waits for there -- its requests packed and exchanged -- has
-	// been done for a whole local phase by then, and its lane's stream waits for IT before the
-	// results go back (MKV_SHARD_CSTREAM=0: the lanes' streams chained by events).
-	const bool cs = e->one_compute_stream != 0;
-	hipStream_t C = e->cstream;
-	if (cs)
-		SH_HIP(e, hipStreamWaitEvent(C, e->ev_start, 0));
-	// L batches in flight: the forward half of batch i+L-1 is queued before the local phase
-	// of batch i, so a lane has the time of L-1 local phases for its exchanges
-	for (int j = 0; j < L - 1 && j < nbatches; j++) {
-		Lane &lj = e->lane[j % L];
-		rc = forward(e, lj, gets[j], n_get[j], sets[j], n_set[j], j % L, j, false);
-		if (rc != MKV_OK)
-			return rc;
-		if (cs)
-			SH_HIP(e, hipEventRecord(lj.ev_recv[(j / L) & 1], lj.stream));
-	}
-	hipEvent_t prev_local = nullptr;
-	for (int i = 0; i < nbatches; i++) {
-		Lane &l = e->lane[i % L];
-		const bool tr = i >= trace_from && i < trace_from + g_trace.on;
-		const int j = i + L - 1;
-		if (j < nbatches) {
-			Lane &lj = e->lane[j % L];
-			rc = forward(e, lj, gets[j], n_get[j], sets[j], n_set[j], j % L, j, tr);
-			if (rc != MKV_OK)
-				return rc;
-			if (cs)
-				SH_HIP(e, hipEventRecord(lj.ev_recv[(j / L) & 1], lj.stream));
-		}
-		hipStream_t ls = cs ? C : l.stream;               // where this batch's local phase runs
-		if (cs)
-			SH_HIP(e, hipStreamWaitEvent(C, l.ev_recv[(i / L) & 1], 0));   // (also: the lane's un-pack of batch i-L is done)
-		else if (prev_local)
-			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
-		const bool timed = timer && timer_every > 0 && i % timer_every == 0;
-		{
-			Span sp("local", i % L, i, ls, tr);
-			rc = mkv_slots_cycle_self(&e->geom, l.recvbuf, e->world, e->cap_get, e->cap_set, l.out_slots, e->table,
-					e->cap_set ? l.set_ptrs : nullptr, (long long)e->n_set, ls, timed ? timer : nullptr,
-					timed ? i / timer_every : 0, e->self_direct ? e->rank : -1,
-					l.back_slots + (size_t)e->rank * (size_t)e->cap_get * 2u, nullptr);
-		}
-		if (rc != MKV_OK)
-			return fail(e, rc, "mkv_slots_cycle", nullptr);
-		prev_local = l.ev_local[(i / L) & 1];
-		SH_HIP(e, hipEventRecord(prev_local, ls));
-		if (cs)
-			SH_HIP(e, hipStreamWaitEvent(l.stream, prev_local, 0));
-		rc = backward(e, l, outs[i], n_get[i], i % L, i, tr);
-		if (rc != MKV_OK)
-			return rc;
-	}
-	for (int li = 0; li < L; li++) {
-		Lane &l = e->lane[li];
-		SH_HIP(e, hipEventRecord(l.ev_done, l.stream));
-		SH_HIP(e, hipStreamWaitEvent(main, l.ev_done, 0));
-	}
-	if (cs) {
-		SH_HIP(e, hipEventRecord(e->ev_cdone, C));
-		SH_HIP(e, hipStreamWaitEvent(main, e->ev_cdone, 0));
-	}
-	print_trace();
-	return MKV_OK;
+	const int rc = run_batches(e, nbatches, gets, n_get, sets, n_set, outs, (hipStream_t)stream, timer, timer_every, trace_from);
+	if (rc == MKV_OK)
+		print_trace();
+	else
+		(void)hipDeviceSynchronize();
+	return rc;
 }
 
 // synchronises; *flag = a slot overflowed since the engine was created (results invalid)

@@ -179,7 +179,6 @@ struct Ctl {
 	uint32_t chain_ok;               // chains committed optimistically
 	uint32_t bar_chain, bar_class;
 	uint32_t carry_lo;               // lowest request index carried over from earlier chunk passes (kNone: none)
-	uint32_t committed[2][kShards];
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
 	uint32_t sync[2];                // arrival counters of the tail launch's two grid-wide sync points
@@ -213,6 +212,12 @@ struct Ctl {
 	uint32_t tl_groups[2];               // work-groups of round 1 / round 2 of this pass
 	uint32_t tl_cnt[2][kTlGroups];       // entries a work-group left (may exceed kTlPer: not all listed)
 	uint32_t tl[2][kTlGroups][kTlPer];
+	// commit counters of rounds 1 / 2, one atomic per wave that committed anything: spread over kShards words
+	// on lines of their own -- 800 atomics on the four lines that 64 ADJACENT words make took 2.5 us to get
+	// through at the end of a round whose launch takes 9 (same-line atomics go one at a time, 12 ns apiece
+	// on an idle chip: profiles/r04_plan_ahead_experiment.txt)
+	// (at the end of the block: the fields before it keep offsets a load instruction can hold)
+	struct { uint32_t n; uint32_t pad[15]; } committed[2][kShards];
 };
 
 struct Req {
@@ -781,13 +786,13 @@ __device__ __forceinline__ void fold_max_dedup(const Fold &f, unsigned long long
 		atomicMax(&words[b], key);
 }
 
-// statistics: one atomic per wave, spread over kShards words
+// statistics: one atomic per wave, spread over kShards words 16 words apart (Ctl::committed)
 __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 {
 	for (int off = 32; off > 0; off >>= 1)
 		n += __shfl_down(n, off);
 	if ((threadIdx.x & 63u) == 0u && n)
-		atomicAdd(&shards[(blockIdx.x * 4u + (threadIdx.x >> 6)) & (kShards - 1)], n);
+		atomicAdd(&shards[((blockIdx.x * 4u + (threadIdx.x >> 6)) & (kShards - 1)) * 16u], n);
 }
 
 // Mark pass, cuckoo: a request that LOOKS hard in the table as it stands (P and A full,
@@ -879,8 +884,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	if (block == 0 && t < (uint32_t)kShards) {
 		// commit counters of the rounds that follow (the tail reads them: statistics, and how
 		// much it will have to gather); cleared here, by the kernel before them in the stream
-		ctl->committed[0][t] = 0;
-		ctl->committed[1][t] = 0;
+		ctl->committed[0][t].n = 0;
+		ctl->committed[1][t].n = 0;
 	}
 	const uint32_t end = hi_idx < total ? hi_idx : total;
 	// requests an earlier chunk pass of this call left unresolved ride along: they have
@@ -1182,22 +1187,41 @@ __device__ __forceinline__ void tail_list_add(uint32_t *s_tl, uint32_t *s_tln, u
 }
 
 template <int ROUND>
-__device__ __forceinline__ void tail_list_flush(Ctl *ctl, const uint32_t *s_tl, const uint32_t *s_tln)
+__device__ __forceinline__ void tail_list_flush(Ctl *ctl, const uint32_t *s_tl, const uint32_t *s_tln, uint32_t block,
+		uint32_t nblocks)
 {
 	__syncthreads();
-	if (blockIdx.x == 0 && threadIdx.x == 0)
-		ctl->tl_groups[ROUND - 1] = gridDim.x;
-	if (blockIdx.x < kTlGroups) {
+	if (block == 0 && threadIdx.x == 0)
+		ctl->tl_groups[ROUND - 1] = nblocks;
+	if (block < kTlGroups) {
 		const uint32_t n = *s_tln;
 		if (threadIdx.x < kTlPer && threadIdx.x < n)
-			ctl->tl[ROUND - 1][blockIdx.x][threadIdx.x] = s_tl[threadIdx.x];
+			ctl->tl[ROUND - 1][block][threadIdx.x] = s_tl[threadIdx.x];
 		if (threadIdx.x == 0)
-			ctl->tl_cnt[ROUND - 1][blockIdx.x] = n;
+			ctl->tl_cnt[ROUND - 1][block] = n;
 	}
 }
 
-template <Op OP, int ROUND>
-__global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
+// LDS of a round's work-group: the queue of held-back requests (QCAP entries; a turn adds at most one per
+// lane), round 1's two fold tables, the list for the tail.  Carved from a buffer the kernel declares (the
+// tail launch, which runs round 2 as its first phase, lays it over its work list).
+template <int ROUND, int QCAP>
+struct RoundLds {
+	static constexpr uint32_t kRFold = ROUND == 1 ? (1u << kMarkFoldLog2) : 1u;
+	static constexpr size_t q = 0;                                                  // uint4[QCAP]
+	static constexpr size_t ftk = q + sizeof(uint4) * QCAP;                         // unsigned long long[2 * kRFold]
+	static constexpr size_t qg = ftk + sizeof(unsigned long long) * 2u * kRFold;    // uint32_t[QCAP]
+	static constexpr size_t ftb = qg + sizeof(uint32_t) * QCAP;                     // uint32_t[2 * kRFold]
+	static constexpr size_t tl = ftb + sizeof(uint32_t) * 2u * kRFold;              // uint32_t[kTlPer]
+	static constexpr size_t words = tl + sizeof(uint32_t) * kTlPer;                 // s_qn, s_fused, s_tln
+	static constexpr size_t bytes = words + 4u * sizeof(uint32_t);
+};
+
+// (block of nblocks: the work-group's place among those that share the round -- the launch's own for
+// rounds launched by themselves)
+template <Op OP, int ROUND, int QCAP>
+__device__ __forceinline__ void round_body(const uint32_t block, const uint32_t nblocks, unsigned char *lds, Ctl *ctl,
+		const DevGeom &g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
 		unsigned long long *emax)
@@ -1207,7 +1231,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	// The first turn's request and tag are fetched before anything is known from the control block
 	// (one round trip less on the critical path of a launch that is all latency); used if the
 	// work-group's first index turns out to be what was guessed (no carried requests).
-	const uint32_t pre_base = lo_idx + blockIdx.x * blockDim.x;
+	const uint32_t pre_base = lo_idx + block * blockDim.x;
 	const uint32_t pre_idx = pre_base + threadIdx.x;
 	const bool pre_ok = pre_idx < req_cap && pre_idx >= lo_idx;
 	const uint8_t pre_st = pre_ok ? state[pre_idx] : (uint8_t)ST_DONE;
@@ -1216,12 +1240,12 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	const bool groups_on = (record_hint & 8) == 0;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
-	if (ROUND == 1 && blockIdx.x == 0 && threadIdx.x == 0)
+	if (ROUND == 1 && block == 0 && threadIdx.x == 0)
 		reset_tail_scratch(ctl);
 	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
 	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
-	const uint32_t span = gridDim.x * blockDim.x;
+	const uint32_t span = nblocks * blockDim.x;
 	uint32_t ndone = 0;
 	// owner table holding the round-1 registrations of every request of this pass (chains claim there)
 	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
@@ -1234,18 +1258,20 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	// wave for that long in every turn of the loop; phase 2 runs the queue on adjacent lanes, once
 	// per work-group (or whenever the queue could overflow).  Nothing else changes: a queued
 	// request owns P all along, and nobody may touch A unless he owns it.
-	__shared__ uint4 s_q[kDeferCap];
-	__shared__ uint32_t s_qg[kDeferCap];        // round 2: the last member of the group a queued request leads (kNone: none)
-	__shared__ uint32_t s_qn;
+	typedef RoundLds<ROUND, QCAP> Lds;
+	uint4 *s_q = reinterpret_cast<uint4 *>(lds + Lds::q);
+	uint32_t *s_qg = reinterpret_cast<uint32_t *>(lds + Lds::qg);   // round 2: the last member of the group a queued request leads (kNone: none)
+	uint32_t *s_words = reinterpret_cast<uint32_t *>(lds + Lds::words);
+	uint32_t &s_qn = s_words[0];
 	// Round 1, batches with many duplicates of a few keys (SETs drawn from a Zipf law: 36 000 of one key
 	// in 2^19): the losers' registrations for round 2 and the followers' election all aim at the words of
 	// those keys' buckets -- 226 us of queueing on a handful of addresses.  Waves with many losers
 	// send theirs through a hash table in LDS, flushed once per turn: one atomic per bucket and
 	// work-group (fold_min_dedup, as the mark pass does).
-	constexpr uint32_t kRFold = ROUND == 1 ? (1u << kMarkFoldLog2) : 1u;
-	__shared__ uint32_t s_ftb[2u * kRFold];
-	__shared__ unsigned long long s_ftk[2u * kRFold];
-	__shared__ uint32_t s_fused;
+	constexpr uint32_t kRFold = Lds::kRFold;
+	uint32_t *s_ftb = reinterpret_cast<uint32_t *>(lds + Lds::ftb);
+	unsigned long long *s_ftk = reinterpret_cast<unsigned long long *>(lds + Lds::ftk);
+	uint32_t &s_fused = s_words[1];
 	Fold fmin, fmax;
 	fmin.tb = s_ftb;
 	fmin.tc = nullptr;
@@ -1253,7 +1279,8 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	fmax.tb = s_ftb + kRFold;
 	fmax.tc = nullptr;
 	fmax.tk = s_ftk + kRFold;
-	__shared__ uint32_t s_tl[kTlPer], s_tln;    // what this work-group leaves to the tail (tail_list_add)
+	uint32_t *s_tl = reinterpret_cast<uint32_t *>(lds + Lds::tl);   // what this work-group leaves to the tail (tail_list_add)
+	uint32_t &s_tln = s_words[2];
 	if (threadIdx.x == 0) {
 		s_qn = 0u;
 		s_fused = 0u;
@@ -1269,7 +1296,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 	uint4 *reqw = const_cast<uint4 *>(reqc);    // (the flag word of a request's cache entry is written here)
 	// whole waves go round together (the re-registration folds the atomics of lanes on one
 	// bucket): the loop variable is the work-group's first index
-	uint32_t base = start + blockIdx.x * blockDim.x;
+	uint32_t base = start + block * blockDim.x;
 	for (bool more = base < count && base >= start; ; ) {
 		if (more) {
 			const uint32_t idx = base + threadIdx.x;
@@ -1390,7 +1417,7 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			__syncthreads();
 		}
 		const uint32_t qn = s_qn;
-		if (more && qn + blockDim.x <= (uint32_t)kDeferCap)
+		if (more && qn + blockDim.x <= (uint32_t)QCAP)
 			continue;                                   // room for another turn's worth
 		// phase 2: the queued requests, one per lane
 		for (uint32_t q0 = 0; q0 < qn; q0 += blockDim.x) {
@@ -1491,8 +1518,20 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 			s_qn = 0u;
 		__syncthreads();
 	}
-	count_add(ctl->committed[ROUND - 1], ndone);
-	tail_list_flush<ROUND>(ctl, s_tl, &s_tln);
+	count_add(&ctl->committed[ROUND - 1][0].n, ndone);
+	tail_list_flush<ROUND>(ctl, s_tl, &s_tln, block, nblocks);
+}
+
+
+template <Op OP, int ROUND>
+__global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
+		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
+		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
+		unsigned long long *emax)
+{
+	__shared__ __align__(16) unsigned char lds[RoundLds<ROUND, kDeferCap>::bytes];
+	round_body<OP, ROUND, kDeferCap>(blockIdx.x, gridDim.x, lds, ctl, g, table, owner, owner_next, reqc, state, undo,
+			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax);
 }
 
 // ---- order validation of eviction chains that run late ------------------------------
@@ -3117,6 +3156,87 @@ __device__ __forceinline__ void truncate_groups(uint32_t *table, uint8_t *state,
 	__syncthreads();
 }
 
+// What the tail launch leaves in the control block for the diagnostics and for the next pass: run
+// by work-group 0 when everything is done -- or at once, when the rounds left nothing to do.
+template <bool IDLE>     // (IDLE: the launch found nothing to do -- no phase has taken any time)
+__device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ticks, uint32_t rounds_total,
+		uint32_t total_all, uint32_t par, uint32_t serial, uint32_t undone, uint32_t viols, int first_chunk, int last_chunk,
+		uint32_t *host_flag)
+{
+	const uint32_t t = threadIdx.x;
+	if (t < 64) {
+		// statistics shards: one wave sums them
+		uint32_t c1 = ctl->committed[0][t].n, c2 = ctl->committed[1][t].n;      // (cleared by the next mark pass)
+		for (int off = 32; off > 0; off >>= 1) {
+			c1 += __shfl_down(c1, off);
+			c2 += __shfl_down(c2, off);
+		}
+		if (t == 0) {
+			ctl->last.round1 = (first_chunk ? 0u : ctl->last.round1) + c1;
+			ctl->last.round2 = (first_chunk ? 0u : ctl->last.round2) + c2;
+		}
+	}
+	if (t == 0) {
+		// diagnostics of this call (summed over its chunks), then the control block of the next pass
+		for (int k = 0; k < 16; k++)
+			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + (IDLE ? 0u : phase_ticks[k]);
+		for (int k = 0; k < 8; k++) {                  // (diagnostic counts ride in the slots of the grid-wide rounds' ticks)
+			ctl->tail_phase[8 + k] += ctl->dbg[k] * 100u;
+			ctl->dbg[k] = 0;
+		}
+		ctl->last.total = total_all;
+		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + par;
+		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + serial;
+		ctl->last.undone = (first_chunk ? 0u : ctl->last.undone) + undone;
+		ctl->last.tail_rounds = (first_chunk ? 0u : ctl->last.tail_rounds) + rounds_total;
+		const uint32_t fh = ctl->first_hard;
+		ctl->last.first_hard = first_chunk ? fh : (fh < ctl->last.first_hard ? fh : ctl->last.first_hard);
+		ctl->last.overflow = ctl->overflow;
+		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
+		// (the two "barrier" fields of the diagnostics now count: order violations handled, and hard
+		// requests the grid-wide rounds left to the tail)
+		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + viols;
+		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->hard_tail;
+		// word 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
+		// an order violation grows with the square of the pass size); word 1: the 40-bit round stamps
+		// are nearly used up -- the host clears the reservation tables before a later call
+		// (ensure_ws); word 2: batches that exceeded the workspace and were dropped, so far.  Only
+		// this kernel writes the words; the host only reads them.
+		if (last_chunk)
+			ctl->late_score = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? kLateSticky :
+					(ctl->late_score ? ctl->late_score - 1u : 0u);
+		if (last_chunk && host_flag) {
+			// (a store to host memory makes the end of this kernel wait for the PCIe write: 4 us between
+			// this launch and the next search, every step -- the words are written when they change)
+			const uint32_t f0 = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u;
+			const uint32_t f1 = ctl->stamp_base > kStampMax - kStampReserve ? 1u : 0u;
+			if (f0 != ctl->hf_last[0]) {
+				host_flag[0] = f0;
+				ctl->hf_last[0] = f0;
+			}
+			if (f1 != ctl->hf_last[1]) {
+				host_flag[1] = f1;
+				ctl->hf_last[1] = f1;
+			}
+			if (ctl->overflow)
+				host_flag[2] = host_flag[2] + 1u;
+		}
+		ctl->hard_tail = 0;
+		ctl->chain_n = 0;
+		ctl->chain_ok = 0;
+		ctl->any_loser = 0;
+		ctl->any_tail = 0;
+		ctl->any_hard = 0;
+		ctl->first_hard = kNone;
+		ctl->total = 0;
+		// stamps: rounds 1 and 2, what the tail's rounds took, one spare
+		const unsigned long long st = ctl->stamp_base + 3ull + rounds_total;
+		ctl->stamp_base = st;
+		ctl->next_stamp = st;
+		ctl->carry_lo = kNone;
+	}
+}
+
 // ---- the tail launch ----------------------------------------------------------------------
 // Finishes what rounds 1 and 2 left: losers of both rounds and hard requests whose chain
 // could not run beside the other requests.  All work-groups share the scans when there is
@@ -3149,6 +3269,14 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	uint32_t phase_ticks[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #define MKV_PHASE(k) do { const unsigned long long now_ = wall_clock64(); phase_ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
 	const uint32_t total_all = ctl->total;
+	// The rounds left nothing (the usual batch, three passes in four): no lists, no scans, no meetings --
+	// every work-group reads the one flag (final: only kernels before this one in the stream set it) and
+	// work-group 0 leaves the control block ready for the next pass.
+	if (ctl->any_tail == 0u) {
+		if (wg == 0)
+			tail_epilogue<true>(ctl, nullptr, 0u, total_all, 0u, 0u, 0u, 0u, first_chunk, last_chunk, host_flag);
+		return;
+	}
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
 	const uint32_t carry_in = ctl->carry_lo;
 	// what the grid-wide rounds left, listed by themselves (tail_list_add) -- unless a work-group left
@@ -3198,7 +3326,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// that pays -- judged by what every work-group reads alike: the rounds' flags and commit
 	// counters (final: only the kernels before this one in the stream change them).
 	if (t < 64u) {
-		uint32_t c = ctl->committed[0][t] + ctl->committed[1][t];
+		uint32_t c = ctl->committed[0][t].n + ctl->committed[1][t].n;
 		for (int off = 32; off > 0; off >>= 1)
 			c += __shfl_down(c, off);
 		if (t == 0)
@@ -3474,77 +3602,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		MKV_PHASE(3);
 	}
 	__syncthreads();
-	if (t < 64) {
-		// statistics shards: one wave sums them
-		uint32_t c1 = ctl->committed[0][t], c2 = ctl->committed[1][t];      // (cleared by the next mark pass)
-		for (int off = 32; off > 0; off >>= 1) {
-			c1 += __shfl_down(c1, off);
-			c2 += __shfl_down(c2, off);
-		}
-		if (t == 0) {
-			ctl->last.round1 = (first_chunk ? 0u : ctl->last.round1) + c1;
-			ctl->last.round2 = (first_chunk ? 0u : ctl->last.round2) + c2;
-		}
-	}
-	if (t == 0) {
-		// diagnostics of this call (summed over its chunks), then the control block of the next pass
-		for (int k = 0; k < 16; k++)
-			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + phase_ticks[k];
-		for (int k = 0; k < 8; k++) {                  // (diagnostic counts ride in the slots of the grid-wide rounds' ticks)
-			ctl->tail_phase[8 + k] += ctl->dbg[k] * 100u;
-			ctl->dbg[k] = 0;
-		}
-		ctl->last.total = total_all;
-		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + s_par;
-		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + s_serial;
-		ctl->last.undone = (first_chunk ? 0u : ctl->last.undone) + s_undone;
-		ctl->last.tail_rounds = (first_chunk ? 0u : ctl->last.tail_rounds) + rounds_total;
-		const uint32_t fh = ctl->first_hard;
-		ctl->last.first_hard = first_chunk ? fh : (fh < ctl->last.first_hard ? fh : ctl->last.first_hard);
-		ctl->last.overflow = ctl->overflow;
-		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
-		// (the two "barrier" fields of the diagnostics now count: order violations handled, and hard
-		// requests the grid-wide rounds left to the tail)
-		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + s_viols;
-		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->hard_tail;
-		// word 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
-		// an order violation grows with the square of the pass size); word 1: the 40-bit round stamps
-		// are nearly used up -- the host clears the reservation tables before a later call
-		// (ensure_ws); word 2: batches that exceeded the workspace and were dropped, so far.  Only
-		// this kernel writes the words; the host only reads them.
-		if (last_chunk)
-			ctl->late_score = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? kLateSticky :
-					(ctl->late_score ? ctl->late_score - 1u : 0u);
-		if (last_chunk && host_flag) {
-			// (a store to host memory makes the end of this kernel wait for the PCIe write: 4 us between
-			// this launch and the next search, every step -- the words are written when they change)
-			const uint32_t f0 = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u;
-			const uint32_t f1 = ctl->stamp_base > kStampMax - kStampReserve ? 1u : 0u;
-			if (f0 != ctl->hf_last[0]) {
-				host_flag[0] = f0;
-				ctl->hf_last[0] = f0;
-			}
-			if (f1 != ctl->hf_last[1]) {
-				host_flag[1] = f1;
-				ctl->hf_last[1] = f1;
-			}
-			if (ctl->overflow)
-				host_flag[2] = host_flag[2] + 1u;
-		}
-		ctl->hard_tail = 0;
-		ctl->chain_n = 0;
-		ctl->chain_ok = 0;
-		ctl->any_loser = 0;
-		ctl->any_tail = 0;
-		ctl->any_hard = 0;
-		ctl->first_hard = kNone;
-		ctl->total = 0;
-		// stamps: rounds 1 and 2, what the tail's rounds took, one spare
-		const unsigned long long st = ctl->stamp_base + 3ull + rounds_total;
-		ctl->stamp_base = st;
-		ctl->next_stamp = st;
-		ctl->carry_lo = kNone;
-	}
+	tail_epilogue<false>(ctl, phase_ticks, rounds_total, total_all, s_par, s_serial, s_undone, s_viols, first_chunk, last_chunk,
+			host_flag);
 }
 
 __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *host_flag)
@@ -3559,7 +3618,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->overflow = 0;
 		ctl->any_loser = ctl->any_tail = 0;
 		for (int k = 0; k < kShards; k++)
-			ctl->committed[0][k] = ctl->committed[1][k] = 0;
+			ctl->committed[0][k].n = ctl->committed[1][k].n = 0;
 		ctl->first_hard = kNone;
 		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0, 0};
 		ctl->bar_chain = ctl->bar_class = 0;
@@ -3798,6 +3857,22 @@ static std::recursive_mutex g_call_mutex;
 struct CallGuard {
 	std::lock_guard<std::recursive_mutex> lock{g_call_mutex};
 };
+}  // namespace mkv
+
+// mkv_cycle (mkv_abi.hip) holds the turn over ALL its parts: its fused search launch fills the
+// device's cycle workspace and its rounds, enqueued two calls later, run over it -- another thread's
+// cycle must not get in between (nor grow the workspace under it).
+extern "C" void mkv_call_lock(void)
+{
+	mkv::g_call_mutex.lock();
+}
+
+extern "C" void mkv_call_unlock(void)
+{
+	mkv::g_call_mutex.unlock();
+}
+
+namespace mkv {
 
 static int order_updates(hipStream_t stream)
 {
@@ -4249,7 +4324,9 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 	if (size_hint > mkv::kMaxReqCap)
 		return MKV_ETOOBIG;
 	// (no ordering against other streams here: the callers of this entry point -- the sharded
-	// engines -- run the local phases of their lanes' streams in batch order with events of their own)
+	// engines -- run the local phases of their lanes' streams in batch order with events of their own;
+	// host threads take turns for the enqueueing like everywhere else)
+	mkv::CallGuard call;
 	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(src, size_hint), s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;

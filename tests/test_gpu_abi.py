@@ -241,3 +241,66 @@ def test_host_threads_updating_their_own_tables_share_the_workspace():
             else:
                 O.insert(og, exp, [e])
         assert np.array_equal(idxs[th].table_numpy(), exp), f"thread {th}: table differs"
+
+
+def test_host_threads_running_cycles_share_the_cycle_workspace():
+    """Four host threads, each with a stream and a table of its own, run mkv_cycle (search + delete +
+    insert, the insert's mark pass -- and without deletes its round 1 -- inside the search launch) at
+    the same time.  A cycle keeps the device's cycle workspace from its fused launch to its rounds,
+    which are enqueued by later parts of the call: the whole call is one turn.  Every table and every
+    result equals the oracle's for the thread's own calls."""
+    import threading
+    import torch
+    import megakv_amd as M
+    from oracle import oracle as O
+    nthreads, calls = 4, 12
+    g = M.Geometry(mem_p=18)
+    og = O.geom(mem_p=18)
+    idxs = [M.HashIndex(g) for _ in range(nthreads)]
+    streams = [torch.cuda.Stream() for _ in range(nthreads)]
+    plans, staged = [], [[] for _ in range(nthreads)]
+    for th in range(nthreads):
+        rng = np.random.default_rng(300 + th)
+        pool = rng.integers(1, 2**32, size=(12000, 3), dtype=np.uint64).astype(np.uint32)
+        plan = []
+        for call in range(calls):
+            e = pool[rng.integers(0, len(pool), size=5000)].copy()
+            e[:, 2] = rng.integers(1, 2**32, size=len(e), dtype=np.uint64)
+            q = np.ascontiguousarray(pool[rng.integers(0, len(pool), size=7000), :2])
+            d = pool[rng.integers(0, len(pool), size=(700 if call % 3 == 2 else 0))].copy()
+            plan.append((q, np.ascontiguousarray(d), np.ascontiguousarray(e)))
+        plans.append(plan)
+        for q, d, e in plan:                                # staged before the threads start: only library calls race
+            tq = torch.from_numpy(q.view(np.int32)).cuda()
+            td = torch.from_numpy(d.view(np.int32)).cuda() if len(d) else None
+            te = torch.from_numpy(e.view(np.int32)).cuda()
+            out = torch.full((len(q), 2), 0x5555, dtype=torch.int32, device="cuda")
+            staged[th].append((tq, td, te, out, idxs[th].stage_blocks([te])))
+    torch.cuda.synchronize()
+    errors = []
+    start = threading.Barrier(nthreads)
+
+    def work(th):
+        try:
+            start.wait()
+            for (q, d, e), (tq, td, te, out, (ptrs, cnts, keep)) in zip(plans[th], staged[th]):
+                idxs[th].cycle(tq, out, ptrs, cnts, len(keep), delem=td, stream=streams[th], insert_hint=len(e))
+        except Exception as ex:                             # noqa: BLE001
+            errors.append((th, repr(ex)))
+
+    ts = [threading.Thread(target=work, args=(th,)) for th in range(nthreads)]
+    for t in ts:
+        t.start()
+    for t in ts:
+        t.join()
+    torch.cuda.synchronize()
+    assert not errors, errors
+    for th in range(nthreads):
+        exp = O.new_table(og)
+        for (q, d, e), (tq, td, te, out, _) in zip(plans[th], staged[th]):
+            want = O.search(og, exp, q)
+            assert np.array_equal(out.cpu().numpy().view(np.uint32), want), f"thread {th}: results differ"
+            if len(d):
+                O.delete(og, exp, d)
+            O.insert(og, exp, [e])
+        assert np.array_equal(idxs[th].table_numpy(), exp), f"thread {th}: table differs"

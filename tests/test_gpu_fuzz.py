@@ -162,6 +162,22 @@ def test_fuzz_cycles(seed):
     """mkv_cycle (search + delete + insert of one worker in one call, the insert's mark pass
     inside the search launch: the path bench.py measures) over random geometries, tables,
     request mixes and launch variants, several cycles in a row against the oracle."""
+    _run_cycles(seed, deletes=True)
+
+
+@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_NODEL_CASES", "24"))))
+def test_fuzz_cycles_without_deletes(seed):
+    """The same without deletes, always fused, one pass -- the shape of bench.py's step -- on 1, 3, 40
+    or 128 mark work-groups."""
+    L = load_library()
+    L.mkv_set_tuning(b"mark_blocks", int(np.random.default_rng(13000 + seed).choice([1, 3, 40, 128])))
+    try:
+        _run_cycles(seed, deletes=False)
+    finally:
+        L.mkv_set_tuning(b"mark_blocks", 128)
+
+
+def _run_cycles(seed, deletes):
     rng = np.random.default_rng(9000 + seed)
     L = load_library()
     mem_p = int(rng.integers(10, 19))
@@ -173,6 +189,8 @@ def test_fuzz_cycles(seed):
     L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 8192, 65536])))
     L.mkv_set_tuning(b"tail_groups", int(rng.choice([1, 5, 32])))
     L.mkv_set_tuning(b"grid_min", int(rng.choice([0, 64, 2048])))
+    if not deletes:
+        L.mkv_set_tuning(b"insert_chunk", 65536)     # (one pass)
     sig_space = int(rng.choice([40, 5000, 1 << 20]))
     exp = random_table(g, rng, float(rng.choice([0.0, 0.3, 0.7, 0.9])), sig_space)
     idx = HashIndex(g)
@@ -180,11 +198,15 @@ def test_fuzz_cycles(seed):
     nslots = g.nbuckets * 8
     memset = bool(rng.integers(0, 2))
     overlap = str(rng.choice(["fused", "fused", "side", "none"]))
+    if not deletes:
+        memset, overlap = False, "fused"
     stream = torch.cuda.Stream()
     with torch.cuda.stream(stream):
         for step in range(3):
             nq = int(rng.integers(0, 20000))
             nd = int(rng.integers(0, 3000))
+            if not deletes:
+                nq, nd = max(nq, 1), 0
             ni = int(rng.integers(0, max(2, min(30000, nslots))))
             hot = float(rng.choice([0.0, 0.1, 0.5]))
             q = random_requests(g, rng, nq, sig_space, hot=hot, zeros=float(rng.choice([0.0, 0.03])))[:, :2].copy()

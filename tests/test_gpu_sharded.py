@@ -97,8 +97,8 @@ def test_pack_layout(g, n_get, n_set, three_pass):
         L.mkv_set_tuning(b"pack_three_pass", 0)
 
 
-@pytest.mark.parametrize("scheme,sched,selfd", [(0, "cs", 1), (1, "cs", 1), (0, "cs", 0), (0, "plain", 1), (1, "plain", 0), (0, "fused", 0)])
-def test_native_engine_one_rank_through_rccl(scheme, sched, selfd, monkeypatch):
+@pytest.mark.parametrize("scheme,selfd", [(0, 1), (1, 1), (0, 0), (1, 0)])
+def test_native_engine_one_rank_through_rccl(scheme, selfd, monkeypatch):
     """The C engine (mkv_shard_*: pack, ncclAllToAll, local search+insert, result exchange,
     unpack; two batches in flight) with a one-rank communicator -- the only RCCL shape a
     one-GPU box can run -- against the oracle, results and final table."""
@@ -107,9 +107,7 @@ def test_native_engine_one_rank_through_rccl(scheme, sched, selfd, monkeypatch):
     from bench import late_imports, sharded_engine as ShardedIndex
     from oracle import oracle as O
     late_imports()
-    monkeypatch.setenv("MKV_SHARD_SCHED", sched)           # the engine reads it when it is created
-    monkeypatch.setenv("MKV_SHARD_SELF", str(selfd))       # 0: the own slot through ncclAllToAll like the peers'
-    monkeypatch.delenv("MKV_SHARD_FUSED", raising=False)
+    monkeypatch.setenv("MKV_SHARD_SELF", str(selfd))       # (the engine reads it when it is created) 0: the own slot through ncclAllToAll like the peers'
     mem_p = 16
     rng = np.random.default_rng(77 + scheme)
     n_get, n_set = 6000, 900
@@ -145,37 +143,34 @@ def test_native_engine_one_rank_through_rccl(scheme, sched, selfd, monkeypatch):
         sh.native.close()
 
 
-@pytest.mark.parametrize("world,sched,scheme,lanes,cstream,selfd,svc", [
-    # the default schedule (run_cs: local phases on one stream, the rest of a batch on a service stream, three
-    # buffer sets, the own slot past the exchange, the peers' slots by grouped send / receive) and its variants
-    (4, "cs", 0, 3, 1, 1, 2), (8, "cs", 0, 3, 1, 1, 2), (2, "cs", 1, 3, 1, 1, 1), (8, "cs", 0, 2, 1, 1, 1), (4, "cs", 0, 4, 1, 1, 3),
-    (4, "cs", 0, 3, 1, 0, 2), (8, "cs", 0, 3, 1, 0, 1), (8, "cs", 0, 2, 1, 1, 2),
-    # the older ones
-    (4, "fused", 0, 2, 0, 1, 1), (4, "plain", 0, 2, 0, 1, 1), (8, "fused", 0, 2, 0, 1, 1), (2, "fused", 1, 2, 0, 1, 1),
-    (4, "fused", 0, 3, 0, 1, 1), (4, "fused", 0, 2, 1, 1, 1), (2, "fused", 0, 4, 1, 1, 1), (4, "plain", 0, 3, 0, 1, 1),
-    (4, "plain", 0, 3, 1, 1, 1), (8, "plain", 0, 2, 1, 0, 1), (8, "plain", 0, 2, 0, 0, 1)])
-def test_native_engine_schedule_with_several_slots(world, sched, scheme, lanes, cstream, selfd, svc, monkeypatch):
-    """The C engine's W-rank schedules (run_fused: one grouped exchange per batch, packs on
-    a stream of their own into alternating `where` arrays; and the plain two-lane one) with
-    every peer looped back to this process (two to four batches in flight, local phases on the
-    lanes' streams or on one of their own): W slots per batch, a different `where` array for
-    every batch, batches of different sizes, results of EVERY batch and the final table
-    against the oracle (canonical order of the local table = slot, then batch index).  Wrong
-    event placement between un-pack and the pack two batches on shows here."""
+@pytest.mark.parametrize("world,scheme,lanes,selfd,svc,paced,delay_us", [
+    # the schedule (local phases on one stream, the rest of a batch on a service stream, three buffer sets,
+    # the own slot past the exchange, the peers' slots by grouped send / receive) and its variants
+    (4, 0, 3, 1, 2, 1, 0), (8, 0, 3, 1, 2, 1, 0), (2, 1, 3, 1, 1, 1, 0), (8, 0, 2, 1, 1, 1, 0), (4, 0, 4, 1, 3, 1, 0),
+    (4, 0, 3, 0, 2, 1, 0), (8, 0, 3, 0, 1, 1, 0), (8, 0, 2, 1, 2, 1, 0), (2, 0, 2, 1, 1, 1, 0), (4, 1, 2, 0, 1, 1, 0),
+    # the un-pack of a batch held back (a slow or skewed exchange) while the stream, not the host, paces the
+    # local phases: the local phase of the batch B later writes this rank's own answers while that un-pack
+    # has not read its batch's yet -- into the buffer of the other parity
+    (4, 0, 3, 1, 2, 0, 150), (8, 0, 2, 1, 1, 0, 150), (2, 1, 2, 1, 1, 0, 300), (4, 0, 3, 1, 2, 1, 150), (8, 0, 3, 0, 2, 0, 150)])
+def test_native_engine_schedule_with_several_slots(world, scheme, lanes, selfd, svc, paced, delay_us, monkeypatch):
+    """The C engine's W-rank schedule with every peer looped back to this process (two to four
+    batches in flight): W slots per batch, a different `where` array for every batch, batches of
+    different sizes, results of EVERY batch and the final table against the oracle (canonical
+    order of the local table = slot, then batch index).  Wrong event placement between un-pack,
+    the local phase and the pack of later batches shows here."""
     import numpy as np
     import torch
     from bench import late_imports, sharded_engine as ShardedIndex
     from oracle import oracle as O
     late_imports()
-    monkeypatch.setenv("MKV_SHARD_SCHED", sched)
-    monkeypatch.delenv("MKV_SHARD_FUSED", raising=False)
-    monkeypatch.setenv("MKV_SHARD_SVC", str(svc))              # service streams of the default schedule
+    monkeypatch.setenv("MKV_SHARD_SVC", str(svc))              # service streams
     monkeypatch.setenv("MKV_SHARD_LANES", str(lanes))          # batches in flight
-    monkeypatch.setenv("MKV_SHARD_CSTREAM", str(cstream))      # local phases on a stream of their own
-    monkeypatch.setenv("MKV_SHARD_SELF", str(selfd))           # the rank's own slot bypasses the exchange (plain schedule)
+    monkeypatch.setenv("MKV_SHARD_SELF", str(selfd))           # the rank's own slot bypasses the exchange
+    monkeypatch.setenv("MKV_SHARD_PACED", str(paced))          # 0: the compute stream waits for the requests' event itself
+    monkeypatch.setenv("MKV_SHARD_DELAY_UNPACK_US", str(delay_us))
     mem_p = 18
     k = world.bit_length() - 1
-    rng = np.random.default_rng(500 + world + len(sched))
+    rng = np.random.default_rng(500 + world + 2 * lanes)
     n_get, n_set = 60000, 6000
     sh = ShardedIndex(mem_p, world, 0, scheme, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6)
     sh.enable_native(None, loopback=True)

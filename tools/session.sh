@@ -1,8 +1,10 @@
 #!/bin/bash
 # One GPU session (gpurun -- bash tools/session.sh): rewritten for every call; what it printed is kept
 # under gpurun_out/.
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s3; mkdir -p $d
-run() { name=$1; shift; env "$@" timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu --no-pcie --update-info > $d/$name.json 2> $d/$name.err; \
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s13; mkdir -p $d
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $d/pytest.txt 2>&1
+grep -E "passed|failed|error" $d/pytest.txt | tail -3
+run() { name=$1; shift; env "$@" > $d/$name.json 2> $d/$name.err; \
 	python - $d/$name.json $name <<'PY'
 import json, sys
 try:
@@ -12,13 +14,15 @@ except Exception as e:
     print(sys.argv[2], "bad", e)
 PY
 }
-# search occupancy: blocks per CU limited by dynamic LDS (12.3 KB static): 160 KB / (12.3 + x)
-run occ_base MKV_PLAN=0
-run occ_6 MKV_PLAN=0 MKV_DBG_DYNLDS=14000
-run occ_5 MKV_PLAN=0 MKV_DBG_DYNLDS=20000
-run occ_4 MKV_PLAN=0 MKV_DBG_DYNLDS=28000
-run occ_3 MKV_PLAN=0 MKV_DBG_DYNLDS=41000
-run occ_2 MKV_PLAN=0 MKV_DBG_DYNLDS=52000
-run occ_base2 MKV_PLAN=0
-run u2_occ4 MKV_PLAN=0 MKV_DBG_DYNLDS=28000 MKV_MARK_BLOCKS=256
-run mb256 MKV_PLAN=0 MKV_MARK_BLOCKS=256
+B="timeout 300 python bench.py --steps 20 --warmup 5 --no-cpu --no-pcie"
+run drv1 $B
+run drv2 $B
+run def1 timeout 300 python bench.py --no-cpu --no-pcie
+run supd $B --sets upd
+run z50 $B --workload zipf50
+run z50upd $B --workload zipf50 --sets upd
+run lf05 $B --lf 0.5
+run sh1 $B --force-sharded
+run get100 $B --workload get100
+bash tools/gpu_trace.sh base --steps 20 --warmup 5 > $d/trace.txt 2>&1; head -9 $d/trace.txt
+timeout 200 python tools/loopback_trace.py 8 2>&1 | tail -5
