@@ -102,6 +102,10 @@ struct Tuning {
 	int dup_groups;         // duplicates of a key inside one pass are settled as a group in round 2 (kFollowBit); 0: off
 	int lazy_alt;           // a request whose primary bucket shows at least this many free slots at mark time does
 	                        // not register on its alternate bucket (0: every request registers on both)
+	int self_help;          // round 1: a bucket's second-lowest registrant commits beside the lowest one when it can tell
+	                        // what that one will do there (self-help, mkv_update.hip); 0: it waits for round 2
+	int merge_round2;       // round 2 runs as the first phase of the tail launch (0: a launch of its own, as before)
+	long long merge_max;    // ... for passes announced with at most this many requests
 	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)
 	int debug_skip;      // tests only (results unchanged): how the tail deals with an order violation --
 	                     // 0 as designed, 1 always the general way (resolve_violations), 2 always the

@@ -155,6 +155,12 @@ Tuning &tuning()
 		s = getenv("MKV_LAZY_ALT");
 		v.lazy_alt = s ? atoi(s) : 2;
 		if (v.lazy_alt < 0 || v.lazy_alt > 8) v.lazy_alt = 2;
+		s = getenv("MKV_SELF_HELP");
+		v.self_help = s ? atoi(s) != 0 : 1;
+		s = getenv("MKV_MERGE_ROUND2");
+		v.merge_round2 = s ? atoi(s) : 1;      // (2: even when round 1 has been leaving round 2 a lot)
+		s = getenv("MKV_MERGE_MAX");
+		v.merge_max = s ? atoll(s) : 131072;
 		s = getenv("MKV_INSERT_CHUNK");
 		v.insert_chunk = s ? atoll(s) : 524288;
 		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
@@ -269,6 +275,12 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 0 || value > 8)
 			return MKV_EINVAL;
 		t.lazy_alt = (int)value;
+	} else if (!strcmp(name, "self_help")) {
+		t.self_help = value != 0;
+	} else if (!strcmp(name, "merge_round2")) {
+		t.merge_round2 = (int)value;
+	} else if (!strcmp(name, "merge_max")) {
+		t.merge_max = value;
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
 	} else if (!strcmp(name, "req_cap")) {

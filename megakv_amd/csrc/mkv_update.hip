@@ -99,6 +99,7 @@ constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (
                                     // launch stays free of scratch memory and calls)
 constexpr uint32_t kLateSticky = 16; // calls for which a call whose chains ran late counts as "chains lately" (diagnostics)
 constexpr int kDeferCap = 768;           // k_round: requests a work-group may hold back for its second phase
+constexpr uint32_t kMergeLosersMax = 2048;   // round 2 runs inside the tail launch while round 1 leaves it at most this many requests
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 
@@ -152,6 +153,7 @@ struct Info {
 	uint32_t total, round1, round2, tail_parallel, tail_serial, undone, first_hard, overflow, chains,
 			bar_chain, bar_class;   // barriers published by failed chains / by classification
 	uint32_t tail_rounds;       // rounds the tail launches ran, summed over the call's passes
+	uint32_t helped, losers;    // round 1: second registrants that helped themselves; requests it left to round 2
 };
 
 // Log of an optimistic eviction chain: every word it overwrote, in order.
@@ -182,6 +184,7 @@ struct Ctl {
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
 	uint32_t sync[2];                // arrival counters of the tail launch's two grid-wide sync points
+	uint32_t sync_r2;                // ... and of the meeting behind a round 2 that ran as the launch's first phase
 	uint32_t glist_n;                // entries of the tail's global work list
 	uint32_t carry_next;             // lowest index the tail leaves pending (next pass's carry_lo)
 	uint32_t undone_acc;             // roll-backs done by the tail's helper work-groups
@@ -201,6 +204,7 @@ struct Ctl {
 	uint32_t late_score;             // > 0: chains ran late in one of the last kLateSticky calls (persists across calls)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t hf_last[2];             // what the host-mapped flag words hold (they are written only when they change)
+	uint32_t hf_losers;              // ... and word 3: round 1 left many requests to round 2 in the last pass
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
@@ -217,7 +221,7 @@ struct Ctl {
 	// through at the end of a round whose launch takes 9 (same-line atomics go one at a time, 12 ns apiece
 	// on an idle chip: profiles/r04_plan_ahead_experiment.txt)
 	// (at the end of the block: the fields before it keep offsets a load instruction can hold)
-	struct { uint32_t n; uint32_t pad[15]; } committed[2][kShards];
+	struct { uint32_t n; uint32_t pad[15]; } committed[4][kShards];     // ([2]: round 1's self-help commits, [3]: its losers)
 };
 
 struct Req {
@@ -786,6 +790,135 @@ __device__ __forceinline__ void fold_max_dedup(const Fold &f, unsigned long long
 		atomicMax(&words[b], key);
 }
 
+// ---- the SECOND-lowest registrant of a bucket (mark pass) ---------------------------------------
+// Round 1 lets the second-lowest registrant j of a bucket P commit beside the lowest one, c, when it can
+// tell what c will do there (self-help, round_body).  For that j must KNOW it is the second: every
+// registration of the mark pass -- primary bucket, alternate bucket, the pre-walk's chain buckets -- is a
+// RETURNING atomicMin, and whoever sees two keys of this pass on a bucket (its own and the one it
+// displaced or lost to) enters the larger one in a second table, `second`, with another atomicMin.
+// Every registrant but the lowest is the larger one of such a pair at some point (it finds a smaller key
+// there, or is displaced by one later), so second[b] ends up holding the lowest of them: the second-lowest
+// registrant.  Where registrations are folded -- the lanes of a wave on one bucket, the entries of a
+// work-group's table -- the fold keeps the two lowest keys it has seen and hands both on.  (The insert
+// blocks of a batch are its closed regions: two requests of one bucket are 6 500 indices apart at most,
+// not 52 000, and meet in one work-group's turn of 256 four times in a hundred.)
+__device__ __forceinline__ void note_second(unsigned long long *second, uint32_t b, unsigned long long old,
+		unsigned long long key)
+{
+	// (same stamp field: an entry of this pass)
+	if ((old >> kIdxBits) == (key >> kIdxBits) && old != key)
+		atomicMin(&second[b], old > key ? old : key);
+}
+
+// key2: a key the caller knows to be another, higher registrant of the bucket (~0: none)
+__device__ __forceinline__ void register_one(unsigned long long *owner, unsigned long long *second, uint32_t b,
+		unsigned long long key, unsigned long long key2 = ~0ull)
+{
+	note_second(second, b, atomicMin(&owner[b], key), key);
+	if (key2 != ~0ull)
+		atomicMin(&second[b], key2);
+}
+
+// the two lowest keys among the lanes of the wave for which `same` holds
+__device__ __forceinline__ void wave_two_lowest(unsigned long long key, bool same, unsigned long long &k, unsigned long long &k2)
+{
+	k = same ? key : ~0ull;
+	for (int off = 32; off > 0; off >>= 1) {
+		const unsigned long long o = __shfl_xor(k, off);
+		k = o < k ? o : k;
+	}
+	k2 = (same && key != k) ? key : ~0ull;
+	for (int off = 32; off > 0; off >>= 1) {
+		const unsigned long long o = __shfl_xor(k2, off);
+		k2 = o < k2 ? o : k2;
+	}
+}
+
+// atomic_min_dedup with the second table behind it (mark pass without the fold table)
+__device__ __forceinline__ void register_dedup(unsigned long long *owner, unsigned long long *second, uint32_t b,
+		unsigned long long key, bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		unsigned long long k = key, k2 = ~0ull;
+		if (__popcll(__ballot(same)) > 1)
+			wave_two_lowest(key, same, k, k2);
+		if ((int)(threadIdx.x & 63u) == first)
+			register_one(owner, second, fb, k, k2);
+		active = active && !same;
+	}
+	if (active)
+		register_one(owner, second, b, key);
+}
+
+// fold_enter / fold_min_dedup / fold_flush of the mark pass with the second table behind them: a slot
+// keeps the lowest key entered (tk) and the lowest of the others (tk2)
+template <int LOG2>
+__device__ __forceinline__ bool mark_fold_enter(const Fold &f, unsigned long long *tk2, uint32_t b, unsigned long long key,
+		unsigned long long key2)
+{
+	uint32_t slot = (b * 2654435761u) >> (32 - LOG2);
+	for (int probe = 0; probe < 2; probe++) {
+		const uint32_t old = atomicCAS(&f.tb[slot], kNone, b);
+		if (old == kNone || old == b) {
+			const unsigned long long prev = atomicMin(&f.tk[slot], key);
+			unsigned long long other = prev == ~0ull ? ~0ull : (prev > key ? prev : key);
+			other = key2 < other ? key2 : other;
+			if (other != ~0ull)
+				atomicMin(&tk2[slot], other);
+			return true;
+		}
+		slot = (slot + 1u) & ((1u << LOG2) - 1u);
+	}
+	return false;
+}
+
+template <int LOG2>
+__device__ __forceinline__ void mark_fold_min_dedup(const Fold &f, unsigned long long *tk2, unsigned long long *owner,
+		unsigned long long *second, uint32_t b, unsigned long long key, bool active)
+{
+#pragma unroll
+	for (int peel = 0; peel < 2; peel++) {
+		const unsigned long long pend = __ballot(active);
+		if (!pend)
+			return;
+		const int first = __ffsll((long long)pend) - 1;
+		const uint32_t fb = __shfl(b, first);
+		const bool same = active && b == fb;
+		unsigned long long k = key, k2 = ~0ull;
+		if (__popcll(__ballot(same)) > 1)
+			wave_two_lowest(key, same, k, k2);
+		if ((int)(threadIdx.x & 63u) == first && !mark_fold_enter<LOG2>(f, tk2, fb, k, k2))
+			register_one(owner, second, fb, k, k2);
+		active = active && !same;
+	}
+	if (active && !mark_fold_enter<LOG2>(f, tk2, b, key, ~0ull))
+		register_one(owner, second, b, key);
+}
+
+template <int LOG2>
+__device__ __forceinline__ void mark_fold_flush(const Fold &f, unsigned long long *tk2, unsigned long long *owner,
+		unsigned long long *second)
+{
+	__syncthreads();
+	for (uint32_t s = threadIdx.x; s < (1u << LOG2); s += blockDim.x) {
+		const uint32_t b = f.tb[s];
+		if (b != kNone) {
+			register_one(owner, second, b, f.tk[s], tk2[s]);
+			f.tb[s] = kNone;
+			tk2[s] = ~0ull;
+		}
+		f.tk[s] = ~0ull;
+	}
+	__syncthreads();
+}
+
 // statistics: one atomic per wave, spread over kShards words 16 words apart (Ctl::committed)
 __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 {
@@ -803,7 +936,7 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 // through the ordinary reservation instead of being committed under the chain's feet.  Only
 // a hint: nothing depends on the walk being right (the table may change before the turn).
 __device__ __forceinline__ void prewalk_register(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P,
-		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi)
+		uint32_t A, unsigned long long *owner, unsigned long long *second, unsigned long long key, uint4 lo, uint4 hi)
 {
 	// (lo, hi: the signature row of P, loaded by the caller)
 	if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
@@ -819,7 +952,7 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 		const uint32_t a = (v & 1u) ? q.y : q.x, c = (v & 1u) ? q.w : q.z;
 		const uint32_t vsig = (v & 2u) ? c : a;
 		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (ref :334)
-		atomicMin(&owner[nb], key);
+		register_one(owner, second, nb, key);
 		load_sig_row<false>(table, nb, lo, hi);
 		if (eq_mask(lo, hi, vsig) | eq_mask(lo, hi, 0u))
 			return;
@@ -829,7 +962,7 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 // ---- K1: mark -----------------------------------------------------------------
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
-		const DevGeom &g, unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap,
+		const DevGeom &g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap,
 		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, uint32_t lazy_free)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
@@ -846,8 +979,12 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	fold.tk = reinterpret_cast<unsigned long long *>(s_ptr + kMarkFoldBlocks);
 	fold.tb = reinterpret_cast<uint32_t *>(fold.tk + (1u << kMarkFoldLog2));
 	fold.tc = nullptr;
-	if (use_fold)
+	__shared__ unsigned long long s_tk2[1u << kMarkFoldLog2];      // (the fold's second-lowest keys: mark_fold_enter)
+	if (use_fold) {
+		for (uint32_t q = threadIdx.x; q < (1u << kMarkFoldLog2); q += blockDim.x)
+			s_tk2[q] = ~0ull;
 		fold_clear<false, kMarkFoldLog2>(fold);
+	}
 	const uint32_t t = threadIdx.x;
 	const uint32_t nblk = src.nblk;
 	const unsigned long long stamp = ctl->stamp_base;
@@ -886,6 +1023,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		// much it will have to gather); cleared here, by the kernel before them in the stream
 		ctl->committed[0][t].n = 0;
 		ctl->committed[1][t].n = 0;
+		ctl->committed[2][t].n = 0;
+		ctl->committed[3][t].n = 0;
 	}
 	const uint32_t end = hi_idx < total ? hi_idx : total;
 	// requests an earlier chunk pass of this call left unresolved ride along: they have
@@ -959,16 +1098,17 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		if (fresh)
 			reqc[idx] = make_uint4(rq.sig, rq.hash, rq.loc, lazy ? kLazyBit : 0u);
 		const unsigned long long key = owner_key(stamp, idx);
+		// (every registration notes the bucket's second-lowest registrant: note_second)
 		if (use_fold) {
-			fold_min_dedup<kMarkFoldLog2>(fold, owner, P, key, live);
-			fold_min_dedup<kMarkFoldLog2>(fold, owner, A, key, live && A != P && !lazy);
-			fold_flush<false, false, kMarkFoldLog2>(fold, owner, nullptr, stamp);
+			mark_fold_min_dedup<kMarkFoldLog2>(fold, s_tk2, owner, second, P, key, live);
+			mark_fold_min_dedup<kMarkFoldLog2>(fold, s_tk2, owner, second, A, key, live && A != P && !lazy);
+			mark_fold_flush<kMarkFoldLog2>(fold, s_tk2, owner, second);
 		} else {
-			atomic_min_dedup(owner, P, key, live);
-			atomic_min_dedup(owner, A, key, live && A != P && !lazy);
+			register_dedup(owner, second, P, key, live);
+			register_dedup(owner, second, A, key, live && A != P && !lazy);
 		}
 		if (OP == OP_CUCKOO && live && table && !lazy)
-			prewalk_register(table, g, rq, P, A, owner, key, plo, phi);
+			prewalk_register(table, g, rq, P, A, owner, second, key, plo, phi);
 	}
 }
 
@@ -1076,10 +1216,10 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 
 template <Op OP>
 __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
-		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
+		unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
 		uint32_t hi_idx, const uint32_t *table, int lazy_on)
 {
-	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, reqc, state, req_cap, lo_idx, hi_idx, table, (uint32_t)lazy_on);
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, second, reqc, state, req_cap, lo_idx, hi_idx, table, (uint32_t)lazy_on);
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -1088,13 +1228,13 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 template <Op OP>
 __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ in,
 		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n, uint32_t search_blocks,
-		Ctl *ctl, ReqSrc src, DevGeom g, unsigned long long *owner, uint4 *reqc, uint8_t *state,
+		Ctl *ctl, ReqSrc src, DevGeom g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state,
 		uint32_t req_cap, uint32_t hi_idx, int lazy_on)
 {
 	// mark blocks first: they are few and latency-bound, let them start early
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
-		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
 				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on);
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
@@ -1106,12 +1246,12 @@ template <Op OP>
 __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__restrict__ recvbuf,
 		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
 		uint32_t chunks_per_slot, uint32_t search_blocks, Ctl *ctl, ReqSrc src, DevGeom g,
-		unsigned long long *owner, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx,
+		unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx,
 		uint32_t self, uint32_t *__restrict__ self_out, int lazy_on)
 {
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
-		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, reqc, state, req_cap, 0u, hi_idx,
+		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
 				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on);
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
@@ -1224,8 +1364,9 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		const DevGeom &g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax)
+		unsigned long long *emax, const unsigned long long *second)
 {
+	// (second: the mark pass's second-lowest registrant per bucket, note_second)
 	// (emax: a word per bucket -- the followers of a bucket's round-1 owner elect the last of them there,
 	// kFollowBit; the tail's elections use the same words under its own, later stamps)
 	// The first turn's request and tag are fetched before anything is known from the control block
@@ -1238,6 +1379,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	const uint4 pre_rc = pre_ok ? reqc[pre_idx] : make_uint4(0u, 0u, 0u, 0u);
 	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
 	const bool groups_on = (record_hint & 8) == 0;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
+	const bool help_on = (record_hint & 32) == 0;         // Tuning::self_help = 0: the second registrant waits for round 2, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
 	if (ROUND == 1 && block == 0 && threadIdx.x == 0)
@@ -1246,7 +1388,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
 	const uint32_t span = nblocks * blockDim.x;
-	uint32_t ndone = 0;
+	uint32_t ndone = 0, ndone_help = 0, nlosers = 0;
 	// owner table holding the round-1 registrations of every request of this pass (chains claim there)
 	unsigned long long *owner_r1 = ROUND == 1 ? const_cast<unsigned long long *>(owner) : owner_next;
 	const uint32_t carry = ctl->carry_lo;
@@ -1359,12 +1501,82 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 					// the bucket's lowest registrant holds the same key: round 1, this request is a follower
 					// of it; round 2, a shadow of it if that one is a follower too (it will write for both)
 					const uint32_t c = (uint32_t)(oP & ((1ull << kIdxBits) - 1ull));
-					if (OP != OP_DELETE && groups_on && r.sig != 0u && c < idx && (ROUND == 1 || (rc.w & kFollowBit))) {
+					const bool look = OP != OP_DELETE && r.sig != 0u && c < idx;
+					if (look && ((ROUND == 1 && (groups_on || help_on)) || (groups_on && (rc.w & kFollowBit)))) {
 						const uint4 rj = reqc[c];
 						const bool same = rj.x == r.sig && ((rj.y ^ r.hash) & g.hash_mask) == 0u;   // (the table's notion of a key: signature and bucket)
-						follower = ROUND == 1 && same;
+						follower = ROUND == 1 && groups_on && same;
 						shadow = ROUND == 2 && same && (rj.w & kFollowBit);
 						lead_of = c;
+						// SELF-HELP (round 1).  This request is the bucket's SECOND-lowest registrant (second[P]: nobody
+						// of the pass stands between the owner c and it, on any account: note_second), P is the primary
+						// bucket of both, and their signatures differ.  Then what c does here is known: it is the lowest
+						// registrant of its primary bucket, so it runs apply_primary on P in this very round -- a duplicate
+						// of its signature gets its location, else the preferred empty slot gets the entry -- whatever
+						// this request stores meanwhile (other words; and taking one other empty slot away does not
+						// change which one c prefers).  So this request commits NOW, on P as c will have left it, instead
+						// of losing to c and coming again in round 2: the signature row it has loaded holds c's new entry
+						// already or not yet, which it can tell (c's signature is in the row or it is not).  The commit
+						// counts as a round-2 commit: tagged ROUND2 and registered in the round-2 table, where this
+						// request is the lowest registrant of P (the other losers of P are later ones) -- who asks for
+						// commits on P finds it by the round-2 table as ever, and a request that comes to P unregistered
+						// finds it through second[P] (later_commit_from).  Not when c finds P full (it may go on to
+						// evict from P), not for signature 0 (it "matches" empty slots: the two would share words).
+						// (second[P] is asked for here, with the owner's request, not beside the reservation: fetched
+						// by every lane of a 52 K pass it cost 1.2 us more than the losers' extra round trip.)
+						if (ROUND == 1 && help_on && !same && rj.x != 0u && rj.x != r.sig && (rj.y & g.hash_mask) == P &&
+								second[P] == key) {
+							uint4 s0 = kP.s0, s1 = kP.s1;
+							bool ok = true;
+							if (!eq_mask(s0, s1, rj.x)) {
+								const uint32_t e = eq_mask(s0, s1, 0u);
+								if (e) {
+									// (c's new entry, not in the row yet: its slot is taken)
+									const uint32_t sc = preferred_slot(e, rj.x);
+									s0.x = sc == 0u ? rj.x : s0.x;
+									s0.y = sc == 1u ? rj.x : s0.y;
+									s0.z = sc == 2u ? rj.x : s0.z;
+									s0.w = sc == 3u ? rj.x : s0.w;
+									s1.x = sc == 4u ? rj.x : s1.x;
+									s1.y = sc == 5u ? rj.x : s1.y;
+									s1.z = sc == 6u ? rj.x : s1.z;
+									s1.w = sc == 7u ? rj.x : s1.w;
+								} else {
+									ok = false;
+								}
+							}
+							if (ok) {
+								Undo u;
+								u.word1 = kNoWord;
+								u.old1 = 0u;
+								const uint32_t m = eq_mask(s0, s1, r.sig);
+								const uint32_t e = eq_mask(s0, s1, 0u);
+								if (m) {
+									const uint32_t sl = (uint32_t)__ffs((int)m) - 1u;
+									u.word0 = (uint32_t)loc_word(P, sl);
+									u.old0 = loc_at(kP, sl);
+									table[u.word0] = r.loc;
+								} else if (e) {
+									const uint32_t sl = preferred_slot(e, r.sig);
+									u.word0 = (uint32_t)sig_word(P, sl);
+									u.old0 = 0u;
+									u.word1 = (uint32_t)loc_word(P, sl);
+									u.old1 = loc_at(kP, sl);
+									table[u.word0] = r.sig;
+									table[u.word1] = r.loc;
+								} else {
+									ok = false;
+								}
+								if (ok) {
+									undo[idx] = u;
+									state[idx] = ST_ROUND2;
+									atomicMin(&owner_next[P], owner_key(stamp + 1, idx));
+									ndone_help++;
+									lose = false;
+									follower = false;
+								}
+							}
+						}
 					}
 				}
 			}
@@ -1397,6 +1609,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 					undo[idx].word0 = lead_of;      // (not counted as finished by this round: it may come back)
 				} else {
 					state[idx] = ROUND == 1 ? ST_LOSER : ST_TAIL;
+					nlosers++;
 					if (ROUND == 1)
 						ctl->any_loser = 1u;
 					else
@@ -1447,6 +1660,11 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 				const uint32_t c1 = (v1 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v1 & ((1ull << kIdxBits) - 1ull)) : kNone;
 				uint32_t e1 = 0;
 				late = c1 != kNone && round_commit_used(state, reqc, undo, chain_logs, g, c1, A, &e1) && e1 > idx;
+				// ... or by the bucket's second registrant helping itself there in round 1 (self-help above)
+				const unsigned long long v3 = second[A];
+				const uint32_t c3 = (v3 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v3 & ((1ull << kIdxBits) - 1ull)) : kNone;
+				if (!late && c3 != kNone && c3 != c1 && c3 > idx)
+					late = round_commit_used(state, reqc, undo, chain_logs, g, c3, A, &e1) && e1 > idx;
 			}
 			if (live && !late && (A == P || owner[A] == key)) {
 				Undo u;
@@ -1497,6 +1715,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			}
 			if (lose) {
 				state[idx] = ST_LOSER;
+				nlosers++;
 				ctl->any_loser = 1u;
 			}
 			if (to_tail) {
@@ -1519,6 +1738,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		__syncthreads();
 	}
 	count_add(&ctl->committed[ROUND - 1][0].n, ndone);
+	if (ROUND == 1 && help_on) {
+		count_add(&ctl->committed[1][0].n, ndone_help);
+		count_add(&ctl->committed[2][0].n, ndone_help);
+	}
+	if (ROUND == 1)
+		count_add(&ctl->committed[3][0].n, nlosers);
 	tail_list_flush<ROUND>(ctl, s_tl, &s_tln, block, nblocks);
 }
 
@@ -1527,11 +1752,11 @@ template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax)
+		unsigned long long *emax, const unsigned long long *second)
 {
 	__shared__ __align__(16) unsigned char lds[RoundLds<ROUND, kDeferCap>::bytes];
 	round_body<OP, ROUND, kDeferCap>(blockIdx.x, gridDim.x, lds, ctl, g, table, owner, owner_next, reqc, state, undo,
-			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax);
+			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax, second);
 }
 
 // ---- order validation of eviction chains that run late ------------------------------
@@ -1553,17 +1778,14 @@ __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *ta
 struct Tv {
 	const unsigned long long *owner1;    // round-1 reservations of this pass (and every chain's claims)
 	const unsigned long long *owner2;    // round-2 reservations
+	const unsigned long long *second;    // the mark pass's second-lowest registrant per bucket: round 1 may have let it help itself
 	unsigned long long stamp1;           // round-1 stamp of this pass (round 2: + 1)
 	const uint8_t *state;
 	const uint4 *reqc;
 	const Undo *undo;
-	const ChainLog *chain_logs;
-	uint32_t *viol;                      // per region: lowest violating index
-	uint32_t *flags;                     // bit 0: violation recorded
-	uint32_t *vlist_n;                   // violations of this turn: {index of the chain's request, bucket}
-	uint2 *vlist;
-	ChainLog *lane_logs;                 // one log per lane of the tail launch (apply_serial_checked)
-	uint32_t *dbg;
+	const ChainLog *chain_logs;          // (behind the kChainLogCap logs of the rounds: one log per lane of the tail launch)
+	Ctl *ctl;                            // violations are noted there: viol[] per region (lowest violating index), tflags
+	                                     // (bit 0: one was recorded), vlist_n / vlist (this turn's: {index, bucket}); dbg[]
 };
 constexpr uint32_t kTvViolation = 1u;
 
@@ -1592,32 +1814,39 @@ __device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint
 	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b, eff);
 }
 
-// the two candidates of bucket b from its reservation words (kNone: none of this pass)
-__device__ __forceinline__ void candidates_of(const Tv &tv, unsigned long long v1, unsigned long long v2, uint32_t &c1,
-		uint32_t &c2)
+// the candidates of bucket b from its reservation words (kNone: none of this pass): its lowest registrant of
+// round 1, of round 2, and the mark pass's second-lowest (a self-help commit of round 1 -- which also
+// stands in the round-2 table, but a request that came to the bucket unregistered may stand before it there)
+__device__ __forceinline__ void candidates_of(const Tv &tv, unsigned long long v1, unsigned long long v2,
+		unsigned long long v3, uint32_t &c1, uint32_t &c2, uint32_t &c3)
 {
 	const unsigned long long f1 = kStampMax - tv.stamp1, f2 = kStampMax - (tv.stamp1 + 1ull);
 	c1 = (v1 >> kIdxBits) == f1 ? (uint32_t)(v1 & ((1ull << kIdxBits) - 1ull)) : kNone;
 	c2 = (v2 >> kIdxBits) == f2 ? (uint32_t)(v2 & ((1ull << kIdxBits) - 1ull)) : kNone;
+	c3 = (v3 >> kIdxBits) == f1 ? (uint32_t)(v3 & ((1ull << kIdxBits) - 1ull)) : kNone;
+	if (c3 == c1 || c3 == c2)
+		c3 = kNone;
 }
 
 // a commit later than idx on bucket b (its index), or kNone -- from reservation words the caller
 // has loaded beside its other accesses to the bucket
 __device__ __forceinline__ uint32_t later_commit_from(const Tv &tv, const DevGeom &g, uint32_t b, unsigned long long v1,
-		unsigned long long v2, uint32_t idx)
+		unsigned long long v2, unsigned long long v3, uint32_t idx)
 {
-	uint32_t c1, c2, e = 0;
-	candidates_of(tv, v1, v2, c1, c2);
+	uint32_t c1, c2, c3, e = 0;
+	candidates_of(tv, v1, v2, v3, c1, c2, c3);
 	if (c1 != kNone && commit_used(tv, g, c1, b, &e) && e > idx)
 		return c1;
 	if (c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx)
 		return c2;
+	if (c3 != kNone && commit_used(tv, g, c3, b, &e) && e > idx)
+		return c3;
 	return kNone;
 }
 
 __device__ __forceinline__ uint32_t later_commit_on(const Tv &tv, const DevGeom &g, uint32_t b, uint32_t idx)
 {
-	return later_commit_from(tv, g, b, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), idx);
+	return later_commit_from(tv, g, b, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), ld_agent(&tv.second[b]), idx);
 }
 
 // A commit on bucket b that has to come after request idx AND does not commute with it: any later
@@ -1630,11 +1859,13 @@ __device__ __forceinline__ uint32_t later_commit_on(const Tv &tv, const DevGeom 
 // group's entry for its duplicate (same signature from another bucket pair).
 __device__ __forceinline__ bool conflict_on(const Tv &tv, const DevGeom &g, uint32_t b, uint32_t idx, uint32_t sig, bool any)
 {
-	uint32_t c1, c2, e = 0;
-	candidates_of(tv, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), c1, c2);
+	uint32_t c1, c2, c3, e = 0;
+	candidates_of(tv, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), ld_agent(&tv.second[b]), c1, c2, c3);
 	if (c1 != kNone && commit_used(tv, g, c1, b, &e) && e > idx && (any || tv.reqc[c1].x == sig))
 		return true;
-	return c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx && (any || tv.reqc[c2].x == sig);
+	if (c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx && (any || tv.reqc[c2].x == sig))
+		return true;
+	return c3 != kNone && commit_used(tv, g, c3, b, &e) && e > idx && (any || tv.reqc[c3].x == sig);
 }
 
 // The check a pending request makes ONCE (kCheckedBit), before anything later than it in its region
@@ -1661,11 +1892,11 @@ __device__ __forceinline__ void report_violation(const Tv &tv, const DevGeom &g,
 		uint32_t bucket)
 {
 	MKV_TR(3u, idx, bucket, P);
-	atomicMin(&tv.viol[P >> g.region_shift], idx);
-	const uint32_t at = atomicAdd(tv.vlist_n, 1u);
+	atomicMin(&tv.ctl->viol[P >> g.region_shift], idx);
+	const uint32_t at = atomicAdd(&tv.ctl->vlist_n, 1u);
 	if (at < (uint32_t)kViolCap)
-		tv.vlist[at] = make_uint2(idx, bucket);
-	atomicOr(tv.flags, kTvViolation);
+		tv.ctl->vlist[at] = make_uint2(idx, bucket);
+	atomicOr(&tv.ctl->tflags, kTvViolation);
 }
 
 // apply_static in the tail, for a request that may not have registered on its alternate bucket in
@@ -1726,7 +1957,7 @@ __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGe
 	// (apply_static_late does before it gives up)
 	// (the log lives in this lane's slot of global memory: local arrays would cost the launch its
 	// scratch-free dispatch)
-	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
+	ChainLog *L = const_cast<ChainLog *>(tv.chain_logs) + kChainLogCap + (blockIdx.x * blockDim.x + threadIdx.x);
 	uint32_t n = 0;
 	uint32_t sig = r.sig, loc = r.loc, b = A;
 	const uint32_t v = r.sig & 7u;          // victim slot: ORIGINAL signature (:360)
@@ -1757,6 +1988,14 @@ __device__ __forceinline__ int apply_serial_checked(uint32_t *table, const DevGe
 }
 
 // ---- K4: tail -------------------------------------------------------------------
+// (an index the compiler takes for new every time: the address built from it is not kept in a register
+// pair -- spilled to scratch memory, in this kernel -- across the launch's main loop)
+__device__ __forceinline__ uint32_t opaque(uint32_t v)
+{
+	asm volatile("" : "+v"(v));
+	return v;
+}
+
 __device__ __forceinline__ void wg_sync()
 {
 	__builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "workgroup");
@@ -1788,6 +2027,7 @@ __device__ __forceinline__ void grid_sync(uint32_t *counter, uint32_t nwg)
 __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 {
 	ctl->sync[0] = ctl->sync[1] = 0;
+	ctl->sync_r2 = 0;
 	ctl->g_sync = 0;
 	ctl->glist_n = 0;
 	ctl->loose = 0;
@@ -2023,32 +2263,32 @@ __device__ __forceinline__ bool walk_and_claim(const uint32_t *table, const DevG
 			return true;                            // last eviction drops its victim: no further bucket
 		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);
 		if (nb == P || nb == A) {
-			atomicAdd(tv.dbg + 7, 1u);
+			atomicAdd(tv.ctl->dbg + 7, 1u);
 			return false;
 		}
 		for (uint32_t i = 0; i < nseen; i++)
 			if (seen[i] == nb) {
-				atomicAdd(tv.dbg + 7, 1u);
+				atomicAdd(tv.ctl->dbg + 7, 1u);
 				return false;
 			}
 		const unsigned long long old = atomicMin(&owner[nb], mykey);
-		const unsigned long long v1 = ld_agent(&tv.owner1[nb]), v2 = ld_agent(&tv.owner2[nb]);
+		const unsigned long long v1 = ld_agent(&tv.owner1[nb]), v2 = ld_agent(&tv.owner2[nb]), v3 = ld_agent(&tv.second[nb]);
 		uint4 lo, hi;
 		load_sig_row<true>(table, nb, lo, hi);
 		if ((old >> kIdxBits) == stamp_field && old != mykey) {
 			if (old < mykey) {
-				atomicAdd(tv.dbg + 3, 1u);
+				atomicAdd(tv.ctl->dbg + 3, 1u);
 				return false;                       // an earlier pending request is on nb: it goes first
 			}
 			// A LATER pending request was the lowest on nb: the bucket is taken over (the atomicMin
 			// has done that), and that request becomes a barrier of this round -- neither it nor
 			// anything behind it in the region commits now, whatever it concluded from the bucket's
 			// free slots and duplicates; it finds at commit time that it no longer owns the bucket.
-			atomicAdd(tv.dbg + 0, 1u);
+			atomicAdd(tv.ctl->dbg + 0, 1u);
 			atomicMin(&rbar[P >> g.region_shift], (uint32_t)(old & ((1ull << kIdxBits) - 1ull)));
 		}
 		// a later request of this pass was committed on nb by the grid-wide rounds: order violation
-		if (later_commit_from(tv, g, nb, v1, v2, idx) != kNone) {
+		if (later_commit_from(tv, g, nb, v1, v2, v3, idx) != kNone) {
 			report_violation(tv, g, P, idx, nb);
 			return false;
 		}
@@ -2078,7 +2318,7 @@ __device__ __forceinline__ bool run_owned_chain(uint32_t *table, const DevGeom &
 	uint32_t vloc = ld_agent32(table + loc_word(A, v));
 	if (oP != mykey || oA != mykey)
 		return false;
-	ChainLog *L = &tv.lane_logs[blockIdx.x * blockDim.x + threadIdx.x];
+	ChainLog *L = const_cast<ChainLog *>(tv.chain_logs) + kChainLogCap + (blockIdx.x * blockDim.x + threadIdx.x);
 	uint32_t n = 0;
 	uint32_t sig = r.sig, loc = r.loc, b = A;
 	for (uint32_t k = 0;; k++) {
@@ -2531,7 +2771,7 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 		recent = round == 0 ? progress : (3u * recent + progress) / 4u;
 		// an order violation blocks its region until the
 		// caller has dealt with it
-		if (progress == 0 || (round >= 3 && recent < kMinRoundProgress) || ld_agent32(tv.flags) != 0u)
+		if (progress == 0 || (round >= 3 && recent < kMinRoundProgress) || ld_agent32(&tv.ctl->tflags) != 0u)
 			break;
 	}
 	return left;
@@ -2552,9 +2792,13 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
 	fold_clear<false, kFoldLog2>(fold);
-	unsigned long long tick = wall_clock64();
 	// ticks[0..7]: register, its meeting, decide, its meeting, election + meeting, commit, its meeting
+#ifdef MKV_DIAGNOSTICS
+	unsigned long long tick = wall_clock64();
 #define MKV_GTICK(k) do { const unsigned long long now_ = wall_clock64(); ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
+#else
+#define MKV_GTICK(k) ((void)0)
+#endif
 	const unsigned long long stamp0 = ctl->stamp_base + 2 + stamp_skip;
 	unsigned long long *emax = cnt + ((size_t)g.hash_mask + 1u);   // election words behind the counts
 	uint32_t left = m, nth = 0, used = 0, par = 0, recent = 0;
@@ -2848,7 +3092,7 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 		// (the flags were last written before the meeting above: every work-group reads the same)
 		// (so few are left that one work-group takes them in one go: it continues alone, with barriers
 		// in place of the grid-wide meetings)
-		if (progress == 0 || (round >= 3 && recent < min_progress) || ld_agent32(tv.flags) != 0u ||
+		if (progress == 0 || (round >= 3 && recent < min_progress) || ld_agent32(&tv.ctl->tflags) != 0u ||
 				left <= kGridHandover)
 			break;
 	}
@@ -2885,9 +3129,9 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 	bool ok = true;
 	while (sp != 0u) {
 		const uint2 e = stack[--sp];
-		uint32_t cand[2];
-		candidates_of(tv, ld_agent(&tv.owner1[e.x]), ld_agent(&tv.owner2[e.x]), cand[0], cand[1]);
-		for (int ci = 0; ci < 2; ci++) {
+		uint32_t cand[3];
+		candidates_of(tv, ld_agent(&tv.owner1[e.x]), ld_agent(&tv.owner2[e.x]), ld_agent(&tv.second[e.x]), cand[0], cand[1], cand[2]);
+		for (int ci = 0; ci < 3; ci++) {
 			const uint32_t u = cand[ci];
 			uint32_t eff = 0;
 			if (u == kNone || (ci == 1 && u == cand[0]))
@@ -3171,15 +3415,29 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 			c1 += __shfl_down(c1, off);
 			c2 += __shfl_down(c2, off);
 		}
+		uint32_t c3 = ctl->committed[2][t].n, c4 = ctl->committed[3][t].n;
+		for (int off = 32; off > 0; off >>= 1) {
+			c3 += __shfl_down(c3, off);
+			c4 += __shfl_down(c4, off);
+		}
 		if (t == 0) {
 			ctl->last.round1 = (first_chunk ? 0u : ctl->last.round1) + c1;
 			ctl->last.round2 = (first_chunk ? 0u : ctl->last.round2) + c2;
+			ctl->last.helped = (first_chunk ? 0u : ctl->last.helped) + c3;
+			ctl->last.losers = (first_chunk ? 0u : ctl->last.losers) + c4;
+			// word 3 of the host's flags: round 1 left round 2 more than a handful -- the host then gives round 2
+			// a launch of its own (more lanes than this launch has) until a pass leaves few again
+			const uint32_t many = c4 > kMergeLosersMax ? 1u : 0u;
+			if (host_flag && many != ctl->hf_losers) {
+				host_flag[3] = many;
+				ctl->hf_losers = many;
+			}
 		}
 	}
 	if (t == 0) {
 		// diagnostics of this call (summed over its chunks), then the control block of the next pass
 		for (int k = 0; k < 16; k++)
-			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + (IDLE ? 0u : phase_ticks[k]);
+			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + ((IDLE || !phase_ticks) ? 0u : phase_ticks[k]);
 		for (int k = 0; k < 8; k++) {                  // (diagnostic counts ride in the slots of the grid-wide rounds' ticks)
 			ctl->tail_phase[8 + k] += ctl->dbg[k] * 100u;
 			ctl->dbg[k] = 0;
@@ -3247,11 +3505,17 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 template <Op OP>
 __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, const unsigned long long *owner1,
-		const unsigned long long *owner2, const uint4 *reqc, uint8_t *state, const Undo *undo, const ChainLog *chain_logs,
+		const unsigned long long *owner2, const unsigned long long *second, const uint4 *reqc, uint8_t *state, const Undo *undo,
+		const ChainLog *chain_logs,
 		uint32_t *glist, int max_rounds,
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
-		int dbg_path)
+		int dbg_path, int round2_hint, uint32_t req_cap)
 {
+	// (round2_hint >= 0: ROUND 2 runs here, as the launch's first phase, with that record_hint -- a launch that
+	// finds nothing to do costs 4.6 - 5 us in this chain, and since a bucket's second registrant helps itself
+	// in round 1 the usual batch leaves round 2 nothing: what is left of its losers takes the lanes of this
+	// launch and a meeting of its work-groups instead of a launch of its own.  A host that announces a pass
+	// of very many requests launches round 2 by itself as before: it wants more lanes than these.)
 	__shared__ __align__(16) uint32_t lkeys[kSortCap];
 	__shared__ __align__(16) uint8_t lreg[kSortCap];    // region of a listed request (in-order replay); in-group rounds: the duplicates' election
 	static_assert(2u * kElectSlots * sizeof(uint32_t) <= (size_t)kSortCap, "the election table lives in lreg");
@@ -3265,14 +3529,30 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+	// (time per phase: diagnostics builds only, make EXTRA=-DMKV_DIAGNOSTICS -- sixteen registers held for the whole
+	// launch are more than this kernel has to spare)
+#ifdef MKV_DIAGNOSTICS
 	unsigned long long tick = wall_clock64();
 	uint32_t phase_ticks[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #define MKV_PHASE(k) do { const unsigned long long now_ = wall_clock64(); phase_ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
+#else
+	uint32_t *const phase_ticks = nullptr;
+#define MKV_PHASE(k) ((void)0)
+#endif
 	const uint32_t total_all = ctl->total;
+	if (round2_hint >= 0 && OP != OP_DELETE && ctl->any_loser != 0u) {
+		// (every work-group reads the same flag: round 1, the kernel before, set it)
+		static_assert(RoundLds<2, kTailThreads>::bytes <= sizeof(lkeys), "round 2's LDS in the work list's");
+		round_body<OP, 2, kTailThreads>(wg, nwg, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
+				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
+				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second);
+		grid_sync(&ctl->sync_r2, nwg);
+	}
 	// The rounds left nothing (the usual batch, three passes in four): no lists, no scans, no meetings --
-	// every work-group reads the one flag (final: only kernels before this one in the stream set it) and
-	// work-group 0 leaves the control block ready for the next pass.
-	if (ctl->any_tail == 0u) {
+	// every work-group reads the one flag (final: only kernels before this one in the stream -- or the
+	// phase above, behind its meeting -- set it) and work-group 0 leaves the control block ready for the
+	// next pass.
+	if (ld_agent32(&ctl->any_tail) == 0u) {
 		if (wg == 0)
 			tail_epilogue<true>(ctl, nullptr, 0u, total_all, 0u, 0u, 0u, 0u, first_chunk, last_chunk, host_flag);
 		return;
@@ -3368,17 +3648,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	Tv tv;
 	tv.owner1 = owner1;
 	tv.owner2 = owner2;
+	tv.second = second;
 	tv.stamp1 = stamp1;
 	tv.state = state;
 	tv.reqc = reqc;
 	tv.undo = undo;
 	tv.chain_logs = chain_logs;
-	tv.viol = ctl->viol;
-	tv.flags = &ctl->tflags;
-	tv.vlist_n = &ctl->vlist_n;
-	tv.vlist = ctl->vlist;
-	tv.lane_logs = const_cast<ChainLog *>(chain_logs) + kChainLogCap;
-	tv.dbg = ctl->dbg;
+	tv.ctl = ctl;
 	uint32_t rounds_total = 0;
 	while (work_left) {
 		const uint32_t m = s_n;
@@ -3395,7 +3671,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
 			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
 			left = grid_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, glist, m, s_rbar, s_rmin, s_below, &s_progress,
-					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks + 8, tv, rounds_total, fold, grid_progress);
+					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks ? phase_ticks + 8 : nullptr, tv, rounds_total, fold, grid_progress);
 			if (wg != 0)
 				return;
 			grid_mode = false;                     // (later turns of this loop are work-group 0's alone)
@@ -3514,10 +3790,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			}
 			__syncthreads();
 			if (t < nseeds && dbg_path != 2) {
-				const uint32_t *sw = reinterpret_cast<const uint32_t *>(ctl->vlist + t);
+				const uint32_t *sw = reinterpret_cast<const uint32_t *>(ctl->vlist + opaque(t));
 				const uint32_t sj = ld_agent32(sw), sX = ld_agent32(sw + 1);
 				if (!select_from(g, state, reqc, undo, chain_logs, tv, sj, sX,
-						reinterpret_cast<uint2 *>(lkeys) + t * kLaneStack, sel, &s_nsel, s_trunc, &s_ntrunc))
+						reinterpret_cast<uint2 *>(lkeys) + opaque(t) * kLaneStack, sel, &s_nsel, s_trunc, &s_ntrunc))
 					s_dflag = 1u;
 			}
 			wg_sync();
@@ -3553,7 +3829,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				// a stack or the list overflowed: the whole suffix of the regions concerned
 				// (roll_back_from also takes back what is flagged already)
 				if (t < kMaxRegions)
-					s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[t]) : kNone;
+					s_thr[t] = t < g.nregions ? ld_agent32(&ctl->viol[opaque(t)]) : kNone;
 				__syncthreads();
 				if (t == 0)
 					s_ntrunc = 0u;                      // (what select_from noted is found again by index)
@@ -3588,7 +3864,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		if (t == 0)
 			s_n = 0;
 		if (t < kMaxRegions)
-			atomicExch(&ctl->viol[t], kNone);
+			atomicExch(&ctl->viol[opaque(t)], kNone);
 		if (t == 0) {
 			atomicExch(&ctl->tflags, 0u);
 			atomicExch(&ctl->vlist_n, 0u);
@@ -3611,16 +3887,16 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 	const uint32_t t = threadIdx.x;
 	if (t == 0) {
 		if (host_flag)
-			host_flag[0] = host_flag[1] = 0;     // (in step with hf_last below)
+			host_flag[0] = host_flag[1] = host_flag[3] = 0;     // (in step with hf_last / hf_losers below)
 		ctl->stamp_base = first_stamp;
 		ctl->next_stamp = first_stamp + kStampsPerCall;
 		ctl->total = 0;
 		ctl->overflow = 0;
 		ctl->any_loser = ctl->any_tail = 0;
 		for (int k = 0; k < kShards; k++)
-			ctl->committed[0][k].n = ctl->committed[1][k].n = 0;
+			ctl->committed[0][k].n = ctl->committed[1][k].n = ctl->committed[2][k].n = ctl->committed[3][k].n = 0;
 		ctl->first_hard = kNone;
-		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0, 0};
+		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0, 0, 0, 0};
 		ctl->bar_chain = ctl->bar_class = 0;
 		ctl->carry_lo = kNone;
 		ctl->chain_n = 0;
@@ -3630,6 +3906,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->hard_tail = 0;
 		ctl->late_score = 0;
 		ctl->hf_last[0] = ctl->hf_last[1] = 0;
+		ctl->hf_losers = 0;
 		for (int k = 0; k < 8; k++)
 			ctl->dbg[k] = 0;
 		reset_tail_scratch(ctl);
@@ -3653,7 +3930,7 @@ struct Workspace {
 	// left as those rounds wrote them until the pass is over: the tail reads from them who can have
 	// been committed where (later_commit_on) --, [2] the tail's rounds, [3] the tail's "lowest
 	// registrant that has the bucket as its alternate"
-	unsigned long long *owner[4] = {nullptr, nullptr, nullptr, nullptr};
+	unsigned long long *owner[5] = {nullptr, nullptr, nullptr, nullptr, nullptr};     // ([4]: the mark pass's second-lowest registrants)
 	unsigned long long *cnt = nullptr;
 	uint8_t *state = nullptr;
 	uint4 *reqc = nullptr;
@@ -3693,7 +3970,7 @@ static unsigned long long g_dropped_total = 0;   // batches dropped because they
 
 static void free_ws(Workspace *w)
 {
-	for (int i = 0; i < 4; i++)
+	for (int i = 0; i < 5; i++)
 		if (w->owner[i]) (void)hipFree(w->owner[i]);
 	if (w->cnt) (void)hipFree(w->cnt);
 	if (w->state) (void)hipFree(w->state);
@@ -3753,7 +4030,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 			// The flag is the kernel's to write; it reads 0 again once a call has run after the
 			// reset, until then it is not looked at.
 			bool ok = true;
-			for (int i = 0; i < 4; i++)
+			for (int i = 0; i < 5; i++)
 				ok = ok && hipMemsetAsync(w->owner[i], 0xff, w->nbuckets * 8, stream) == hipSuccess;
 			ok = ok && hipMemsetAsync(w->cnt, 0, w->nbuckets * 16, stream) == hipSuccess;
 			if (!ok)
@@ -3776,7 +4053,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	w->nbuckets = nb;
 	w->req_cap = rc;
 	bool ok = true;
-	for (int i = 0; i < 4 && ok; i++)
+	for (int i = 0; i < 5 && ok; i++)
 		ok = ok && hipMalloc(&w->owner[i], nb * 8) == hipSuccess;
 	ok = ok && hipMalloc(&w->cnt, nb * 16) == hipSuccess;     // registrant counts, then the election words
 	ok = ok && hipMalloc(&w->state, ((size_t)rc + 15) & ~(size_t)15) == hipSuccess;
@@ -3800,7 +4077,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	}
 	if (ok) {
 		// owner entries start at "no owner" (all ones); counters at zero
-		for (int i = 0; i < 4; i++)
+		for (int i = 0; i < 5; i++)
 			ok = ok && hipMemsetAsync(w->owner[i], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 16, stream) == hipSuccess;
 		if (ok)
@@ -3934,12 +4211,13 @@ static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipSt
 		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
 	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)tuning().mark_alone_blocks), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt);
+			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt);
 }
 
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
-		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1, hipEvent_t done_ev = nullptr);
+		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1, hipEvent_t done_ev = nullptr,
+		long long hint = 0);
 
 // Canonical-index passes of one call.  With a size hint from the caller a large batch runs
 // pass after pass (stream order = canonical order), Tuning::insert_chunk requests each; no
@@ -4034,7 +4312,7 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		uint32_t lo, hi;
 		chunk_range(c, ck, &lo, &hi);
 		launch_mark<OP>(w, g, src, stream, table, lo, hi);
-		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1);
+		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : hint);
 		if (rc != MKV_OK)
 			return rc;
 	}
@@ -4071,21 +4349,33 @@ static unsigned tail_groups_for()
 // the marker packet of its own (3 us between two kernels of a stream, tools/probes/event_probe.hip)
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
-		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev)
+		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev, long long hint)
 {
+	// (hint: the caller's upper bound on the pass's requests, 0 = unknown)
 	int tail_rounds = tuning().tail_rounds;
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
+	// what the rounds are told about the tuning: bit 2 -- every eviction chain left to the tail (tests);
+	// bit 3 -- no groups of duplicates; bit 5 -- no self-help of a bucket's second registrant
+	const int rhint = (tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32);
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			(tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8), w->cnt + ((size_t)g.hash_mask + 1u));
-	hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			(tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8), w->cnt + ((size_t)g.hash_mask + 1u));
+			rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4]);
+	// round 2: inside the tail launch (k_tail's first phase), unless the pass is announced with more
+	// requests than that launch has lanes for in a few turns, or is a delete
+	// (word 3 of the tail kernel's flags, read without synchronising -- a pass late, which only costs time:
+	// round 1 has been leaving round 2 a lot: duplicates of hot keys, say)
+	const bool merged = OP != OP_DELETE && tuning().merge_round2 != 0 && hint <= (long long)tuning().merge_max &&
+			!(w->host_flag && w->host_flag[3] && tuning().merge_round2 == 1);
+	if (!merged)
+		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
+				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
+				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4]);
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
-			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3);
+			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3,
+			merged ? rhint : -1, (uint32_t)w->req_cap);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -4211,11 +4501,11 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
-				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi,
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
 				mkv::tuning().lazy_alt);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, in2, out, t4, num_search,
-				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi,
+				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
 				mkv::tuning().lazy_alt);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
@@ -4242,7 +4532,6 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 	src.nblk = (uint32_t)num_blks;
 	src.cnt_stride = 1;
 	// chunk 0 was marked beside (or inside) the search launch; later chunks are marked here
-	(void)size_hint;
 	const mkv::Chunking ck = w->cycle_ck;
 	const int nchunks = ck.passes;
 	for (int c = 0; c < nchunks; c++) {
@@ -4251,11 +4540,11 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 		if (d.scheme == MKV_SCHEME_2CHOICE) {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint);
 		} else {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1);
+			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint);
 		}
 		if (rc != MKV_OK)
 			return rc;
@@ -4307,7 +4596,7 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 		mkv::ReqSrc none = {};
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), s, tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr,
 				recvbuf, slot_words, (uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks,
-				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (uint4 *)nullptr,
+				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint4 *)nullptr,
 				(uint8_t *)nullptr, 0u, 0u, self_u, self_out, 0);
 		if (done_event && hipEventRecord((hipEvent_t)done_event, s) != hipSuccess)
 			return MKV_EHIP;
@@ -4341,11 +4630,11 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 	if (cuckoo)
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
+				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
+				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
 		mkv::chunk_range(c, ck, &lo, &hi);
@@ -4353,11 +4642,11 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 		if (cuckoo) {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, dev);
+			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, dev, nchunks > 1 ? (long long)ck.step : size_hint);
 		} else {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, dev);
+			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, dev, nchunks > 1 ? (long long)ck.step : size_hint);
 		}
 		if (rc != MKV_OK)
 			return rc;
@@ -4457,7 +4746,7 @@ extern "C" long long mkv_workspace_bytes(void)
 		const mkv::Workspace *w = kv.second;
 		if (!w || w->device != dev)
 			continue;
-		total += (long long)w->nbuckets * 48 +
+		total += (long long)w->nbuckets * 56 +
 				(long long)w->req_cap * (1 + 16 + 16 + 4) +
 				(long long)(((size_t)mkv::kChainLogCap + mkv::kTailLanes) * sizeof(mkv::ChainLog)) + (long long)sizeof(mkv::Ctl);
 	}
@@ -4502,6 +4791,8 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->bar_chain = h.last.bar_chain;
 	info->bar_class = h.last.bar_class;
 	info->tail_rounds = h.last.tail_rounds;
+	info->helped = h.last.helped;
+	info->losers = h.last.losers;
 	return MKV_OK;
 }
 

@@ -20,7 +20,8 @@ class MkvUpdateInfo(ctypes.Structure):
     _fields_ = [("total", ctypes.c_uint32), ("round1", ctypes.c_uint32), ("round2", ctypes.c_uint32),
                 ("tail_parallel", ctypes.c_uint32), ("tail_serial", ctypes.c_uint32),
                 ("undone", ctypes.c_uint32), ("first_hard", ctypes.c_uint32), ("chains", ctypes.c_uint32),
-                ("bar_chain", ctypes.c_uint32), ("bar_class", ctypes.c_uint32), ("tail_rounds", ctypes.c_uint32)]
+                ("bar_chain", ctypes.c_uint32), ("bar_class", ctypes.c_uint32), ("tail_rounds", ctypes.c_uint32),
+                ("helped", ctypes.c_uint32), ("losers", ctypes.c_uint32)]
 
 
 # every symbol include/libgpuhash.h, include/megakv_hip.h and

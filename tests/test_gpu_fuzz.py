@@ -25,6 +25,8 @@ def _defaults():
     L.mkv_set_tuning(b"calm_factor", 4)
     L.mkv_set_tuning(b"debug_skip", 0)
     L.mkv_set_tuning(b"round_blocks", 512)
+    L.mkv_set_tuning(b"self_help", 1)
+    L.mkv_set_tuning(b"merge_round2", 1)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
@@ -105,7 +107,12 @@ def _run(seed, forced):
     L.mkv_set_tuning(b"debug_skip", int(rng3.choice([0, 0, 1, 2])) + int(rng3.choice([0, 0, 0, 4])))
     # work-groups of rounds 1 and 2: few make a work-group's queue of held-back requests run over
     L.mkv_set_tuning(b"round_blocks", int(rng3.choice([1, 3, 64, 512, 512])))
-    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"debug_skip", b"round_blocks"):   # bisecting aid
+    # round 1's self-help of a bucket's second registrant, round 2 inside the tail launch: on (the default) or off
+    rng4 = np.random.default_rng(17000 + seed)
+    L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
+    L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
+    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"debug_skip", b"round_blocks",
+                 b"self_help", b"merge_round2"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
             L.mkv_set_tuning(name, int(v))
@@ -189,6 +196,9 @@ def _run_cycles(seed, deletes):
     L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 8192, 65536])))
     L.mkv_set_tuning(b"tail_groups", int(rng.choice([1, 5, 32])))
     L.mkv_set_tuning(b"grid_min", int(rng.choice([0, 64, 2048])))
+    rng4 = np.random.default_rng(17000 + seed)
+    L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
+    L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
     if not deletes:
         L.mkv_set_tuning(b"insert_chunk", 65536)     # (one pass)
     sig_space = int(rng.choice([40, 5000, 1 << 20]))
