@@ -75,6 +75,11 @@ def parse(argv=None):
     ap.add_argument("--comm", default="nccl", choices=["nccl", "staged"],
                     help="staged: gloo collectives through host memory, all ranks on cuda:0 -- only to exercise "
                          "the multi-rank flow of this script on a one-GPU box")
+    ap.add_argument("--repeats", type=int, default=3,
+                    help="the timed region (exactly --steps steps between barriers) is run this many times, each time "
+                         "from the same table image and over the same batches; `value` is the median")
+    ap.add_argument("--no-abi", action="store_true",
+                    help="skip the side measurement of the reference's three-call sequence (abi_three_call)")
     ap.add_argument("--strict-engine", action="store_true",
                     help="N > 1: exit non-zero if the C shard engine cannot be set up or fails its warm-up check "
                          "(default: report the phase that failed, fall back to the Python-driven step and tag the "
@@ -372,28 +377,56 @@ def main():
         run_timed = None
         if sharded and not args.no_pipeline:
             run_timed = engine.prepare_pipelined(timed, (lambda i: [timer.h, i // every] if (timer and i % every == 0) else None))
-        barrier()
-        t_start = time.perf_counter()
-        if run_timed is not None:
-            # several batches in flight: exchanges of one overlap the local kernels of the others
-            run_timed()
-        else:
-            for i, b in enumerate(timed):
-                engine.step(b, run_stream, [timer.h, i // every] if (timer and i % every == 0) else None)
-        t_submit = time.perf_counter() - t_start
-        t_done = t_submit
-        barrier()                     # (on the run stream: behind the K steps)
-    elapsed = time.perf_counter() - t_start
-    if os.environ.get("MKV_BENCH_SPLIT"):
-        print(f"bench split: submit {t_submit * 1e6:.0f} us, stream done {t_done * 1e6:.0f} us, after the closing barrier "
-              f"{elapsed * 1e6:.0f} us", file=sys.stderr)
-    if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        # The timed region -- barrier, EXACTLY K steps, barrier -- is run `repeats` times, every time from the
+        # SAME table image (a device copy of the table taken here, put back before each run: 1 GiB, < 1 ms,
+        # outside the clock) and over the SAME K batches, so that the runs do the same work; `value` is the
+        # median, the others are in the line.  One sample is not a measurement: the same command read 15.2
+        # and 19.9 Gops minutes apart in round 3 (profiles/r03_final_lines.txt).
+        image = engine.table_image()
+        abi = None
+        if (not sharded and not args.no_abi and not args.graph and args.steps and not args.memset
+                and args.overlap == "fused"):
+            # side measurement, same table image, same batches, same clock: the reference's own call sequence
+            # (src/mega_scheduler.c:393-502: memset, gpu_hash_search, gpu_hash_insert as three calls)
+            barrier()
+            t0 = time.perf_counter()
+            for b in timed:
+                engine.step_three_call(b, run_stream)
+            barrier()
+            dt = time.perf_counter() - t0
+            abi = {"value": round((1 << args.batch_log2) * args.steps / dt / 1e6, 1), "unit": "Mops",
+                   "us_per_step": round(dt / args.steps * 1e6, 2),
+                   "calls": "hipMemsetAsync(out) + mkv_search(KEEP_MISS) + mkv_insert_hinted per step (the entry points "
+                            "gpu_hash_search / gpu_hash_insert are thin calls of), same batches and table image as `value`"}
+            engine.restore_table(image)
+        elapsed_runs, t_submit = [], 0.0
+        for rep in range(max(1, args.repeats)):
+            if rep:
+                engine.restore_table(image)
+            barrier()
+            t_start = time.perf_counter()
+            if run_timed is not None:
+                # several batches in flight: exchanges of one overlap the local kernels of the others
+                run_timed()
+            else:
+                for i, b in enumerate(timed):
+                    engine.step(b, run_stream, [timer.h, i // every] if (timer and i % every == 0) else None)
+            t_submit = time.perf_counter() - t_start
+            barrier()                     # (on the run stream: behind the K steps)
+            e = time.perf_counter() - t_start
+            if dist is not None:
+                t = torch.tensor([e], dtype=torch.float64, device="cpu" if args.comm == "staged" else device)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                e = float(t.item())
+            elapsed_runs.append(e)
+        del image
+    elapsed = float(np.median(elapsed_runs))
 
     n_ops = (1 << args.batch_log2) * args.steps * world
     value = n_ops / elapsed / 1e6
+    repeats = {"runs": len(elapsed_runs), "mops": [round(n_ops / e / 1e6, 1) for e in elapsed_runs],
+               "us_per_step": [round(e / args.steps * 1e6, 2) for e in elapsed_runs],
+               "spread": round((max(elapsed_runs) - min(elapsed_runs)) / elapsed, 4)}
     if args.update_info and not sharded:
         print("update info:", engine.idx.last_update_info(run_stream, cycle_insert=True),
               "tail phases us:", engine.idx.tail_phases_us(run_stream, cycle_insert=True), file=sys.stderr)
@@ -518,6 +551,7 @@ def main():
                        + ("steps one by one" if args.no_pipeline else "2 batches in flight"),
                        "launch": "hipGraph" if args.graph else
                        ("one C call per run (library-owned RCCL communicator)" if native else "eager")},
+            "repeats": repeats, "abi_three_call": abi,
             "engine": ("single table (mkv_cycle)" if not sharded else "C shard engine (mkv_shard_run)" if native else
                        "python-fallback" if engine_error else "python-driven step"),
             "engine_error": engine_error,
@@ -557,6 +591,15 @@ def sharded_engine(*a, **kw):
             dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).to(self.device)
             return {"q": dev(gets), "s": dev(sets.reshape(-1, 3)),
                     "out": torch.zeros((gets.shape[0], 2), dtype=torch.int32, device=self.device)}
+
+        def table_image(self):
+            torch.cuda.synchronize()
+            return self.idx.table.clone()
+
+        def restore_table(self, image):
+            torch.cuda.synchronize()
+            self.idx.table.copy_(image)
+            torch.cuda.synchronize()
 
         def reserve(self, stream):
             self.idx.reserve(self.world * self.cap_set + 1024, stream)
@@ -687,6 +730,20 @@ class SingleGpu:
 
     def table_host(self):
         return self.idx.table_numpy()
+
+    def table_image(self):
+        torch.cuda.synchronize()
+        return self.idx.table.clone()
+
+    def restore_table(self, image):
+        torch.cuda.synchronize()
+        self.idx.table.copy_(image)
+        torch.cuda.synchronize()
+
+    def step_three_call(self, b, stream):
+        """the reference's sequence for one worker and cycle: memset(out), search, insert -- three calls"""
+        self.idx.cycle(b["q"], b["out"], b.get("ptrs"), b.get("cnts"), len(b["keep"]) if "keep" in b else 0,
+                       memset=True, overlap="none", stream=stream, insert_hint=b.get("n_set", 0))
 
     def prewarm(self, batches, ms, stream):
         """untimed read-only searches of the staged batches into a scratch buffer"""

@@ -30,9 +30,9 @@
  *   - one insert/delete call may carry at most MKV_REQ_CAP requests (environment variable,
  *     default 4 194 304; the reference's hosts stay below 32 768 per call,
  *     src/mega.c:143-144,163-165).  The counts are device memory, so an oversize batch is only
- *     detected on the device: it is NOT applied, and the next insert/delete call on that
- *     workspace prints what happened and abort()s -- loud, never silent.
- *     mkv_insert_hinted (megakv_hip.h) takes the batch size and grows the workspace instead.
+ *     detected on the device: it is NOT applied; the next insert/delete call reports it on
+ *     stderr, once per dropped batch, and mkv_dropped_batches() (megakv_hip.h) counts them --
+ *     nothing aborts.  mkv_insert_hinted takes the batch size and grows the workspace instead.
  *
  * Result definition: search output and final table state are bit-identical to
  * the reference kernels executed one request at a time in (block, index) order

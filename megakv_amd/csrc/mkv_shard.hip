@@ -78,7 +78,7 @@ struct mkv_shard {
 	hipStream_t cstream = nullptr;  // every local phase, one after the other
 	hipEvent_t ev_cdone = nullptr;
 	int host_paced = 1;             // the host, not the stream, waits for a local phase's requests (MKV_SHARD_PACED=0)
-	int nsvc = 1;                   // service streams (MKV_SHARD_SVC = 1..3; default 1 rank: 1, else 2)
+	int nsvc = 1;                   // service streams (MKV_SHARD_SVC = 1..3; default 1 rank: 1, else 3)
 	hipStream_t svc[3] = {nullptr, nullptr, nullptr};
 	int delay_unpack_us = 0;        // tests (MKV_SHARD_DELAY_UNPACK_US): every un-pack starts that much later
 	const char *phase = "idle";     // what the engine was doing when a call failed (mkv_shard_error)
@@ -325,7 +325,10 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	}
 	if (const char *v = getenv("MKV_SHARD_PACED"))
 		e->host_paced = atoi(v) != 0;
-	e->nsvc = world > 1 ? 2 : 1;
+	// (one service stream per buffer set with several ranks: with two, the stream that serves two of the
+	// three sets -- pack 30, exchange, un-pack 10, three hand-overs -- was what a batch waited for:
+	// eight looped-back ranks 103 -> 87 us per batch, two 73.5 -> 66.2; profiles/r04_loopback.txt)
+	e->nsvc = world > 1 ? 3 : 1;
 	if (const char *v = getenv("MKV_SHARD_SVC")) {
 		const int n = atoi(v);
 		if (n >= 1 && n <= 3)
