@@ -11,9 +11,12 @@
  * It is the build's own counterpart of the caller (the reference's .c files
  * are not copied) and doubles as the link test of lib/libgpuhash.a:
  *   gcc -Iinclude examples/scheduler_cycle.c -Llib -lgpuhash -lamdhip64 -lstdc++
- * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0]
+ * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0] [one call, default 0]
  *   mapped = 1: no staging copies; the library gets the pinned host buffers themselves
  *   (mapped into the device's address space), same calls, same checks.
+ *   one call = 1: the cycle's library work -- every worker's search, delete and insert -- is ONE
+ *   mkv_cycle_workers call on the first worker's stream (megakv_hip.h) instead of three calls per
+ *   worker; same buffers, same copies, same checks.
  * Self-checking: every key inserted in cycle c is found in cycle c+1 with its
  * loc (property P1 of libgpuhash/test/insert_test.c:178-195), deleted keys are
  * gone (P2, :237-244).  Exit code 0 = all checks passed.
@@ -25,6 +28,7 @@
 #include <time.h>
 
 #include "libgpuhash.h"
+#include "megakv_hip.h"
 
 #define MAX_WORKERS 16		/* assert(config->cpu_worker_num <= 16), src/mega_scheduler.c:276 */
 #define MAX_SEARCH 32768	/* config->batch_max_search_job, src/mega.c:136 */
@@ -73,6 +77,14 @@ int main(int argc, char **argv)
 	 * (same addresses), so the library is handed the host buffers themselves and its kernels read
 	 * the requests and write the results over PCIe.  0: the reference's copies. */
 	int MAPPED = argc > 3 ? atoi(argv[3]) : 0;
+	int ONECALL = argc > 4 ? atoi(argv[4]) : 0;
+	mkv_geom_t geom = {MEM_P, IBLOCK_P,
+#if defined(HASH_2CHOICE)
+		MKV_SCHEME_2CHOICE, 0
+#else
+		MKV_SCHEME_CUCKOO, MAX_CUCKOO_NUM
+#endif
+	};
 	uint8_t *table;
 	worker_t w[MAX_WORKERS];
 	if (WORKERS < 1 || WORKERS > MAX_WORKERS)
@@ -138,7 +150,53 @@ int main(int argc, char **argv)
 		}
 
 		/* --- scheduler: one cycle --- */
-		for (id = 0; id < WORKERS; id++) {				/* 1. search */
+		if (ONECALL) {
+			/* the copies of every worker on one stream, then ONE library call for the whole cycle */
+			mkv_worker_t mw[MAX_WORKERS];
+			cudaStream_t st = w[0].stream;
+			for (id = 0; id < WORKERS; id++) {
+				worker_t *k = &w[id];
+				if (!MAPPED) {
+					if (k->num_search)
+						CUDA_SAFE_CALL(cudaMemcpyAsync(k->search_in_d, k->search_in, k->num_search * sizeof(selem_t),
+									cudaMemcpyHostToDevice, st));
+					if (k->num_delete)
+						CUDA_SAFE_CALL(cudaMemcpyAsync(k->delete_in_d, k->delete_in, k->num_delete * sizeof(delem_t),
+									cudaMemcpyHostToDevice, st));
+					for (b = 0; b < INSERT_BLOCK; b++)
+						if (k->insert_job_num[b])
+							CUDA_SAFE_CALL(cudaMemcpyAsync(k->insert_in_d + (size_t)b * MAX_INSERT, k->insert_in[b],
+										k->insert_job_num[b] * sizeof(ielem_t), cudaMemcpyHostToDevice, st));
+					CUDA_SAFE_CALL(cudaMemcpyAsync(k->insert_job_num_d, k->insert_job_num, sizeof(k->insert_job_num),
+								cudaMemcpyHostToDevice, st));
+				} else {
+					for (b = 0; b < INSERT_BLOCK; b++)
+						k->insert_job_num_p[b] = k->insert_job_num[b];
+				}
+				for (b = 0; b < INSERT_BLOCK; b++)
+					total_insert += k->insert_job_num[b];
+				total_search += k->num_search;
+				total_delete += k->num_delete;
+				mw[id].search_in = MAPPED ? k->search_in : k->search_in_d;
+				mw[id].search_out = MAPPED ? k->search_out : k->search_out_d;
+				mw[id].num_search = k->num_search;
+				mw[id].delete_in = MAPPED ? k->delete_in : k->delete_in_d;
+				mw[id].num_delete = k->num_delete;
+				mw[id].blk_input = k->insert_ptrarray_d;
+				mw[id].blk_elem_num = MAPPED ? k->insert_job_num_p : k->insert_job_num_d;
+				mw[id].num_blks = INSERT_BLOCK;
+			}
+			if (mkv_cycle_workers(&geom, (bucket_t *)table, mw, WORKERS, st) != MKV_OK) {
+				fprintf(stderr, "mkv_cycle_workers failed\n");
+				return 2;
+			}
+			if (!MAPPED)
+				for (id = 0; id < WORKERS; id++)
+					if (w[id].num_search)
+						CUDA_SAFE_CALL(cudaMemcpyAsync(w[id].search_out, w[id].search_out_d,
+									2 * w[id].num_search * sizeof(loc_t), cudaMemcpyDeviceToHost, st));
+		}
+		for (id = 0; id < WORKERS && !ONECALL; id++) {	/* 1. search */
 			worker_t *k = &w[id];
 			if (k->num_search == 0)
 				continue;
@@ -157,7 +215,7 @@ int main(int argc, char **argv)
 						cudaMemcpyDeviceToHost, k->stream));
 			total_search += k->num_search;
 		}
-		for (id = 0; id < WORKERS; id++) {				/* 2. delete */
+		for (id = 0; id < WORKERS && !ONECALL; id++) {	/* 2. delete */
 			worker_t *k = &w[id];
 			if (k->num_delete == 0)
 				continue;
@@ -171,7 +229,7 @@ int main(int argc, char **argv)
 			gpu_hash_delete(k->delete_in_d, (bucket_t *)table, k->num_delete, 16384, 256, k->stream);
 			total_delete += k->num_delete;
 		}
-		for (id = 0; id < WORKERS; id++) {				/* 3. insert */
+		for (id = 0; id < WORKERS && !ONECALL; id++) {	/* 3. insert */
 			worker_t *k = &w[id];
 			if (MAPPED) {
 				for (b = 0; b < INSERT_BLOCK; b++) {
@@ -245,8 +303,9 @@ int main(int argc, char **argv)
 	clock_gettime(CLOCK_MONOTONIC, &t1);
 	double us = 1e6 * (t1.tv_sec - t0.tv_sec) + (t1.tv_nsec - t0.tv_nsec) / 1e3;
 	CUDA_SAFE_CALL(cudaMemGetInfo(&free_end, &total_mem));
-	printf("cycles %d workers %d%s: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d, library memory %.0f MiB\n",
-			cycles, WORKERS, MAPPED ? " (host buffers mapped, no copies)" : "", (unsigned long long)total_search, (unsigned long long)total_insert,
+	printf("cycles %d workers %d%s%s: search %llu insert %llu delete %llu in %.0f us -> %.2f Mops end to end, errors %d, library memory %.0f MiB\n",
+			cycles, WORKERS, MAPPED ? " (host buffers mapped, no copies)" : "", ONECALL ? " (one library call per cycle)" : "",
+			(unsigned long long)total_search, (unsigned long long)total_insert,
 			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors,
 			free_setup > free_end ? (double)(free_setup - free_end) / 1048576.0 : 0.0);
 	return errors ? 1 : 0;

@@ -79,6 +79,28 @@ int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t *search_in,
 		ielem_t **blk_input, int *blk_elem_num, int num_blks, int64_t insert_hint, uint32_t search_flags,
 		void *stream, void *timer, int slot);
 
+/* One call for ALL workers of a scheduler cycle (src/mega_scheduler.c:393-502 runs memset, search,
+ * delete, insert per worker on a stream each -- up to 16 x 9 launches of a few microseconds of work).
+ * Per worker exactly what the three entry points take: device arrays of search requests and results,
+ * of delete requests, and the device array of block pointers with its device int[] of block counts
+ * (rewritten by the host every cycle, as in the ABI).  Work: one search launch over every worker's
+ * requests (a miss writes 0: no memset), one delete pass, one insert pass.  Order: every search sees
+ * the table as the cycle found it; then the deletes in (worker, index) order; then the inserts in
+ * (worker, block, index) order -- the result of the per-worker calls whenever no worker deletes what an
+ * earlier worker inserts in the same cycle.  At most 32 workers and 1024 insert blocks in all.
+ * Asynchronous on `stream`. */
+typedef struct mkv_worker_s {
+	const selem_t *search_in;	/* device, num_search requests */
+	loc_t *search_out;			/* device, 2 * num_search results */
+	int64_t num_search;
+	delem_t *delete_in;			/* device, num_delete requests */
+	int64_t num_delete;
+	ielem_t **blk_input;		/* device array of num_blks device pointers */
+	int *blk_elem_num;			/* device int[num_blks] */
+	int num_blks;
+} mkv_worker_t;
+int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const mkv_worker_t *workers, int nworkers, void *stream);
+
 /* Measurement aid: `slots` HIP event pairs; mkv_cycle(timer, slot) records pair
  * `slot` on the caller's stream around its search launch.  timer may be NULL. */
 void *mkv_timer_create(int slots);

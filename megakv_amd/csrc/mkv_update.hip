@@ -69,6 +69,7 @@
 // exclusivity comes from the reservation, so a commit is two plain stores.
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
 
 #include <mutex>
 #include <unordered_map>
@@ -4652,6 +4653,159 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 			return rc;
 	}
 	return MKV_OK;
+}
+
+// ---- one call for ALL workers of a scheduler cycle ------------------------------------------------
+// The reference's scheduler runs, per cycle, memset + gpu_hash_search + gpu_hash_delete + gpu_hash_insert
+// for each of up to 16 workers on a stream each (src/mega_scheduler.c:393-502) with at most 32 767
+// searches and 8 x 4 096 inserts per worker (src/mega.c:136,143-144): 16 x 9 launches of a few
+// microseconds of work each, the updates serialised.  Here the whole cycle is four pieces of work:
+// ONE search launch over every worker's requests (a miss writes 0: no memset), one tiny launch that
+// gathers the workers' block pointers and counts (device arrays the host rewrites per cycle, as the
+// ABI has them) into one array, ONE delete pass over the workers' delete arrays as its blocks and ONE
+// insert pass over all the workers' blocks, worker-major.  Order: every search sees the table as the
+// cycle found it; then the deletes in (worker, index) order; then the inserts in (worker, block, index)
+// order -- what the per-worker calls give when the workers' keys do not meet within a cycle (per worker
+// they run delete then insert: a worker deleting what an EARLIER worker inserts in the same cycle is
+// the one case that differs).
+namespace mkv {
+
+constexpr int kMaxWorkers = 32;
+
+struct MultiSearch {
+	const uint2 *in[kMaxWorkers];
+	uint32_t *out[kMaxWorkers];
+	uint32_t n[kMaxWorkers];
+	uint32_t first[kMaxWorkers + 1];     // first work-group of worker w; [nw] = all
+	int nw;
+};
+
+__global__ __launch_bounds__(256) void k_search_multi(MultiSearch a, const uint4 *__restrict__ table, uint32_t hash_mask,
+		uint32_t blk_mask)
+{
+	int w = 0;
+	while (w + 1 < a.nw && blockIdx.x >= a.first[w + 1])
+		w++;
+	search_body<4, true, false>(blockIdx.x - a.first[w], a.in[w], a.out[w], table, (int64_t)a.n[w], hash_mask, blk_mask);
+}
+
+struct GatherBlocks {
+	const uint32_t *const *ins_ptrs[kMaxWorkers];    // worker w's device array of block pointers
+	const int *ins_cnts[kMaxWorkers];                // ... and of block counts
+	uint32_t ins_first[kMaxWorkers + 1];             // worker w's first block in the gathered array
+	const uint32_t *del_ptr[kMaxWorkers];
+	int del_cnt[kMaxWorkers];
+	int nw;
+};
+
+__global__ void k_gather_blocks(GatherBlocks a, const uint32_t **ins_ptrs, int *ins_cnts, const uint32_t **del_ptrs,
+		int *del_cnts)
+{
+	const uint32_t t = threadIdx.x;
+	if (t < a.ins_first[a.nw]) {
+		int w = 0;
+		while (w + 1 < a.nw && t >= a.ins_first[w + 1])
+			w++;
+		const uint32_t b = t - a.ins_first[w];
+		ins_ptrs[t] = a.ins_ptrs[w][b];
+		ins_cnts[t] = a.ins_cnts[w][b];
+	}
+	if (t < (uint32_t)a.nw) {
+		del_ptrs[t] = a.del_ptr[t];
+		del_cnts[t] = a.del_cnt[t];
+	}
+}
+
+// the gathered arrays: one set per device, made on first use (a cycle's calls are one turn: CallGuard)
+struct WorkerArrays {
+	const uint32_t **ins_ptrs = nullptr, **del_ptrs = nullptr;
+	int *ins_cnts = nullptr, *del_cnts = nullptr;
+};
+static WorkerArrays g_wk[64];
+
+}  // namespace mkv
+
+extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const mkv_worker_t *workers, int nworkers,
+		void *stream)
+{
+	mkv::DevGeom d;
+	if (!mkv::make_dev_geom(geom, &d) || !table || !workers || nworkers < 1 || nworkers > mkv::kMaxWorkers)
+		return MKV_EINVAL;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
+		return MKV_EHIP;
+	hipStream_t s = (hipStream_t)stream;
+	mkv::MultiSearch ms;
+	mkv::GatherBlocks gb;
+	memset(&ms, 0, sizeof(ms));
+	memset(&gb, 0, sizeof(gb));
+	ms.nw = gb.nw = nworkers;
+	uint32_t blocks = 0, nblk = 0;
+	long long ndel = 0;
+	for (int w = 0; w < nworkers; w++) {
+		const mkv_worker_t &k = workers[w];
+		if (k.num_search < 0 || k.num_search > 0x7fffffffLL || k.num_delete < 0 || k.num_delete > 0x7fffffffLL ||
+				k.num_blks < 0 || (k.num_search && (!k.search_in || !k.search_out)) || (k.num_delete && !k.delete_in) ||
+				(k.num_blks && (!k.blk_input || !k.blk_elem_num)))
+			return MKV_EINVAL;
+		ms.in[w] = reinterpret_cast<const uint2 *>(k.search_in);
+		ms.out[w] = reinterpret_cast<uint32_t *>(k.search_out);
+		ms.n[w] = (uint32_t)k.num_search;
+		ms.first[w] = blocks;
+		blocks += (uint32_t)((k.num_search + 255) / 256);
+		gb.ins_ptrs[w] = reinterpret_cast<const uint32_t *const *>(k.blk_input);
+		gb.ins_cnts[w] = k.blk_elem_num;
+		gb.ins_first[w] = nblk;
+		nblk += (uint32_t)k.num_blks;
+		gb.del_ptr[w] = reinterpret_cast<const uint32_t *>(k.delete_in);
+		gb.del_cnt[w] = (int)k.num_delete;
+		ndel += k.num_delete;
+	}
+	ms.first[nworkers] = blocks;
+	gb.ins_first[nworkers] = nblk;
+	if (nblk > (uint32_t)mkv::kMaxBlocks)
+		return MKV_EINVAL;
+	mkv::CallGuard call;                        // (the parts below are one turn)
+	mkv::WorkerArrays &wa = mkv::g_wk[dev];
+	if (!wa.ins_ptrs) {
+		const size_t n = (size_t)mkv::kMaxBlocks;
+		if (hipMalloc(&wa.ins_ptrs, n * sizeof(void *)) != hipSuccess || hipMalloc(&wa.ins_cnts, n * sizeof(int)) != hipSuccess ||
+				hipMalloc(&wa.del_ptrs, mkv::kMaxWorkers * sizeof(void *)) != hipSuccess ||
+				hipMalloc(&wa.del_cnts, mkv::kMaxWorkers * sizeof(int)) != hipSuccess)
+			return MKV_ENOMEM;
+	}
+	if (blocks)
+		hipLaunchKernelGGL(mkv::k_search_multi, dim3(blocks), dim3(256), 0, s, ms, reinterpret_cast<const uint4 *>(table),
+				d.hash_mask, d.blk_mask);
+	if (nblk || ndel)
+		hipLaunchKernelGGL(mkv::k_gather_blocks, dim3(1), dim3(1024), 0, s, gb, wa.ins_ptrs, wa.ins_cnts, wa.del_ptrs,
+				wa.del_cnts);
+	if (hipGetLastError() != hipSuccess)
+		return MKV_EHIP;
+	uint32_t *t = reinterpret_cast<uint32_t *>(table);
+	int rc = MKV_OK;
+	if (ndel) {
+		mkv::ReqSrc src;
+		src.blk_input = wa.del_ptrs;
+		src.single = nullptr;
+		src.blk_elem_num = wa.del_cnts;
+		src.single_n = 0;
+		src.nblk = (uint32_t)nworkers;
+		src.cnt_stride = 1;
+		rc = mkv::run_update<mkv::OP_DELETE>(d, t, src, s, ndel);
+	}
+	if (rc == MKV_OK && nblk) {
+		mkv::ReqSrc src;
+		src.blk_input = wa.ins_ptrs;
+		src.single = nullptr;
+		src.blk_elem_num = wa.ins_cnts;
+		src.single_n = 0;
+		src.nblk = nblk;
+		src.cnt_stride = 1;
+		rc = d.scheme == MKV_SCHEME_2CHOICE ? mkv::run_update<mkv::OP_2CHOICE>(d, t, src, s, 0)
+		                                    : mkv::run_update<mkv::OP_CUCKOO>(d, t, src, s, 0);
+	}
+	return rc;
 }
 
 extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,

@@ -16,6 +16,12 @@ class MkvGeom(ctypes.Structure):
                 ("scheme", ctypes.c_uint32), ("max_cuckoo", ctypes.c_uint32)]
 
 
+class MkvWorker(ctypes.Structure):
+    _fields_ = [("search_in", ctypes.c_void_p), ("search_out", ctypes.c_void_p), ("num_search", ctypes.c_int64),
+                ("delete_in", ctypes.c_void_p), ("num_delete", ctypes.c_int64),
+                ("blk_input", ctypes.c_void_p), ("blk_elem_num", ctypes.c_void_p), ("num_blks", ctypes.c_int)]
+
+
 class MkvUpdateInfo(ctypes.Structure):
     _fields_ = [("total", ctypes.c_uint32), ("round1", ctypes.c_uint32), ("round2", ctypes.c_uint32),
                 ("tail_parallel", ctypes.c_uint32), ("tail_serial", ctypes.c_uint32),
@@ -30,7 +36,7 @@ ABI_SYMBOLS = [
     "gpu_hash_search", "gpu_hash_insert", "gpu_hash_delete", "gpu_delete_insert",
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
-    "mkv_set_tuning", "mkv_cycle", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
+    "mkv_set_tuning", "mkv_cycle", "mkv_cycle_workers", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
@@ -72,6 +78,8 @@ def load_library():
     L.mkv_delete.argtypes = [G, P, P, I64, P]
     L.mkv_cycle.restype = INT
     L.mkv_cycle.argtypes = [G, P, P, P, I64, P, I64, P, P, INT, I64, U32, P, P, INT]
+    L.mkv_cycle_workers.restype = INT
+    L.mkv_cycle_workers.argtypes = [G, P, ctypes.POINTER(MkvWorker), INT, P]
     L.mkv_insert_hinted.restype = INT
     L.mkv_insert_hinted.argtypes = [G, P, P, P, INT, ctypes.c_longlong, P]
     L.mkv_dropped_batches.restype = ctypes.c_ulonglong

@@ -96,6 +96,10 @@ def test_plain_c_scheduler_driver_runs_clean():
     r = subprocess.run([exe, "12", "1", "1"], capture_output=True, text=True, timeout=600)
     assert r.returncode == 0, r.stdout + r.stderr
     assert "errors 0" in r.stdout and "no copies" in r.stdout
+    # ... and with the whole cycle's library work as ONE call (mkv_cycle_workers): staged and mapped
+    for mapped in ("0", "1"):
+        r = subprocess.run([exe, "12", "16", mapped, "1"], capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0 and "errors 0" in r.stdout and "one library call" in r.stdout, r.stdout + r.stderr
 
 
 def test_cycle_captured_into_a_hipgraph_through_the_c_api():
@@ -304,3 +308,62 @@ def test_host_threads_running_cycles_share_the_cycle_workspace():
                 O.delete(og, exp, d)
             O.insert(og, exp, [e])
         assert np.array_equal(idxs[th].table_numpy(), exp), f"thread {th}: table differs"
+
+
+@pytest.mark.parametrize("scheme,nworkers", [(0, 5), (1, 3), (0, 16)])
+def test_cycle_workers_one_call_for_all_workers_of_a_cycle(scheme, nworkers):
+    """mkv_cycle_workers: one search launch over every worker's requests, one delete pass, one insert
+    pass with worker-major blocks -- against the oracle run in the documented order (every search on
+    the table as the cycle found it; deletes in worker order; inserts in worker, block, index order).
+    The workers' keys overlap on purpose: the order is part of the contract."""
+    import ctypes
+    from megakv_amd.lib import MkvWorker
+    from megakv_amd.index import _dev_ptr, _stream_ptr
+    g = M.Geometry(mem_p=19, scheme=scheme)
+    og = O.geom(mem_p=19, scheme=scheme)
+    idx = M.HashIndex(g)
+    exp = O.new_table(og)
+    rng = np.random.default_rng(900 + nworkers)
+    pool = rng.integers(1, 2**32, size=(40000, 3), dtype=np.uint64).astype(np.uint32)
+    stream = torch.cuda.Stream()
+    for cycle in range(4):
+        ws, keep, host_w = (MkvWorker * nworkers)(), [], []
+        for w in range(nworkers):
+            ns, nd = int(rng.integers(0, 4000)), int(rng.integers(0, 600)) if cycle else 0
+            q = np.ascontiguousarray(pool[rng.integers(0, len(pool), size=ns), :2])
+            dl = pool[rng.integers(0, len(pool), size=nd)].copy()
+            nb = 8
+            blocks = []
+            for b in range(nb):
+                e = pool[rng.integers(0, len(pool), size=int(rng.integers(0, 700)))].copy()
+                e[:, 2] = rng.integers(1, 2**32, size=len(e), dtype=np.uint64)
+                blocks.append(np.ascontiguousarray(e))
+            tq = dev(q) if ns else None
+            out = torch.full((max(ns, 1), 2), 0x5555, dtype=torch.int32, device="cuda")
+            td = dev(dl) if nd else None
+            tb = [dev(b.reshape(-1, 3)) for b in blocks]
+            ptrs, cnts, kp = idx.stage_blocks(tb)
+            keep.append((tq, out, td, tb, ptrs, cnts, kp))
+            host_w.append((q, dl, blocks))
+            ws[w].search_in = _dev_ptr(tq).value if ns else None
+            ws[w].search_out = _dev_ptr(out).value
+            ws[w].num_search = ns
+            ws[w].delete_in = _dev_ptr(td).value if nd else None
+            ws[w].num_delete = nd
+            ws[w].blk_input = _dev_ptr(ptrs).value
+            ws[w].blk_elem_num = _dev_ptr(cnts).value
+            ws[w].num_blks = nb
+        torch.cuda.synchronize()
+        rc = idx.lib.mkv_cycle_workers(ctypes.byref(idx._g), _dev_ptr(idx.table), ws, nworkers, _stream_ptr(stream))
+        assert rc == 0
+        stream.synchronize()
+        for w in range(nworkers):
+            q = host_w[w][0]
+            if len(q):
+                want = O.search(og, exp, q)
+                assert np.array_equal(keep[w][1].cpu().numpy().view(np.uint32)[: len(q)], want), (cycle, w, "search")
+        for w in range(nworkers):
+            if len(host_w[w][1]):
+                O.delete(og, exp, np.ascontiguousarray(host_w[w][1]))
+        O.insert(og, exp, [b for w in range(nworkers) for b in host_w[w][2]])
+        assert np.array_equal(idx.table_numpy(), exp), (cycle, "table")

@@ -1,10 +1,6 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s21; mkdir -p $d
-for cfg in "MKV_SHARD_SVC=2 MKV_SHARD_LANES=3" "MKV_SHARD_SVC=3 MKV_SHARD_LANES=3" "MKV_SHARD_SVC=3 MKV_SHARD_LANES=4" "MKV_SHARD_SVC=2 MKV_SHARD_LANES=4" "MKV_SHARD_SVC=1 MKV_SHARD_LANES=3" "MKV_SHARD_SVC=3 MKV_SHARD_LANES=3 MKV_SHARD_PACED=0"; do
-  for w in 8 2; do
-    echo "== $cfg world $w fake 7"; env $cfg MKV_SHARD_FAKE_XFER_US=7 timeout 300 python tools/loopback_trace.py $w 64 30 zipf 2>&1 | grep "us per batch\|rror" | tail -1
-  done
-done 2>&1 | tee $d/svc.txt
-for cfg in "MKV_SHARD_SVC=1 MKV_SHARD_LANES=2" "MKV_SHARD_SVC=2 MKV_SHARD_LANES=2" "MKV_SHARD_SVC=2 MKV_SHARD_LANES=3"; do
-  echo "== $cfg world 1"; env $cfg timeout 300 python tools/loopback_trace.py 1 64 30 zipf 2>&1 | grep "us per batch\|rror" | tail -1
-done 2>&1 | tee -a $d/svc.txt
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s22; mkdir -p $d
+( timeout 900 python -m pytest tests -m gpu -x -q 2>&1 | tail -15 ) > $d/pytest.txt 2>&1
+grep -E "passed|failed|error" $d/pytest.txt | tail -3; grep -B5 -A25 "Error\|assert" $d/pytest.txt | head -60
+exe=megakv_amd/_lib/scheduler_cycle
+for wk in 1 4 16; do for mode in "0 0" "0 1" "1 0" "1 1"; do $exe 60 $wk $mode 2>&1 | tail -1; done; done | tee $d/scheduler.txt
