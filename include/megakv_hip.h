@@ -151,7 +151,7 @@ typedef struct mkv_update_info_s {
 	uint32_t bar_chain;		/* region barriers raised by chains that met another request's bucket */
 	uint32_t bar_class;		/* region barriers raised for requests that might turn hard */
 	uint32_t tail_rounds;	/* reservation rounds the tail launches ran */
-	uint32_t helped;		/* round 1: second registrants of a bucket that committed beside its owner (self-help; counted in round2) */
+	uint32_t helped;		/* round 1: second registrants of a bucket that committed beside its owner (self-help; counted in round1) */
 	uint32_t losers;		/* round 1: requests it left to round 2 */
 } mkv_update_info_t;
 

@@ -1332,14 +1332,27 @@ __device__ __forceinline__ void tail_list_flush(Ctl *ctl, const uint32_t *s_tl, 
 		uint32_t nblocks)
 {
 	__syncthreads();
-	if (block == 0 && threadIdx.x == 0)
-		ctl->tl_groups[ROUND - 1] = nblocks;
-	if (block < kTlGroups) {
+	if (nblocks <= kTlGroups) {
+		if (block == 0 && threadIdx.x == 0)
+			ctl->tl_groups[ROUND - 1] = nblocks;
 		const uint32_t n = *s_tln;
 		if (threadIdx.x < kTlPer && threadIdx.x < n)
 			ctl->tl[ROUND - 1][block][threadIdx.x] = s_tl[threadIdx.x];
 		if (threadIdx.x == 0)
 			ctl->tl_cnt[ROUND - 1][block] = n;
+		return;
+	}
+	// more work-groups than places (round 2 of a large pass runs on up to 2048): several share a place and
+	// take their part of it with one atomic each -- only those that leave anything (the places' counts were
+	// cleared by round 1's first work-group)
+	if (block == 0 && threadIdx.x == 0)
+		ctl->tl_groups[ROUND - 1] = kTlGroups;
+	const uint32_t n = *s_tln;
+	if (n != 0u && threadIdx.x == 0) {
+		const uint32_t slot = block & (kTlGroups - 1u);
+		const uint32_t at = atomicAdd(&ctl->tl_cnt[ROUND - 1][slot], n);
+		for (uint32_t k = 0; k < n && k < kTlPer && at + k < kTlPer; k++)
+			ctl->tl[ROUND - 1][slot][at + k] = s_tl[k];
 	}
 }
 
@@ -1383,8 +1396,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	const bool help_on = (record_hint & 32) == 0;         // Tuning::self_help = 0: the second registrant waits for round 2, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
-	if (ROUND == 1 && block == 0 && threadIdx.x == 0)
-		reset_tail_scratch(ctl);
+	if (ROUND == 1 && block == 0) {
+		if (threadIdx.x == 0)
+			reset_tail_scratch(ctl);
+		for (uint32_t q = threadIdx.x; q < kTlGroups; q += blockDim.x)
+			ctl->tl_cnt[1][q] = 0u;                 // (round 2's places: its work-groups may have to share them, tail_list_flush)
+	}
 	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
 	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
@@ -1517,12 +1534,13 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 						// this request stores meanwhile (other words; and taking one other empty slot away does not
 						// change which one c prefers).  So this request commits NOW, on P as c will have left it, instead
 						// of losing to c and coming again in round 2: the signature row it has loaded holds c's new entry
-						// already or not yet, which it can tell (c's signature is in the row or it is not).  The commit
-						// counts as a round-2 commit: tagged ROUND2 and registered in the round-2 table, where this
-						// request is the lowest registrant of P (the other losers of P are later ones) -- who asks for
-						// commits on P finds it by the round-2 table as ever, and a request that comes to P unregistered
-						// finds it through second[P] (later_commit_from).  Not when c finds P full (it may go on to
-						// evict from P), not for signature 0 (it "matches" empty slots: the two would share words).
+						// already or not yet, which it can tell (c's signature is in the row or it is not).  It is a
+						// round-1 commit like c's (the two write different words: either may be taken back first) and
+						// does not stand in the round-2 table: the THIRD registrant of P, a loser of this round, is the
+						// lowest one there and commits in round 2 on P as these two left it.  Who asks for commits on P
+						// finds this one through second[P] (candidates_of: the bucket's lowest registrant of round 1, of
+						// round 2, and this).  Not when c finds P full (it may go on to evict from P), not for signature
+						// 0 (it "matches" empty slots: the two would share words).
 						// (second[P] is asked for here, with the owner's request, not beside the reservation: fetched
 						// by every lane of a 52 K pass it cost 1.2 us more than the losers' extra round trip.)
 						if (ROUND == 1 && help_on && !same && rj.x != 0u && rj.x != r.sig && (rj.y & g.hash_mask) == P &&
@@ -1570,8 +1588,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 								}
 								if (ok) {
 									undo[idx] = u;
-									state[idx] = ST_ROUND2;
-									atomicMin(&owner_next[P], owner_key(stamp + 1, idx));
+									state[idx] = ST_ROUND1;
 									ndone_help++;
 									lose = false;
 									follower = false;
@@ -1740,7 +1757,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	}
 	count_add(&ctl->committed[ROUND - 1][0].n, ndone);
 	if (ROUND == 1 && help_on) {
-		count_add(&ctl->committed[1][0].n, ndone_help);
+		count_add(&ctl->committed[0][0].n, ndone_help);
 		count_add(&ctl->committed[2][0].n, ndone_help);
 	}
 	if (ROUND == 1)
@@ -1816,8 +1833,7 @@ __device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint
 }
 
 // the candidates of bucket b from its reservation words (kNone: none of this pass): its lowest registrant of
-// round 1, of round 2, and the mark pass's second-lowest (a self-help commit of round 1 -- which also
-// stands in the round-2 table, but a request that came to the bucket unregistered may stand before it there)
+// round 1, of round 2, and the mark pass's second-lowest (a self-help commit of round 1)
 __device__ __forceinline__ void candidates_of(const Tv &tv, unsigned long long v1, unsigned long long v2,
 		unsigned long long v3, uint32_t &c1, uint32_t &c2, uint32_t &c3)
 {
@@ -4368,8 +4384,12 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	// round 1 has been leaving round 2 a lot: duplicates of hot keys, say)
 	const bool merged = OP != OP_DELETE && tuning().merge_round2 != 0 && hint <= (long long)tuning().merge_max &&
 			!(w->host_flag && w->host_flag[3] && tuning().merge_round2 == 1);
+	// (round 2 looks at every request's tag to find its few: a lane per announced request, within 2048
+	// work-groups -- 524 K tags on the 512 work-groups of round 1 took 15 us, on 2048 they take 6.5)
+	long long r2_blocks = (hint + 255) / 256;
+	r2_blocks = r2_blocks < tuning().round_blocks ? tuning().round_blocks : (r2_blocks > 2048 ? 2048 : r2_blocks);
 	if (!merged)
-		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
+		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
 				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4]);
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
