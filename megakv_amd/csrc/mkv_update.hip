@@ -100,7 +100,9 @@ constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (
                                     // launch stays free of scratch memory and calls)
 constexpr uint32_t kLateSticky = 16; // calls for which a call whose chains ran late counts as "chains lately" (diagnostics)
 constexpr int kDeferCap = 768;           // k_round: requests a work-group may hold back for its second phase
-constexpr uint32_t kMergeLosersMax = 2048;   // round 2 runs inside the tail launch while round 1 leaves it at most this many requests
+constexpr uint32_t kMergeLosersMax = 16;   // round 2 runs inside the tail launch while round 1 leaves it at most this many requests
+                                          // (with work to do it costs what its own launch costs, and a little more: 20.7 against 19.0 us
+                                          // for round 2 + tail at load factor 0.5)
 
 enum Op : uint32_t { OP_CUCKOO = 0, OP_2CHOICE = 1, OP_DELETE = 2 };
 
@@ -794,7 +796,7 @@ __device__ __forceinline__ void fold_max_dedup(const Fold &f, unsigned long long
 // ---- the SECOND-lowest registrant of a bucket (mark pass) ---------------------------------------
 // Round 1 lets the second-lowest registrant j of a bucket P commit beside the lowest one, c, when it can
 // tell what c will do there (self-help, round_body).  For that j must KNOW it is the second: every
-// registration of the mark pass -- primary bucket, alternate bucket, the pre-walk's chain buckets -- is a
+// registration of the mark pass on a request's own buckets -- primary, alternate -- is a
 // RETURNING atomicMin, and whoever sees two keys of this pass on a bucket (its own and the one it
 // displaced or lost to) enters the larger one in a second table, `second`, with another atomicMin.
 // Every registrant but the lowest is the larger one of such a pair at some point (it finds a smaller key
@@ -937,7 +939,7 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 // through the ordinary reservation instead of being committed under the chain's feet.  Only
 // a hint: nothing depends on the walk being right (the table may change before the turn).
 __device__ __forceinline__ void prewalk_register(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P,
-		uint32_t A, unsigned long long *owner, unsigned long long *second, unsigned long long key, uint4 lo, uint4 hi)
+		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi)
 {
 	// (lo, hi: the signature row of P, loaded by the caller)
 	if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
@@ -953,7 +955,11 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 		const uint32_t a = (v & 1u) ? q.y : q.x, c = (v & 1u) ? q.w : q.z;
 		const uint32_t vsig = (v & 2u) ? c : a;
 		const uint32_t nb = alt_bucket(r.hash, vsig, g.hash_mask, g.blk_mask);   // ORIGINAL hash (ref :334)
-		register_one(owner, second, nb, key);
+		// (not noted in the table of second registrants: a returning atomic per step made the walk, and with
+		// it the fused launch of a well-filled table, a third longer -- 34 -> 46 us at load factor 0.85.
+		// A bucket's second registrant that helps itself behind a chain's hint commits where it would
+		// have committed in round 2, and the chain, should it ever come, finds it like any later commit.)
+		atomicMin(&owner[nb], key);
 		load_sig_row<false>(table, nb, lo, hi);
 		if (eq_mask(lo, hi, vsig) | eq_mask(lo, hi, 0u))
 			return;
@@ -1109,7 +1115,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			register_dedup(owner, second, A, key, live && A != P && !lazy);
 		}
 		if (OP == OP_CUCKOO && live && table && !lazy)
-			prewalk_register(table, g, rq, P, A, owner, second, key, plo, phi);
+			prewalk_register(table, g, rq, P, A, owner, key, plo, phi);
 	}
 }
 
@@ -4247,11 +4253,18 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 // within the last Tuning::barrier_sticky calls) -- never the result.
 // work-groups of the mark pass inside a fused search launch: Tuning::mark_blocks for the usual
 // few per cent of SETs, more when the caller announces many (one per 512 requests, up to 1024)
-static uint32_t mark_blocks_for(long long hint)
+// (busy: eviction chains have been running late lately, chains_lately -- a well-filled table: most
+// requests register on both their buckets and many walk ahead, and the mark pass, whose registrations
+// wait for their atomics to return, is what the fused launch ends with: a lane per announced request
+// then -- load factor 0.85: launch 40 -> 34 us; at load factor 0.2 the extra work-groups cost the
+// search half a microsecond)
+static uint32_t mark_blocks_for(long long hint, bool busy = false)
 {
 	long long b = tuning().mark_blocks;
 	if (hint / 512 > b)
 		b = hint / 512;
+	if (busy && (hint + 255) / 256 > b)
+		b = (hint + 255) / 256;
 	return (uint32_t)(b > 1024 ? 1024 : b);
 }
 
@@ -4506,16 +4519,16 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	if (rc != MKV_OK)
 		return rc;
 	const int64_t search_blocks = (num_search + 255) / 256;      // U = 4: 256 requests per block
-	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint);
-	if (search_blocks + mark_blocks > 0x7fffffffLL)
-		return MKV_ETOOBIG;
-	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
 	const uint2 *in2 = reinterpret_cast<const uint2 *>(in);
 	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
 	// the fused launch marks the first chunk only
 	uint32_t lo, hi;
 	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
 	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
+	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint, w->barrier_score > 0);
+	if (search_blocks + mark_blocks > 0x7fffffffLL)
+		return MKV_ETOOBIG;
+	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
 	// (ev_start / ev_stop: HIP events that receive the START and END time of this very dispatch --
 	// hipExtLaunchKernelGGL -- i.e. the kernel's duration as a profiler sees it, without the
 	// launch latency a pair of hipEventRecord calls around the launch includes)
@@ -4645,7 +4658,7 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 	const int nchunks = ck.passes;
 	uint32_t lo, hi;
 	mkv::chunk_range(0, ck, &lo, &hi);
-	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint);
+	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint, w->barrier_score > 0);
 	const dim3 grid(search_blocks + mark_blocks), block(256);
 	hipEvent_t e0 = tm ? tm->ev[2 * slot] : nullptr, e1 = tm ? tm->ev[2 * slot + 1] : nullptr;
 	if (cuckoo)
