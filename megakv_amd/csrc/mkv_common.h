@@ -91,6 +91,7 @@ struct Tuning {
 	long long insert_chunk; // requests per canonical-index chunk when the caller hints the batch size
 	int mark_blocks;        // work-groups of the insert mark pass inside the fused search launch
 	int pack_three_pass;    // sharded pack: the three-kernel stable path instead of the one-launch pack
+	int pack_threads;       // one-launch pack: lanes per work-group (256, 512 or 1024)
 	int barrier_sticky;     // calls for which a call that met a barrier counts as "barriers lately"
 	int barrier_split;      // barriers lately: cut a hinted single-chunk batch into this many chunks (1: off)
 	int grid_min;           // a final tail list longer than this runs its rounds on all work-groups of the launch

@@ -360,13 +360,19 @@ __global__ __launch_bounds__(256) void k_pack_scatter(const uint32_t *__restrict
 // back tile by tile through LDS was built and measured -- 8.0 / 10.0 us against 7.8 / 7.7 us at
 // 1 / 8 shards: two dependent round trips either way.)
 // The last work-group to finish writes the slot headers and clears the control words.
-constexpr int kPackThreads = 1024;
-constexpr int kSetTile = 4096;       // SETs per work-group (4 per lane: three 16-byte loads)
+// (SETs per work-group: 4 per lane -- three 16-byte loads)
 constexpr int kPackBins = 16;        // shards the one-launch pack handles
 constexpr int kCursorStride = 32;    // words between two shards' cursors (a 128-byte line each)
 constexpr int kPackArrive = kPackBins * kCursorStride, kPackDone = kPackArrive + kCursorStride;
 constexpr int kPackCtlWords = kPackDone + kCursorStride;    // cursors, arrive, done; then the SET tiles' counts
 constexpr int64_t kTileR8From = 1 << 19;                    // batches from this many GETs on: 8 per lane, else 4
+
+// lanes per work-group of the one-launch pack (tuning "pack_threads": 256, 512 or 1024)
+static inline int pack_threads()
+{
+	const int t = tuning().pack_threads;
+	return t == 256 || t == 512 ? t : 1024;
+}
 
 __device__ __forceinline__ uint32_t pack_ld(const uint32_t *p)
 {
@@ -423,8 +429,8 @@ __device__ __forceinline__ void wave_rank(const uint32_t (&sh)[R], uint32_t G, u
 	mine = lane < G ? (uint32_t)(t >> (16u * (lane & 3u))) & 0xffffu : 0u;
 }
 
-template <int R>      // GETs per lane: 8 or 4
-__global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__restrict__ gets, int64_t n_get,
+template <int R, int THREADS>      // GETs per lane: 8 or 4; lanes per work-group: 1024, 512 or 256
+__global__ __launch_bounds__(THREADS) void k_pack_tiles(const uint32_t *__restrict__ gets, int64_t n_get,
 		const uint32_t *__restrict__ sets, int64_t n_set, uint32_t hash_mask, uint32_t shift, int nshards,
 		uint32_t *__restrict__ sendbuf, int64_t slot_words, uint32_t cap_get, uint32_t cap_set,
 		int32_t *__restrict__ perm_get, uint32_t *ctl, int *overflow, uint32_t set_tiles, uint32_t get_tiles,
@@ -432,9 +438,9 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 {
 	// (self_slot: the slot of shard `self` is written THERE -- the rank's own receive buffer: what a
 	// rank sends to itself need not pass through the exchange; self >= nshards: none)
-	constexpr int kTile = kPackThreads * R;
+	constexpr int kTile = THREADS * R, kSetTile = THREADS * 4, NW = THREADS / 64;
 	__shared__ uint2 s_stage[kTile];
-	__shared__ uint32_t s_wcnt[16][kPackBins];
+	__shared__ uint32_t s_wcnt[NW][kPackBins];
 	__shared__ uint32_t s_base[kPackBins], s_off[kPackBins + 1];
 	__shared__ uint32_t s_last;
 	const uint32_t t = threadIdx.x, lane = t & 63u, wave = t >> 6;
@@ -477,7 +483,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 		// (an agent-scope fence flushes the L2 the GET tiles are filling -- 100 us of them)
 		if (t < G) {
 			uint32_t c = 0;
-			for (int wv = 0; wv < 16; wv++)
+			for (int wv = 0; wv < NW; wv++)
 				c += s_wcnt[wv][t];
 			__hip_atomic_store(&tile_counts[(size_t)tile * kPackBins + t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
@@ -511,7 +517,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 		}
 		if (tile == set_tiles - 1u && t < G) {
 			uint32_t total = s_base[t];
-			for (int wv = 0; wv < 16; wv++)
+			for (int wv = 0; wv < NW; wv++)
 				total += s_wcnt[wv][t];
 			uint32_t *hdr = t == self ? self_slot : sendbuf + (int64_t)t * slot_words;
 			if (total > cap_set) {
@@ -529,7 +535,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 		uint32_t sh[R], rank[R];
 #pragma unroll
 		for (int i = 0; i < R / 2; i++) {
-			const int64_t e = tile0 + 2 * ((int64_t)i * kPackThreads + t);
+			const int64_t e = tile0 + 2 * ((int64_t)i * THREADS + t);
 			uint4 v = make_uint4(0u, 0u, 0u, 0u);
 			if (e + 2 <= n_get && gets16) {
 				v = *reinterpret_cast<const uint4 *>(gets + e * 2);
@@ -558,7 +564,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 		// shard's place in the LDS staging area, and where the tile went (for the un-pack)
 		if (t < kPackBins) {
 			uint32_t c = 0;
-			for (int wv = 0; wv < 16; wv++)
+			for (int wv = 0; wv < NW; wv++)
 				c += s_wcnt[wv][t];
 			const uint32_t base = (t < G && c) ? atomicAdd(&cursors[t * kCursorStride], c) : 0u;
 			s_base[t] = base;
@@ -594,7 +600,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 		// where the requests went (their results come back to the same place): request order, coalesced
 #pragma unroll
 		for (int i = 0; i < R / 2; i++) {
-			const int64_t e = tile0 + 2 * ((int64_t)i * kPackThreads + t);
+			const int64_t e = tile0 + 2 * ((int64_t)i * THREADS + t);
 			if (e + 2 <= n_get && perm8) {
 				*reinterpret_cast<int2 *>(perm_get + e) = make_int2(wh[2 * i], wh[2 * i + 1]);
 			} else if (e < n_get) {
@@ -608,7 +614,7 @@ __global__ __launch_bounds__(kPackThreads) void k_pack_tiles(const uint32_t *__r
 		for (uint32_t k = 0; k < G; k++) {
 			const uint32_t lo = s_off[k], hi = s_off[k + 1u], base = s_base[k];
 			uint2 *slot = reinterpret_cast<uint2 *>((k == self ? self_slot : sendbuf + (int64_t)k * slot_words) + kHdrWords);
-			for (uint32_t j = lo + t; j < hi; j += kPackThreads) {
+			for (uint32_t j = lo + t; j < hi; j += THREADS) {
 				const uint32_t dst = base + (j - lo);
 				if (dst < cap_get)
 					slot[dst] = s_stage[j];
@@ -695,7 +701,7 @@ extern "C" int64_t mkv_pack_scratch_bytes(int64_t n_get, int64_t n_set, int nsha
 	const int64_t nw_get = (n_get + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
 	const int64_t nw_set = (n_set + mkv::kRouteChunk - 1) / mkv::kRouteChunk;
 	const int64_t three_pass = (nw_get + nw_set) * nshards * 4 + 64;
-	const int64_t set_tiles = (n_set + mkv::kSetTile - 1) / mkv::kSetTile;
+	const int64_t set_tiles = (n_set + 1023) / 1024;        // (the smallest SET tile: 256 lanes x 4)
 	const int64_t one_pass = (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4 + 64;
 	return three_pass > one_pass ? three_pass : one_pass;
 }
@@ -715,19 +721,23 @@ extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const 
 // largest batch).
 extern "C" int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_bytes)
 {
-	static int resident_cap[64] = {0};
+	static int resident_cap[64][3] = {{0}};
 	int dev = 0;
 	(void)hipGetDevice(&dev);
-	if (dev >= 0 && dev < 64 && resident_cap[dev] == 0) {
+	const int threads = mkv::pack_threads(), v = threads == 1024 ? 0 : threads == 512 ? 1 : 2;
+	if (dev >= 0 && dev < 64 && resident_cap[dev][v] == 0) {
 		int per_cu = 0, cus = 0;
-		if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8>, mkv::kPackThreads, 0) != hipSuccess ||
-				hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
+		const hipError_t e = v == 0 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8, 1024>, 1024, 0) :
+				v == 1 ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8, 512>, 512, 0) :
+				hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, mkv::k_pack_tiles<8, 256>, 256, 0);
+		if (e != hipSuccess || hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess)
 			per_cu = cus = 0;
-		resident_cap[dev] = per_cu * cus > 0 ? per_cu * cus : -1;
+		resident_cap[dev][v] = per_cu * cus > 0 ? per_cu * cus : -1;
 	}
-	const int64_t set_tiles = ((n_set > 0 ? n_set : 0) + mkv::kSetTile - 1) / mkv::kSetTile;
-	const int64_t set_tiles_max = (dev >= 0 && dev < 64 && resident_cap[dev] > 0) ?
-			(resident_cap[dev] < 1024 ? resident_cap[dev] : 1024) : 128;
+	const int64_t set_tile = threads * 4;
+	const int64_t set_tiles = ((n_set > 0 ? n_set : 0) + set_tile - 1) / set_tile;
+	const int64_t set_tiles_max = (dev >= 0 && dev < 64 && resident_cap[dev][v] > 0) ?
+			(resident_cap[dev][v] < 1024 ? resident_cap[dev][v] : 1024) : 128;
 	return nshards >= 1 && nshards <= mkv::kPackBins && set_tiles <= set_tiles_max && !mkv::tuning().pack_three_pass &&
 			scratch_bytes >= (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4;
 }
@@ -767,23 +777,27 @@ extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const 
 	const uint32_t *g32 = reinterpret_cast<const uint32_t *>(gets);
 	const uint32_t *s32 = reinterpret_cast<const uint32_t *>(sets);
 	const bool r8 = n_get >= mkv::kTileR8From;
-	const int64_t get_tile = mkv::kPackThreads * (r8 ? 8 : 4);
-	const int64_t set_tiles = (n_set + mkv::kSetTile - 1) / mkv::kSetTile;
+	const int threads = mkv::pack_threads();
+	const int64_t get_tile = (int64_t)threads * (r8 ? 8 : 4), set_tile = (int64_t)threads * 4;
+	const int64_t set_tiles = (n_set + set_tile - 1) / set_tile;
 	const int64_t get_tiles = (n_get + get_tile - 1) / get_tile;
 	if (mkv_pack_one_launch(n_set, nshards, scratch_bytes)) {
 		// one launch; its control words (the head of `scratch`) are zero between calls: zeroed
 		// by the caller once, cleared again by the kernel's last work-group
 		const int64_t blocks = set_tiles + get_tiles ? set_tiles + get_tiles : 1;
-		if (r8)
-			hipLaunchKernelGGL(mkv::k_pack_tiles<8>, dim3((unsigned)blocks), dim3(mkv::kPackThreads), 0, s, g32, n_get, s32,
-					n_set, hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set,
-					perm_get, reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles, (uint32_t)get_tiles,
-					self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot);
-		else
-			hipLaunchKernelGGL(mkv::k_pack_tiles<4>, dim3((unsigned)blocks), dim3(mkv::kPackThreads), 0, s, g32, n_get, s32,
-					n_set, hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set,
-					perm_get, reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles, (uint32_t)get_tiles,
-					self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot);
+#define MKV_PACK_LAUNCH(R, T) \
+		hipLaunchKernelGGL((mkv::k_pack_tiles<R, T>), dim3((unsigned)blocks), dim3(T), 0, s, g32, n_get, s32, n_set, \
+				hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set, perm_get, \
+				reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles, (uint32_t)get_tiles, \
+				self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot)
+		if (threads == 1024) {
+			if (r8) MKV_PACK_LAUNCH(8, 1024); else MKV_PACK_LAUNCH(4, 1024);
+		} else if (threads == 512) {
+			if (r8) MKV_PACK_LAUNCH(8, 512); else MKV_PACK_LAUNCH(4, 512);
+		} else {
+			if (r8) MKV_PACK_LAUNCH(8, 256); else MKV_PACK_LAUNCH(4, 256);
+		}
+#undef MKV_PACK_LAUNCH
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
 	if (self >= 0)

@@ -132,6 +132,9 @@ Tuning &tuning()
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
 		s = getenv("MKV_PACK_THREE_PASS");
 		v.pack_three_pass = s ? atoi(s) != 0 : 0;
+		s = getenv("MKV_PACK_THREADS");
+		v.pack_threads = s ? atoi(s) : 1024;
+		if (v.pack_threads != 256 && v.pack_threads != 512) v.pack_threads = 1024;
 		s = getenv("MKV_BARRIER_STICKY");
 		v.barrier_sticky = s ? atoi(s) : 16;
 		if (v.barrier_sticky < 0) v.barrier_sticky = 0;
@@ -235,6 +238,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.mark_blocks = (int)value;
 	} else if (!strcmp(name, "pack_three_pass")) {
 		t.pack_three_pass = value != 0;
+	} else if (!strcmp(name, "pack_threads")) {
+		if (value != 256 && value != 512 && value != 1024)
+			return MKV_EINVAL;
+		t.pack_threads = (int)value;
 	} else if (!strcmp(name, "barrier_sticky")) {
 		if (value < 0 || value > 1000000)
 			return MKV_EINVAL;

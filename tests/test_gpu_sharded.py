@@ -20,11 +20,15 @@ def test_sharded_pipelined_two_lanes(world):
     run_and_check(world, "gpu-pipe", mem_p_local=16, scheme=0, seed=30 + world, timeout=900)
 
 
+PACK_THREADS_DEFAULT = 1024
+
+
+@pytest.mark.parametrize("threads", [1024, 512, 256])
 @pytest.mark.parametrize("g,n_get,n_set,three_pass", [(1, 5000, 300, 0), (2, 70001, 4099, 0), (8, 200000, 30000, 0),
                                                         (4, 0, 2500, 0), (4, 3000, 0, 0), (8, 50000, 5000, 1),
                                                         (1, 1 << 20, 52428, 0), (8, 996149, 52427, 0), (16, 600001, 9, 0),
-                                                        (2, 1, 1, 0), (8, 4097, 4097, 0)])
-def test_pack_layout(g, n_get, n_set, three_pass):
+                                                        (2, 1, 1, 0), (8, 4097, 4097, 0), (8, 524288, 524288, 0)])
+def test_pack_layout(g, n_get, n_set, three_pass, threads):
     """mkv_pack_requests: every request lands in the slot of its shard; SET slots keep
     batch order (the canonical insert order of a shard is source rank, then index); GET
     slots hold the right requests in any order, `perm[e]` telling where request e went;
@@ -35,7 +39,10 @@ def test_pack_layout(g, n_get, n_set, three_pass):
     from megakv_amd.lib import load_library
     from megakv_amd.index import _dev_ptr, _stream_ptr
     L = load_library()
+    if three_pass and threads != 1024:
+        pytest.skip("the three-pass pack has one form")
     L.mkv_set_tuning(b"pack_three_pass", three_pass)
+    assert L.mkv_set_tuning(b"pack_threads", threads) == 0
     try:
         rng = np.random.default_rng(g * 1000 + n_get % 97)
         mem_p_agg = 20
@@ -95,6 +102,7 @@ def test_pack_layout(g, n_get, n_set, three_pass):
                     assert (o[n_get] == 0xffffffff).all()                                # nothing written past the end
     finally:
         L.mkv_set_tuning(b"pack_three_pass", 0)
+        L.mkv_set_tuning(b"pack_threads", PACK_THREADS_DEFAULT)
 
 
 @pytest.mark.parametrize("scheme,selfd", [(0, 1), (1, 1), (0, 0), (1, 0)])

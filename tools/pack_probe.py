@@ -24,8 +24,9 @@ def timed(fn, n=50):
     return a.elapsed_time(b) / n * 1e3
 
 
-def run(g, n_get, n_set, three):
+def run(g, n_get, n_set, three, threads=1024):
     L.mkv_set_tuning(b"pack_three_pass", three)
+    L.mkv_set_tuning(b"pack_threads", threads)
     rng = np.random.default_rng(1)
     mem_p_agg = 30 + (g.bit_length() - 1)
     mask, shift = (1 << (mem_p_agg - 6)) - 1, 24
@@ -47,12 +48,14 @@ def run(g, n_get, n_set, three):
                             cap_set, _dev_ptr(perm), _dev_ptr(scratch), scratch.numel() * 4, _dev_ptr(overflow), _stream_ptr(None))
     t_pack = timed(pack)
     t_un = timed(lambda: L.mkv_unpack_results(_dev_ptr(back), _dev_ptr(perm), n_get, _dev_ptr(out), _stream_ptr(None))) if n_get else 0.0
-    print(f"G={g} n_get={n_get} n_set={n_set} three_pass={three}: pack {t_pack:.1f} us  un-pack {t_un:.1f} us  "
+    print(f"G={g} n_get={n_get} n_set={n_set} three_pass={three} threads={threads}: pack {t_pack:.1f} us  un-pack {t_un:.1f} us  "
           f"overflow {int(overflow.item())}")
 
 
 for g in ([int(a) for a in sys.argv[1:]] or [1, 2, 8]):
-    run(g, 996148, 52428, 0)
+    for th in (1024, 512, 256):
+        run(g, 996148, 52428, 0, th)
+        run(g, 524288, 524288, 0, th)
     run(g, 996148, 0, 0)
     run(g, 0, 52428, 0)
     run(g, 524288, 524288, 0)

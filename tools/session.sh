@@ -1,16 +1,15 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s32; mkdir -p $d
-p() { python - "$1" "$2" <<'PY'
-import json, sys
-try:
-    x = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
-    print(sys.argv[2], x["value"], x["ms_per_step"], x.get("roofline",{}).get("launch_us"))
-except Exception as e:
-    print(sys.argv[2], "bad", e)
-PY
-}
-for mb in 128 205 256 384; do
-for cfg in "lf085 --steps 40 --warmup 5 --lf 0.85" "drv --steps 20 --warmup 5" "lf05 --steps 20 --warmup 5 --lf 0.5"; do
-  set -- $cfg; name=$1; shift
-  MKV_MARK_BLOCKS=$mb timeout 300 python bench.py --no-cpu --no-pcie --no-abi "$@" > $d/mb${mb}_$name.json 2>> $d/r4.err; p $d/mb${mb}_$name.json mb${mb}_$name
-done; done
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s34; mkdir -p $d
+timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $d/pytest.txt
+MKV_FUZZ_CASES=400 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -2 | tee $d/fuzz.txt
+line() { python bench.py --no-cpu --no-pcie --no-abi "$@" 2>&1 | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('$1 $2 $3 $4 $5 $6', j['value'], j['ms_per_step']*1000, j.get('repeats',{}).get('mops'))"; }
+python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $d/drv.json; python -c "
+import json; j=json.load(open('$d/drv.json')); print('drv', j['value'], j['repeats'], j['abi_three_call'], j['roofline'])"
+line --steps 20 --warmup 5 --lf 0.5
+line --steps 20 --warmup 5 --lf 0.85
+line --steps 20 --warmup 5 --lf 0.2
+line --steps 20 --warmup 5 --workload zipf50
+line --steps 100 --warmup 5 --workload zipf50
+line --steps 20 --warmup 5 --workload zipf95 --sets upd
+line --steps 20 --warmup 5 --workload zipf50 --sets upd
