@@ -428,8 +428,7 @@ def main():
                "us_per_step": [round(e / args.steps * 1e6, 2) for e in elapsed_runs],
                "spread": round((max(elapsed_runs) - min(elapsed_runs)) / elapsed, 4)}
     if args.update_info and not sharded:
-        print("update info:", engine.idx.last_update_info(run_stream, cycle_insert=True),
-              "tail phases us:", engine.idx.tail_phases_us(run_stream, cycle_insert=True), file=sys.stderr)
+        print("update info:", engine.idx.last_update_info(run_stream, cycle_insert=True), file=sys.stderr)
 
     # the results of the LAST timed batch, checked like those of the warm-up: every GET of a
     # pre-loaded key must have come back with its own key id in its own place (all ranks)

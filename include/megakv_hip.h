@@ -158,6 +158,11 @@ typedef struct mkv_update_info_s {
 int mkv_last_update_info(void *stream, mkv_update_info_t *info);
 /* cycle_insert != 0: the insert half of the last mkv_cycle on `stream` */
 int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_update_info_t *info);
+/* ---- diagnostics build only ---------------------------------------------------
+ * (make -C megakv_amd/csrc DIAG=1 -> libmegakv_hip_diag.so, compiled with -DMKV_DIAGNOSTICS.  The
+ * product library and lib/libgpuhash.a export none of these and refuse the tunings listed under
+ * "diagnostics build" below.) */
+#ifdef MKV_DIAGNOSTICS
 /* diagnostics: microseconds the last call's tail kernels spent per phase (roll-back, gather,
  * exact replay below a barrier, retag, in-group rounds, serial replay, two gather details; then
  * inside the grid-wide rounds: register, meeting, decide, meeting, election + meeting, commit,
@@ -173,6 +178,10 @@ long long mkv_debug_random_read(const void *buf, long long buf_bytes, int gran, 
  * 40-bit round stamps ran low (the tail kernel flags it, a later call acts on it); -1: no
  * such workspace. */
 int mkv_debug_stamp_resets(void *stream, int cycle_insert);
+/* what the workspace holds for request idx after the last pass: out[0] = tag, out[1..4] = the
+ * request cache {sig, hash, loc, flags}, out[5..8] = its undo record.  Synchronises the device. */
+int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9]);
+#endif
 
 /* ---- request preparation on the device ------------------
  * What the reference's receiver does per packet on the CPU, for a batch of
@@ -319,11 +328,9 @@ void mkv_pipe_destroy(mkv_pipe_t *p);
 void *mkv_host_alloc(int64_t bytes);    /* pinned host memory (hipHostMalloc) */
 void mkv_host_free(void *ptr);
 
-/* Tuning knobs (all but the debug ones also environment variables MKV_<NAME>, read once at start-up):
+/* Tuning knobs (also environment variables MKV_<NAME>, read once at start-up):
  *   search:  "search_u" (1/2/4/8 requests in flight per lane group), "search_nt" (non-temporal
- *            table loads), "search_wide" (8 lanes per request, one 64-byte access per bucket),
- *            "search_lds" (signature rows staged in LDS and probed with a wave ballot, the location
- *            fetched by a second load: the reference's structure, kept for the measurement);
+ *            table loads);
  *   update:  "tail_rounds" (0..48 reservation rounds of the tail), "tail_groups" (work-groups of
  *            the tail launch, 1..64), "grid_min" (a final tail list longer than this runs its
  *            rounds on all of them), "insert_chunk" (requests per pass of a hinted insert),
@@ -332,11 +339,19 @@ void mkv_host_free(void *ptr);
  *            search launch), "mark_alone_blocks" (of a mark launch of its own), "round_blocks"
  *            (work-groups of rounds 1 and 2; 512: more lanes in flight were slower),
  *            "grid_progress" (grid-wide tail rounds go on while they resolve at least this many
- *            requests), "req_cap" (default request capacity of an update workspace);
- *   sharded: "pack_three_pass";
- *   tests:   "debug_first_stamp", "debug_skip" (1 / 2: the tail takes the general way / the
- *            region-suffix fall-back for every order violation of an eviction chain; + 4: the
- *            grid-wide rounds leave every eviction chain to the tail).
+ *            requests), "req_cap" (default request capacity of an update workspace), "dup_groups",
+ *            "lazy_alt", "self_help" (round 1: a bucket's second registrant commits beside its
+ *            owner), "merge_round2" (round 2 inside the tail launch: 0 never, 1 while round 1
+ *            leaves it next to nothing, 2 always), "merge_max" (... and the batch is no larger);
+ *   sharded: "pack_threads" (lanes per work-group of the one-launch pack: 256 / 512 / 1024).
+ * Diagnostics build only (MKV_EINVAL in the product library):
+ *            "search_wide" (8 lanes per request, one 64-byte access per bucket), "search_lds"
+ *            (signature rows staged in LDS and probed with a wave ballot, the location fetched by
+ *            a second load: the reference's structure) -- the two search layouts that were built,
+ *            measured and withdrawn; "pack_three_pass" (forces the pack's
+ *            fall-back); "debug_first_stamp"; "debug_skip" (1 / 2: the tail takes the general way /
+ *            the region-suffix fall-back for every order violation of an eviction chain; + 4:
+ *            the grid-wide rounds leave every eviction chain to the tail).
  * Results never depend on them; they exist for measurement and tests. */
 int mkv_set_tuning(const char *name, long long value);
 

@@ -38,6 +38,8 @@ __global__ __launch_bounds__(256) void k_search(const uint2 *__restrict__ in,
 	search_body<U, ZERO_MISS, NT>(blockIdx.x, in, out, table, n, hash_mask, blk_mask);
 }
 
+// (the two other layouts of the search that were built and measured, DESIGN.md 5.1: diagnostics builds only)
+#ifdef MKV_DIAGNOSTICS
 template <int U, bool ZERO_MISS, bool NT>
 __global__ __launch_bounds__(256) void k_search_wide(const uint2 *__restrict__ in,
 		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n,
@@ -53,6 +55,7 @@ __global__ __launch_bounds__(256) void k_search_lds(const uint2 *__restrict__ in
 {
 	search_body_lds<ZERO_MISS>(blockIdx.x, in, out, table, n, hash_mask, blk_mask);
 }
+#endif
 
 template <int U>
 static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int64_t n,
@@ -65,6 +68,7 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 		return MKV_ETOOBIG;
 	dim3 grid((unsigned)blocks), block(256);
 	const bool zero = (flags & MKV_SEARCH_ZERO_MISS) != 0;
+#ifdef MKV_DIAGNOSTICS
 	if (tuning().search_lds) {
 		// 64 requests per block of 4 waves
 		const int64_t lblocks = (n + 63) / 64;
@@ -84,6 +88,7 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 			MKV_LAUNCH_TIMED((k_search_wide<U, false, false>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
+#endif
 	if (zero) {
 		if (nt)
 			MKV_LAUNCH_TIMED((k_search<U, true, true>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
@@ -108,10 +113,7 @@ Tuning &tuning()
 			v.search_u = 4;
 		s = getenv("MKV_SEARCH_NT");
 		v.search_nt = s ? atoi(s) != 0 : 0;
-		s = getenv("MKV_SEARCH_WIDE");
-		v.search_wide = s ? atoi(s) != 0 : 0;
-		s = getenv("MKV_SEARCH_LDS");
-		v.search_lds = s ? atoi(s) != 0 : 0;
+		v.search_wide = v.search_lds = 0;      // (diagnostics builds: mkv_set_tuning)
 		s = getenv("MKV_TAIL_ROUNDS");
 		v.tail_rounds = s ? atoi(s) : 48;
 		if (v.tail_rounds < 0) v.tail_rounds = 0;
@@ -130,8 +132,7 @@ Tuning &tuning()
 		v.mark_blocks = s ? atoi(s) : 128;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
-		s = getenv("MKV_PACK_THREE_PASS");
-		v.pack_three_pass = s ? atoi(s) != 0 : 0;
+		v.pack_three_pass = 0;                 // (diagnostics builds: mkv_set_tuning forces the fall-back)
 		s = getenv("MKV_PACK_THREADS");
 		v.pack_threads = s ? atoi(s) : 1024;
 		if (v.pack_threads != 256 && v.pack_threads != 512) v.pack_threads = 1024;
@@ -220,10 +221,12 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.search_u = (int)value;
 	} else if (!strcmp(name, "search_nt")) {
 		t.search_nt = value != 0;
+#ifdef MKV_DIAGNOSTICS
 	} else if (!strcmp(name, "search_wide")) {
 		t.search_wide = value != 0;
 	} else if (!strcmp(name, "search_lds")) {
 		t.search_lds = value != 0;
+#endif
 	} else if (!strcmp(name, "tail_rounds")) {
 		if (value < 0 || value > 48)
 			return MKV_EINVAL;
@@ -236,8 +239,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 1024)
 			return MKV_EINVAL;
 		t.mark_blocks = (int)value;
+#ifdef MKV_DIAGNOSTICS
 	} else if (!strcmp(name, "pack_three_pass")) {
 		t.pack_three_pass = value != 0;
+#endif
 	} else if (!strcmp(name, "pack_threads")) {
 		if (value != 256 && value != 512 && value != 1024)
 			return MKV_EINVAL;
@@ -274,8 +279,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		if (value < 1 || value > 65536)
 			return MKV_EINVAL;
 		t.mark_alone_blocks = (int)value;
+#ifdef MKV_DIAGNOSTICS
 	} else if (!strcmp(name, "debug_first_stamp")) {
 		t.debug_first_stamp = value;
+#endif
 	} else if (!strcmp(name, "dup_groups")) {
 		t.dup_groups = value != 0;
 	} else if (!strcmp(name, "lazy_alt")) {
@@ -288,8 +295,10 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.merge_round2 = (int)value;
 	} else if (!strcmp(name, "merge_max")) {
 		t.merge_max = value;
+#ifdef MKV_DIAGNOSTICS
 	} else if (!strcmp(name, "debug_skip")) {
 		t.debug_skip = (int)value;
+#endif
 	} else if (!strcmp(name, "req_cap")) {
 		if (value < 1024)
 			return MKV_EINVAL;
@@ -307,6 +316,7 @@ extern "C" int mkv_tuning_is_default_search(void)
 	return t.search_u == 4 && t.search_nt == 0 && t.search_wide == 0 && t.search_lds == 0;
 }
 
+#ifdef MKV_DIAGNOSTICS
 // ---- diagnostics: what the memory system gives for random reads ---------------------
 // Every 4-lane group reads `gran`-byte aligned pieces (64, 128 or 256 bytes: 16 bytes per
 // lane and step) at pseudo-random places of a buffer, `unroll` pieces in flight per group
@@ -400,3 +410,4 @@ extern "C" long long mkv_debug_random_read(const void *buf, long long buf_bytes,
 		return MKV_EHIP;
 	return (long long)grid.x * 64 * pieces_per_group * gran;
 }
+#endif  // MKV_DIAGNOSTICS

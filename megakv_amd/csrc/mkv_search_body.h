@@ -95,6 +95,7 @@ __device__ __forceinline__ uint32_t dpp_from_plus4(uint32_t v)
 	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x104, 0xF, 0xF, true);
 }
 
+#ifdef MKV_DIAGNOSTICS
 // The same search with 8 lanes per request: a quad owns one bucket, each lane one 16-byte
 // quarter of it (sig[0..3], sig[4..7], loc[0..3], loc[4..7]), so a bucket is ONE 64-byte
 // access of one load instruction instead of two 32-byte halves of two instructions -- half
@@ -222,6 +223,7 @@ __device__ __forceinline__ void search_body_lds(uint32_t block, const uint2 *__r
 		}
 	}
 }
+#endif  // MKV_DIAGNOSTICS
 
 // Search of the slots a shard received (padded exchange format, mkv_route.hip):
 // linear block index -> (slot, 256-request chunk); the slot's request count is read

@@ -3552,14 +3552,15 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
-	// (time per phase: diagnostics builds only, make EXTRA=-DMKV_DIAGNOSTICS -- sixteen registers held for the whole
+	// (time per phase: diagnostics builds only, make DIAG=1 -- sixteen registers held for the whole
 	// launch are more than this kernel has to spare)
 #ifdef MKV_DIAGNOSTICS
 	unsigned long long tick = wall_clock64();
 	uint32_t phase_ticks[16] = {0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u, 0u};
 #define MKV_PHASE(k) do { const unsigned long long now_ = wall_clock64(); phase_ticks[k] += (uint32_t)(now_ - tick); tick = now_; } while (0)
+	uint32_t *const grid_ticks = phase_ticks + 8;
 #else
-	uint32_t *const phase_ticks = nullptr;
+	uint32_t *const phase_ticks = nullptr, *const grid_ticks = nullptr;
 #define MKV_PHASE(k) ((void)0)
 #endif
 	const uint32_t total_all = ctl->total;
@@ -3694,7 +3695,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
 			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
 			left = grid_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, glist, m, s_rbar, s_rmin, s_below, &s_progress,
-					&s_left, &s_dupw, kGridRoundsMax, &used, &par, phase_ticks ? phase_ticks + 8 : nullptr, tv, rounds_total, fold, grid_progress);
+					&s_left, &s_dupw, kGridRoundsMax, &used, &par, grid_ticks, tv, rounds_total, fold, grid_progress);
 			if (wg != 0)
 				return;
 			grid_mode = false;                     // (later turns of this loop are work-group 0's alone)
@@ -4983,6 +4984,8 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	return MKV_OK;
 }
 
+// ---- diagnostics builds only (make DIAG=1: ../_lib/libmegakv_hip_diag.so) ----
+#ifdef MKV_DIAGNOSTICS
 // diagnostics (tests/debug/streams_probe.py): what the workspace holds for request idx after the last
 // pass -- out[0] = tag, out[1..4] = request cache {sig, hash, loc, flags}, out[5..8] = undo record
 extern "C" int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9])
@@ -5062,3 +5065,4 @@ extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_u
 		out_us[k] = (float)h.tail_phase[k] * 0.01f;
 	return MKV_OK;
 }
+#endif  // MKV_DIAGNOSTICS

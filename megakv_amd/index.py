@@ -138,8 +138,9 @@ class HashIndex:
       delete:  delem [n,3]
     """
 
-    def __init__(self, geom: Geometry = Geometry(), device=None):
-        self.lib = load_library()   # raises if the HIP library is absent
+    def __init__(self, geom: Geometry = Geometry(), device=None, lib=None):
+        # (lib: tests pass the diagnostics build, load_library(diagnostics=True))
+        self.lib = lib if lib is not None else load_library()   # raises if the HIP library is absent
         if not torch.cuda.is_available():
             raise MkvError("no GPU visible: the hash index has no CPU path")
         self.geom = geom
@@ -223,6 +224,8 @@ class HashIndex:
         """diagnostics: time of the last call's tail kernels per phase (roll-back, gather,
         exact replay, retag, in-group rounds, serial), microseconds"""
         out = (ctypes.c_float * 16)()
+        if not hasattr(self.lib, "mkv_debug_tail_phases"):
+            raise MkvError("tail_phases_us: diagnostics build only (HashIndex(lib=load_library(diagnostics=True)))")
         _check(self.lib.mkv_debug_tail_phases(_stream_ptr(stream), 1 if cycle_insert else 0, out),
                "mkv_debug_tail_phases")
         return [round(float(x), 1) for x in out]

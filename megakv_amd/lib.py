@@ -5,6 +5,9 @@ import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "_lib", "libmegakv_hip.so")
+# the same sources built with -DMKV_DIAGNOSTICS (make -C megakv_amd/csrc DIAG=1): the mkv_debug_* entry points and
+# the path-forcing tunings of tests and tools; never what bench.py or a host links
+DIAG_LIB_PATH = os.path.join(_HERE, "_lib", "libmegakv_hip_diag.so")
 
 
 class LibraryMissing(RuntimeError):
@@ -37,7 +40,7 @@ ABI_SYMBOLS = [
     "mkv_search", "mkv_insert", "mkv_delete", "mkv_reserve", "mkv_release_all",
     "mkv_last_update_info", "mkv_route_requests", "mkv_unroute_results", "mkv_version",
     "mkv_set_tuning", "mkv_cycle", "mkv_cycle_workers", "mkv_insert_hinted", "mkv_pack_slot_words", "mkv_pack_scratch_bytes", "mkv_pack_requests",
-    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
+    "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
     "mkv_forget_stream", "mkv_dropped_batches", "mkv_workspace_bytes", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
@@ -47,21 +50,34 @@ ABI_SYMBOLS = [
     "cudaGetLastError", "cudaGetErrorString", "cudaMemGetInfo",
 ]
 
+DIAG_SYMBOLS = ["mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_debug_request"]
+
 _lib = None
+_diag_lib = None
 
 
-def load_library():
-    global _lib
-    if _lib is not None:
-        return _lib
+def load_library(diagnostics=False):
+    """The product library; diagnostics=True: the diagnostics build (a second, independent copy
+    of the library in this process -- its workspaces and tunings are its own)."""
+    global _lib, _diag_lib
+    if diagnostics:
+        if _diag_lib is None:
+            _diag_lib = _load(DIAG_LIB_PATH, True)
+        return _diag_lib
+    if _lib is None:
+        _lib = _load(LIB_PATH, False)
+    return _lib
+
+
+def _load(LIB_PATH, diagnostics):
     if not os.path.exists(LIB_PATH):
         raise LibraryMissing(
             f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "or `make -C megakv_amd/csrc`.  There is no CPU fallback.")
+            f"or `make -C megakv_amd/csrc{' DIAG=1' if diagnostics else ''}`.  There is no CPU fallback.")
     L = ctypes.CDLL(LIB_PATH)
     P, I64, U32, INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
     G = ctypes.POINTER(MkvGeom)
-    for name in ABI_SYMBOLS:
+    for name in ABI_SYMBOLS + (DIAG_SYMBOLS if diagnostics else []):
         if not hasattr(L, name):
             raise LibraryMissing(f"{LIB_PATH} does not export {name}")
     L.gpu_hash_search.restype = None
@@ -99,12 +115,13 @@ def load_library():
     L.mkv_last_update_info.argtypes = [P, ctypes.POINTER(MkvUpdateInfo)]
     L.mkv_last_update_info_ex.restype = INT
     L.mkv_last_update_info_ex.argtypes = [P, INT, ctypes.POINTER(MkvUpdateInfo)]
-    L.mkv_debug_random_read.restype = ctypes.c_longlong
-    L.mkv_debug_random_read.argtypes = [P, ctypes.c_longlong, INT, ctypes.c_longlong, ctypes.c_longlong, P, P]
-    L.mkv_debug_stamp_resets.restype = INT
-    L.mkv_debug_stamp_resets.argtypes = [P, INT]
-    L.mkv_debug_tail_phases.restype = INT
-    L.mkv_debug_tail_phases.argtypes = [P, INT, ctypes.POINTER(ctypes.c_float)]
+    if diagnostics:
+        L.mkv_debug_random_read.restype = ctypes.c_longlong
+        L.mkv_debug_random_read.argtypes = [P, ctypes.c_longlong, INT, ctypes.c_longlong, ctypes.c_longlong, P, P]
+        L.mkv_debug_stamp_resets.restype = INT
+        L.mkv_debug_stamp_resets.argtypes = [P, INT]
+        L.mkv_debug_tail_phases.restype = INT
+        L.mkv_debug_tail_phases.argtypes = [P, INT, ctypes.POINTER(ctypes.c_float)]
     L.mkv_route_requests.restype = INT
     L.mkv_route_requests.argtypes = [P, INT, I64, U32, U32, INT, P, P, P, P, I64, P]
     L.mkv_pack_slot_words.restype = I64
@@ -160,5 +177,4 @@ def load_library():
     L.mkv_set_tuning.restype = INT
     L.mkv_set_tuning.argtypes = [ctypes.c_char_p, ctypes.c_longlong]
     L.mkv_version.restype = ctypes.c_char_p
-    _lib = L
     return L

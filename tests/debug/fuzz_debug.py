@@ -19,7 +19,7 @@ def main():
     seed = int(sys.argv[1])
     over = dict(a.split("=") for a in sys.argv[2:])
     rng = np.random.default_rng(1000 + seed)
-    L = load_library()
+    L = load_library(diagnostics=True)
     mem_p = int(rng.integers(10, 19))
     iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
     scheme = int(rng.integers(0, 2))
@@ -41,7 +41,7 @@ def main():
     fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
     sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
     exp = random_table(g, rng, fill, sig_space)
-    idx = HashIndex(g)
+    idx = HashIndex(g, lib=L)
     idx.load_table(exp)
     nslots = g.nbuckets * 8
     print(dict(mem_p=mem_p, iblock_p=iblock_p, scheme=scheme, max_cuckoo=max_cuckoo, fill=fill, sig_space=sig_space))

@@ -9,11 +9,11 @@ import megakv_amd as M
 from megakv_amd.lib import load_library
 from oracle import oracle as O
 ns = int(sys.argv[1])
-L = load_library()
+L = load_library(diagnostics=True)      # (the diagnostics build: make -C megakv_amd/csrc DIAG=1)
 for a in sys.argv[2:]:
     k, v = a.split("="); L.mkv_set_tuning(k.encode(), int(v))
 g = M.Geometry(mem_p=20); og = O.geom(mem_p=20)
-idx = M.HashIndex(g); exp = O.new_table(og)
+idx = M.HashIndex(g, lib=L); exp = O.new_table(og)
 rng = np.random.default_rng(12)
 streams = [torch.cuda.Stream() for _ in range(ns)]
 pool = rng.integers(1, 2**32, size=(30000, 3), dtype=np.uint64).astype(np.uint32)

@@ -10,11 +10,15 @@ import pytest
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def declared_functions():
+def declared_functions(diagnostics=False):
+    """what the headers declare: outside their `#ifdef MKV_DIAGNOSTICS` sections (the product
+    library), or inside them (what the diagnostics build adds)"""
     names = set()
     for h in ("libgpuhash.h", "megakv_hip.h", "cuda_runtime.h"):
         txt = open(os.path.join(ROOT, "include", h)).read()
         txt = re.sub(r"/\*.*?\*/", "", txt, flags=re.S)
+        diag = "".join(re.findall(r"#ifdef MKV_DIAGNOSTICS\n(.*?)#endif", txt, flags=re.S))
+        txt = diag if diagnostics else re.sub(r"#ifdef MKV_DIAGNOSTICS\n.*?#endif", "", txt, flags=re.S)
         txt = re.sub(r"#define[^\n]*(\\\n[^\n]*)*", "", txt)
         for m in re.finditer(r"\b(gpu_[a-z_]+|mkv_[a-z_]+|cuda[A-Z][A-Za-z]+)\s*\(", txt):
             names.add(m.group(1))
@@ -32,6 +36,20 @@ def test_library_exports_every_declared_symbol():
     for name in decl:
         assert hasattr(L, name), f"{name} declared in include/ but not exported"
         assert name in ABI_SYMBOLS, f"{name} not covered by the loader's symbol list"
+
+
+def test_diagnostics_stay_out_of_the_product_library():
+    """mkv_debug_* entry points exist in the diagnostics build (libmegakv_hip_diag.so) only; neither
+    the product shared object nor the static archive a C host links has any."""
+    from megakv_amd.lib import DIAG_LIB_PATH, DIAG_SYMBOLS, LIB_PATH, load_library
+    decl = declared_functions(diagnostics=True)
+    assert sorted(decl) == sorted(DIAG_SYMBOLS)
+    D = load_library(diagnostics=True)
+    for name in decl:
+        assert hasattr(D, name), f"{name} missing from {DIAG_LIB_PATH}"
+    for lib in (LIB_PATH, os.path.join(ROOT, "lib", "libgpuhash.a")):
+        syms = subprocess.check_output(["nm", "--defined-only", lib], text=True, stderr=subprocess.DEVNULL)
+        assert "mkv_debug" not in syms, lib
 
 
 def test_layouts_match_reference_header():

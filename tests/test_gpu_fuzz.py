@@ -1,7 +1,11 @@
 """Seeded fuzzing of insert / delete / search parity over random geometries
 (MEM_P, IBLOCK_P, MAX_CUCKOO_NUM, scheme), fills, key distributions, block
 splits and tuning (chunk size, tail rounds, tail work-groups, grid-wide tail rounds).  Every case: GPU result == oracle,
-bit for bit, for a sequence of operations on one table."""
+bit for bit, for a sequence of operations on one table.
+
+Two builds of the same sources are under test: the product library, and -- for the cases that FORCE
+a path the product takes rarely (tuning "debug_skip": how the tail takes commits back, every eviction
+chain left to the tail) -- the diagnostics build, the only one that has that tuning."""
 import numpy as np
 import pytest
 import torch
@@ -17,16 +21,18 @@ pytestmark = pytest.mark.gpu
 @pytest.fixture(autouse=True)
 def _defaults():
     yield
-    L = load_library()
-    L.mkv_set_tuning(b"tail_rounds", 48)
-    L.mkv_set_tuning(b"insert_chunk", 65536)
-    L.mkv_set_tuning(b"tail_groups", 32)
-    L.mkv_set_tuning(b"grid_min", 2048)
-    L.mkv_set_tuning(b"calm_factor", 4)
-    L.mkv_set_tuning(b"debug_skip", 0)
-    L.mkv_set_tuning(b"round_blocks", 512)
-    L.mkv_set_tuning(b"self_help", 1)
-    L.mkv_set_tuning(b"merge_round2", 1)
+    for diag in (False, True):
+        L = load_library(diag)
+        L.mkv_set_tuning(b"tail_rounds", 48)
+        L.mkv_set_tuning(b"insert_chunk", 65536)
+        L.mkv_set_tuning(b"tail_groups", 32)
+        L.mkv_set_tuning(b"grid_min", 2048)
+        L.mkv_set_tuning(b"calm_factor", 4)
+        if diag:
+            L.mkv_set_tuning(b"debug_skip", 0)
+        L.mkv_set_tuning(b"round_blocks", 512)
+        L.mkv_set_tuning(b"self_help", 1)
+        L.mkv_set_tuning(b"merge_round2", 1)
 
 
 @pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
@@ -59,15 +65,16 @@ def test_order_violations_of_late_chains(path, chunk):
     requests walk late and step on buckets later requests were already committed on.  Each of
     the three ways of taking those commits back (a sole commit alone / the commits involved /
     the region suffix) must leave the oracle's table."""
-    L = load_library()
-    L.mkv_set_tuning(b"debug_skip", path)
+    L = load_library(diagnostics=path != 0)
+    if path:
+        assert L.mkv_set_tuning(b"debug_skip", path) == 0
     L.mkv_set_tuning(b"insert_chunk", chunk)
     L.mkv_set_tuning(b"calm_factor", 1)
     g = Geometry(mem_p=20)
     og = ogeom(g)
     rng = np.random.default_rng(31 + path)
     exp = random_table(g, rng, 0.75, 1 << 31)
-    idx = HashIndex(g)
+    idx = HashIndex(g, lib=L)
     idx.load_table(exp)
     violations = late = 0
     for step in range(4):
@@ -85,8 +92,15 @@ def test_order_violations_of_late_chains(path, chunk):
 
 def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
-    L = load_library()
     env = __import__("os").environ
+    # how the tail deals with an order violation of a late eviction chain: as designed (a sole later
+    # commit is taken back alone), always the general way, always the region-suffix fall-back
+    # (+ 4: rounds 1 and 2 leave every eviction chain to the tail) -- anything but "as designed"
+    # is the diagnostics build's
+    rng3 = np.random.default_rng(11000 + seed)
+    skip = int(rng3.choice([0, 0, 1, 2])) + int(rng3.choice([0, 0, 0, 4]))
+    skip = int(env.get("MKV_FUZZ_DEBUG_SKIP", forced.get(b"debug_skip", skip)))
+    L = load_library(diagnostics=skip != 0)
     big = int(env.get("MKV_FUZZ_BIG", "0"))          # 1: tables up to 2 MiB, batches up to 300 K requests
     mem_p = int(rng.integers(10, 19)) + (int(rng.integers(0, 4)) if big else 0)
     iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
@@ -100,28 +114,26 @@ def _run(seed, forced):
     L.mkv_set_tuning(b"tail_groups", int(rng2.choice([1, 2, 5, 32])))
     L.mkv_set_tuning(b"grid_min", int(rng2.choice([0, 0, 64, 2048])))
     L.mkv_set_tuning(b"calm_factor", int(rng2.choice([1, 4])))
-    # how the tail deals with an order violation of a late eviction chain: as designed (a sole later
-    # commit is taken back alone), always the general way, always the region-suffix fall-back
-    # (+ 4: rounds 1 and 2 leave every eviction chain to the tail)
-    rng3 = np.random.default_rng(11000 + seed)
-    L.mkv_set_tuning(b"debug_skip", int(rng3.choice([0, 0, 1, 2])) + int(rng3.choice([0, 0, 0, 4])))
+    if skip:
+        assert L.mkv_set_tuning(b"debug_skip", skip) == 0
     # work-groups of rounds 1 and 2: few make a work-group's queue of held-back requests run over
     L.mkv_set_tuning(b"round_blocks", int(rng3.choice([1, 3, 64, 512, 512])))
     # round 1's self-help of a bucket's second registrant, round 2 inside the tail launch: on (the default) or off
     rng4 = np.random.default_rng(17000 + seed)
     L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
     L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
-    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"debug_skip", b"round_blocks",
+    for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"round_blocks",
                  b"self_help", b"merge_round2"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
             L.mkv_set_tuning(name, int(v))
     for name, v in forced.items():
-        L.mkv_set_tuning(name, int(v))
+        if name != b"debug_skip":
+            L.mkv_set_tuning(name, int(v))
     fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
     sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
     exp = random_table(g, rng, fill, sig_space)
-    idx = HashIndex(g)
+    idx = HashIndex(g, lib=L)
     idx.load_table(exp)
     nslots = g.nbuckets * 8
     # request shapes beside uniformly random ones, drawn apart from the main stream of random

@@ -15,8 +15,8 @@ pytestmark = pytest.mark.gpu
 SCHEMES = [SCHEME_CUCKOO, SCHEME_2CHOICE]
 
 
-def set_tuning(name, value):
-    assert load_library().mkv_set_tuning(name.encode(), value) == 0
+def set_tuning(name, value, diagnostics=False):
+    assert load_library(diagnostics).mkv_set_tuning(name.encode(), value) == 0
 
 
 @pytest.fixture(autouse=True)
@@ -26,8 +26,20 @@ def _defaults():
     set_tuning("insert_chunk", 65536)
     set_tuning("search_u", 4)
     set_tuning("search_nt", 0)
-    set_tuning("search_wide", 0)
-    set_tuning("search_lds", 0)
+    set_tuning("search_u", 4, True)
+    set_tuning("search_wide", 0, True)
+    set_tuning("search_lds", 0, True)
+
+
+def test_product_library_has_no_diagnostics():
+    """The library a host links exports no mkv_debug_* entry point and refuses the tunings that
+    exist for tests and measurements of withdrawn layouts; the diagnostics build has them."""
+    L, D = load_library(), load_library(diagnostics=True)
+    for name in ("mkv_debug_request", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read"):
+        assert not hasattr(L, name) and hasattr(D, name)
+    for name in (b"debug_skip", b"debug_first_stamp", b"search_wide", b"search_lds", b"pack_three_pass"):
+        assert L.mkv_set_tuning(name, 0) != 0
+        assert D.mkv_set_tuning(name, 0) == 0
 
 
 # ---------------------------------------------------------------- search ----
@@ -71,13 +83,13 @@ def test_search_tuning_variants_agree(u, nt):
 def test_search_wide_layout_agrees(u, zero_miss, n):
     """The 8-lanes-per-request layout (one 64-byte access per bucket; slower, kept as a
     measured alternative: DESIGN 5.1) gives the same results, ragged tails included."""
-    set_tuning("search_u", u)
-    set_tuning("search_wide", 1)
+    set_tuning("search_u", u, True)
+    set_tuning("search_wide", 1, True)
     g = Geometry(mem_p=18)
     rng = np.random.default_rng(78 + n)
     img = random_table(g, rng, 0.6, sig_space=60)          # few signatures: in-bucket duplicates
     q = random_requests(g, rng, n, 60)[:, :2].copy()
-    idx = HashIndex(g)
+    idx = HashIndex(g, lib=load_library(diagnostics=True))
     idx.load_table(img)
     exp = np.zeros((n, 2), np.uint32) if zero_miss else np.full((n, 2), 0xABCD1234, np.uint32)
     O.search(ogeom(g), img, q, out=exp)
@@ -94,12 +106,12 @@ def test_search_lds_ballot_layout_agrees(zero_miss, n):
     request, ffs/clz for the slot, a dependent load for the location (the search the task's
     north star sketches; measured and kept as an alternative: DESIGN 5.1) -- gives the same
     results, in-bucket duplicates and ragged tails included."""
-    set_tuning("search_lds", 1)
+    set_tuning("search_lds", 1, True)
     g = Geometry(mem_p=18)
     rng = np.random.default_rng(178 + n)
     img = random_table(g, rng, 0.6, sig_space=60)
     q = random_requests(g, rng, n, 60, zero_low=0.1)[:, :2].copy()
-    idx = HashIndex(g)
+    idx = HashIndex(g, lib=load_library(diagnostics=True))
     idx.load_table(img)
     exp = np.zeros((n, 2), np.uint32) if zero_miss else np.full((n, 2), 0xABCD1234, np.uint32)
     O.search(ogeom(g), img, q, out=exp)
@@ -601,8 +613,9 @@ def test_round_stamps_running_low_clear_the_reservation_tables():
     """The reservation tables carry 40-bit round stamps that only grow.  A workspace started
     close to the end of that range (tests-only tuning) must ask the host to clear its tables
     (flag written by the tail kernel, acted on by a later call) and carry on with identical
-    results -- here across a few dozen insert/delete calls, most of them with chains."""
-    L = load_library()
+    results -- here across a few dozen insert/delete calls, most of them with chains.
+    (Diagnostics build: the product library cannot be told where to start its stamps.)"""
+    L = load_library(diagnostics=True)
     g = Geometry(mem_p=14, scheme=0)
     og = ogeom(g)
     L.mkv_release_all()
@@ -610,7 +623,7 @@ def test_round_stamps_running_low_clear_the_reservation_tables():
     try:
         rng = np.random.default_rng(99)
         exp = random_table(g, rng, 0.8, 1 << 20)
-        idx = HashIndex(g)
+        idx = HashIndex(g, lib=L)
         idx.load_table(exp)
         for step in range(40):
             e = random_requests(g, rng, int(rng.integers(200, 3000)), 1 << 20, hot=0.1)

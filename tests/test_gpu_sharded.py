@@ -38,10 +38,11 @@ def test_pack_layout(g, n_get, n_set, three_pass, threads):
     import torch
     from megakv_amd.lib import load_library
     from megakv_amd.index import _dev_ptr, _stream_ptr
-    L = load_library()
     if three_pass and threads != 1024:
         pytest.skip("the three-pass pack has one form")
-    L.mkv_set_tuning(b"pack_three_pass", three_pass)
+    L = load_library(diagnostics=bool(three_pass))      # (forcing the fall-back: the diagnostics build's tuning)
+    if three_pass:
+        assert L.mkv_set_tuning(b"pack_three_pass", 1) == 0
     assert L.mkv_set_tuning(b"pack_threads", threads) == 0
     try:
         rng = np.random.default_rng(g * 1000 + n_get % 97)
@@ -101,7 +102,8 @@ def test_pack_layout(g, n_get, n_set, three_pass, threads):
                     assert np.array_equal(o[:n_get], back[where]), "un-pack"
                     assert (o[n_get] == 0xffffffff).all()                                # nothing written past the end
     finally:
-        L.mkv_set_tuning(b"pack_three_pass", 0)
+        if three_pass:
+            L.mkv_set_tuning(b"pack_three_pass", 0)
         L.mkv_set_tuning(b"pack_threads", PACK_THREADS_DEFAULT)
 
 

@@ -27,8 +27,8 @@ def main():
     for a in sys.argv[4:]:
         if "=" in a:
             name, value = a.split("=")
-            assert M.lib.load_library().mkv_set_tuning(name.encode(), int(value)) == 0, a
-    idx = M.HashIndex(g)
+            assert M.lib.load_library(diagnostics=True).mkv_set_tuning(name.encode(), int(value)) == 0, a
+    idx = M.HashIndex(g, lib=M.lib.load_library(diagnostics=True))
     idx.reserve(max(batch, 1 << 20) + 8)
     P = W.preload_count(30, lf)
     t0 = time.time()

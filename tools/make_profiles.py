@@ -6,12 +6,13 @@ evidence under profiles/:
                                             (and of the launch-timing pass behind it), plus the PMC
                                             averages per launch over the timed region's dispatches
   profiles/search_traffic.json              HBM bytes per launch of the dominant kernel, read by bench.py
-usage: make_profiles.py <round> <tag> <workload-key> <warmup> <steps> <head>
-       e.g.  r02 default zipf95-mix 20 100 $(git rev-parse --short HEAD)
+usage: make_profiles.py <round> <tag> <workload-key> <warmup> <steps> <head> [repeats=3]
+       e.g.  r04 default zipf95-mix 20 100 $(git rev-parse --short HEAD)
 
-A bench.py run launches the step's kernels in this order: W warm-up steps, K timed steps, then
-(after the checks) the launch-timing pass.  One step = one dispatch of the dominant kernel
-(k_search_mark), so its dispatches number W .. W+K-1 are the timed region's."""
+A bench.py run launches the step's kernels in this order: W warm-up steps, R repeats of the K timed
+steps (each from the same restored table image), then (after the checks) the launch-timing pass.
+One step = one dispatch of the dominant kernel (k_search_mark), so its dispatches number
+W + r K .. W + (r+1) K - 1 are repeat r's timed region."""
 import collections
 import csv
 import glob
@@ -41,6 +42,7 @@ def steps_of(rows, key="k_search_mark"):
 
 def main():
     rnd, tag, key, W, K, head = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4]), int(sys.argv[5]), sys.argv[6]
+    R = int(sys.argv[7]) if len(sys.argv) > 7 else 3
     raw = os.path.join(ROOT, "gpurun_out", "profiles_raw", tag)
     out = os.path.join(ROOT, "profiles")
     os.makedirs(out, exist_ok=True)
@@ -60,7 +62,7 @@ def main():
     marks = steps_of(trows, dom)
     marks_set = set(marks)
     summary = {"round": rnd, "tag": tag, "head": head, "warmup": W, "steps": K,
-               "command": open(os.path.join(raw, "stats.err")).read()[:0] or "python3 bench.py " + " ".join(sys.argv[7:])}
+               "command": open(os.path.join(raw, "stats.err")).read()[:0] or "python3 bench.py " + " ".join(sys.argv[8:]), "repeats": R}
 
     cycle = ("k_search_mark", "k_search<", "k_round", "k_tail", "k_mark", "k_search_slots")
 
@@ -84,9 +86,15 @@ def main():
         d["_step_span_us"] = round(span, 2)
         return d
 
-    summary["timed_region"] = region(W, W + K)
-    if len(marks) > W + K + 8:
-        summary["launch_timing_pass"] = region(W + K + 4, len(marks))
+    reps = [region(W + r * K, W + (r + 1) * K) for r in range(R)]
+    spans = [x.get("_step_span_us") for x in reps]
+    summary["step_span_us_per_repeat"] = spans
+    order = sorted(range(R), key=lambda r: spans[r] if spans[r] is not None else 1e30)
+    summary["timed_region"] = reps[order[R // 2]]              # the median repeat (bench.py's `value`)
+    summary["timed_region_all_repeats"] = region(W, W + R * K)  # (its span includes the table restores in between)
+    summary["timed_region_all_repeats"].pop("_step_span_us", None)
+    if len(marks) > W + R * K + 8:
+        summary["launch_timing_pass"] = region(W + R * K + 4, len(marks))
     # --- PMC per launch, timed region's dispatches only
     pmc = collections.defaultdict(dict)
     for name in ("pmc_fetch", "pmc_write", "pmc_l2"):
@@ -98,9 +106,9 @@ def main():
         ids = [d for d, k in order]
         names = {d: k for d, k in order}
         dmarks = [d for d in ids if dom in names[d]]
-        if len(dmarks) <= W + K:
+        if len(dmarks) <= W + R * K:
             continue
-        lo, hi = dmarks[W], dmarks[W + K]
+        lo, hi = dmarks[W], dmarks[W + R * K]
         per = collections.defaultdict(lambda: collections.defaultdict(list))
         for r in crow:
             d = int(r["Dispatch_Id"])

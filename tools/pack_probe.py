@@ -8,7 +8,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from megakv_amd.lib import load_library
 from megakv_amd.index import _dev_ptr, _stream_ptr
-L = load_library()
+L = load_library(diagnostics=True)      # (the diagnostics build: make -C megakv_amd/csrc DIAG=1)
 
 
 def timed(fn, n=50):

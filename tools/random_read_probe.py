@@ -13,7 +13,7 @@ sys.path.insert(0, ROOT)
 from megakv_amd.lib import load_library  # noqa: E402
 from megakv_amd.index import _dev_ptr, _stream_ptr  # noqa: E402
 
-L = load_library()
+L = load_library(diagnostics=True)      # (the diagnostics build: make -C megakv_amd/csrc DIAG=1)
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
 for mib in (1024, 16):
     buf = torch.empty(mib << 18, dtype=torch.int32, device="cuda").random_()

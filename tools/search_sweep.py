@@ -22,9 +22,9 @@ def dev(a):
 
 def main():
     keying = W.KEYING_MIX if (len(sys.argv) < 2 or sys.argv[1] == "mix") else W.KEYING_REF
-    L = load_library()
+    L = load_library(diagnostics=True)
     g = M.Geometry(mem_p=30)
-    idx = M.HashIndex(g)
+    idx = M.HashIndex(g, lib=M.lib.load_library(diagnostics=True))
     P = W.preload_count(30, 0.2)
     for lo in range(1, P, 1 << 20):
         k = np.arange(lo, min(lo + (1 << 20), P), dtype=np.uint32)

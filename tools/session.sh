@@ -1,15 +1,10 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s34; mkdir -p $d
-timeout 1500 python -m pytest tests -m gpu -x -q 2>&1 | tail -3 | tee $d/pytest.txt
-MKV_FUZZ_CASES=400 timeout 1200 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | tail -2 | tee $d/fuzz.txt
-line() { python bench.py --no-cpu --no-pcie --no-abi "$@" 2>&1 | tail -1 | python -c "
-import sys,json; j=json.loads(sys.stdin.read()); print('$1 $2 $3 $4 $5 $6', j['value'], j['ms_per_step']*1000, j.get('repeats',{}).get('mops'))"; }
-python bench.py --steps 20 --warmup 5 2>&1 | tail -1 > $d/drv.json; python -c "
-import json; j=json.load(open('$d/drv.json')); print('drv', j['value'], j['repeats'], j['abi_three_call'], j['roofline'])"
-line --steps 20 --warmup 5 --lf 0.5
-line --steps 20 --warmup 5 --lf 0.85
-line --steps 20 --warmup 5 --lf 0.2
-line --steps 20 --warmup 5 --workload zipf50
-line --steps 100 --warmup 5 --workload zipf50
-line --steps 20 --warmup 5 --workload zipf95 --sets upd
-line --steps 20 --warmup 5 --workload zipf50 --sets upd
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s36; mkdir -p $d
+timeout 1800 python -m pytest tests -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5 | tee $d/pytest.txt
+MKV_FUZZ_CASES=300 MKV_FUZZ_CYCLE_CASES=100 MKV_FUZZ_NODEL_CASES=100 timeout 1500 python -m pytest tests/test_gpu_fuzz.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror" | tail -5 | tee $d/fuzz.txt
+bash tools/collect_profiles.sh driver --steps 20 --warmup 5 2>&1 | tail -6
+bash tools/collect_profiles.sh default 2>&1 | tail -6
+bash tools/collect_profiles.sh get100 --workload get100 --prewarm-ms 0 --no-abi 2>&1 | tail -6
+PMC=0 bash tools/collect_profiles.sh zipf50 --workload zipf50 --steps 20 --warmup 5 2>&1 | tail -3
+PMC=0 bash tools/collect_profiles.sh supd --sets upd --steps 20 --warmup 5 2>&1 | tail -3
+PMC=0 bash tools/collect_profiles.sh zipf50upd --workload zipf50 --sets upd --steps 20 --warmup 5 2>&1 | tail -3

@@ -24,10 +24,10 @@ def main():
     lf, batch, nb = float(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     sets = sys.argv[4] if len(sys.argv) > 4 else "upd"
     scheme = M.SCHEME_2CHOICE if (len(sys.argv) > 5 and sys.argv[5] == "2choice") else M.SCHEME_CUCKOO
-    L = M.lib.load_library()
+    L = M.lib.load_library(diagnostics=True)
     assert hasattr(L, "mkv_debug_trace"), "build with EXTRA=-DMKV_TRACE"
     g = M.Geometry(mem_p=30, scheme=scheme)
-    idx = M.HashIndex(g)
+    idx = M.HashIndex(g, lib=M.lib.load_library(diagnostics=True))
     idx.reserve(max(batch, 1 << 20) + 8)
     P = W.preload_count(30, lf)
     for lo in range(1, P, 1 << 20):
