@@ -1,0 +1,52 @@
+#!/usr/bin/env python3
+"""What the tail launch of a bench.py step spends where: the step's workload through the DIAGNOSTICS
+build (per-phase clocks in k_tail), update info and phase times per step.
+usage: tail_phases.py [zipf95|zipf50] [new|upd] [steps, default 8] [lf, default 0.2]
+phases (us): 0 roll-back, 1 gather, 2 exact replay below a barrier, 3 retag, 4 in-group rounds, 5 serial replay,
+6-7 gather details; 8.. inside the grid-wide rounds: register, meeting, decide, meeting, election + meeting,
+commit, meeting."""
+import argparse
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import bench  # noqa: E402
+import megakv_amd as M  # noqa: E402
+from megakv_amd.index import HashIndex  # noqa: E402
+from megakv_amd.lib import load_library  # noqa: E402
+
+
+def main():
+    wl = sys.argv[1] if len(sys.argv) > 1 else "zipf95"
+    sets = sys.argv[2] if len(sys.argv) > 2 else "new"
+    steps = int(sys.argv[3]) if len(sys.argv) > 3 else 8
+    lf = float(sys.argv[4]) if len(sys.argv) > 4 else 0.2
+    bench.late_imports()
+    args = argparse.Namespace(keying="mix", lf=lf, workload=wl, batch_log2=20, sets=sets, mem_p=30, memset=False,
+                              overlap="fused", graph=False, sorted_gets=False)
+    sg = bench.Stream(args, 0, 1, 30)
+    L = load_library(diagnostics=True)
+    eng = bench.SingleGpu(HashIndex(M.Geometry(mem_p=30), device="cuda:0", lib=L), args)
+    eng.preload(sg.P, sg.keying)
+    s = torch.cuda.Stream()
+    eng.reserve(s)
+    batches = [eng.stage(*sg.batch()) for _ in range(steps)]
+    torch.cuda.synchronize()
+    for i, b in enumerate(batches):
+        a, z = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(s)
+        eng.step(b, s, None)
+        z.record(s)
+        s.synchronize()
+        info = eng.idx.last_update_info(s, cycle_insert=True)
+        ph = eng.idx.tail_phases_us(s, cycle_insert=True)
+        keep = {k: info[k] for k in ("round1", "round2", "helped", "losers", "tail_parallel", "tail_serial", "undone",
+                                     "tail_rounds", "bar_chain", "bar_class")}
+        print(f"step {i}: {a.elapsed_time(z) * 1e3:7.1f} us  {keep}  tail phases us {ph}")
+
+
+if __name__ == "__main__":
+    main()
