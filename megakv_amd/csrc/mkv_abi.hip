@@ -195,5 +195,5 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 
 extern "C" const char *mkv_version(void)
 {
-	return "megakv_amd libgpuhash gfx950 r3";
+	return "megakv_amd libgpuhash gfx950 r4";
 }

@@ -331,11 +331,10 @@ constexpr uint32_t kNoWord = 0xffffffffu;
 // Duplicate -> overwrite loc; else empty -> claim; returns true when finished.
 // `pref_sig` is the ORIGINAL request's signature (slot preference, ref :301).
 template <bool COHERENT, bool LOG>
-__device__ __forceinline__ bool try_place(uint32_t *table, uint32_t b, uint32_t sig, uint32_t loc,
-		uint32_t pref_sig, Undo *u)
+__device__ __forceinline__ bool try_place_rows(uint32_t *table, uint32_t b, const uint4 &lo, const uint4 &hi, uint32_t sig,
+		uint32_t loc, uint32_t pref_sig, Undo *u)
 {
-	uint4 lo, hi;
-	load_sig_row<COHERENT>(table, b, lo, hi);
+	// (lo, hi: the bucket's signature row as the caller has just loaded it)
 	const uint32_t m = eq_mask(lo, hi, sig);
 	if (m) {
 		const uint64_t w = loc_word(b, (uint32_t)__ffs((int)m) - 1u);
@@ -362,6 +361,14 @@ __device__ __forceinline__ bool try_place(uint32_t *table, uint32_t b, uint32_t 
 		return true;
 	}
 	return false;
+}
+template <bool COHERENT, bool LOG>
+__device__ __forceinline__ bool try_place(uint32_t *table, uint32_t b, uint32_t sig, uint32_t loc,
+		uint32_t pref_sig, Undo *u)
+{
+	uint4 lo, hi;
+	load_sig_row<COHERENT>(table, b, lo, hi);
+	return try_place_rows<COHERENT, LOG>(table, b, lo, hi, sig, loc, pref_sig, u);
 }
 
 // delete in one bucket: zero the signature of every slot holding (sig, loc);
@@ -1287,13 +1294,13 @@ __device__ __forceinline__ bool shadow_live(const uint8_t *state, const Undo *un
 // bucket counts as used even when full: it was examined.)
 // *eff: the index the commit counts as -- its own, or for the one commit of a group of duplicates
 // (kLeadBit) the index of the group's last member, whose write it stands for.
-__device__ __forceinline__ bool round_commit_used(const uint8_t *state, const uint4 *reqc, const Undo *undo,
+// (st, sh: the candidate's tag and cache entry, fetched by the caller -- who asks about up to three
+// candidates of a bucket fetches them all at once instead of one after the other's verdict)
+__device__ __forceinline__ bool round_commit_used_pre(uint32_t st, const uint4 &sh, const Undo *undo,
 		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
 {
-	const uint32_t st = state[c];
 	if (!tag_logged(st))
 		return false;                       // pending, done by the tail, or taken back (or selected already)
-	const uint4 sh = reqc[c];
 	*eff = (sh.w & kLeadBit) ? (sh.w >> 8) : c;
 	const uint32_t P = sh.y & g.hash_mask;
 	if (b == P)
@@ -1310,6 +1317,14 @@ __device__ __forceinline__ bool round_commit_used(const uint8_t *state, const ui
 		if ((L->word[i] >> 4) == b)
 			return true;
 	return false;
+}
+__device__ __forceinline__ bool round_commit_used(const uint8_t *state, const uint4 *reqc, const Undo *undo,
+		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
+{
+	const uint32_t st = state[c];
+	if (!tag_logged(st))
+		return false;
+	return round_commit_used_pre(st, reqc[c], undo, chain_logs, g, c, b, eff);
 }
 
 // ---- K2 / K3: rounds 1 and 2 ------------------------------------------------------
@@ -1837,6 +1852,27 @@ __device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint
 {
 	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b, eff);
 }
+// the tags and cache entries of a bucket's (up to three) candidates, asked for together: one round trip
+// instead of up to six in a row (a request of the in-order replay spends its time in exactly these)
+struct Cands {
+	uint32_t st1, st2, st3;
+	uint4 sh1, sh2, sh3;
+};
+__device__ __forceinline__ void load_cands(const Tv &tv, uint32_t c1, uint32_t c2, uint32_t c3, Cands &k)
+{
+	const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+	k.st1 = c1 != kNone ? (uint32_t)tv.state[c1] : (uint32_t)ST_PENDING;
+	k.st2 = c2 != kNone ? (uint32_t)tv.state[c2] : (uint32_t)ST_PENDING;
+	k.st3 = c3 != kNone ? (uint32_t)tv.state[c3] : (uint32_t)ST_PENDING;
+	k.sh1 = c1 != kNone ? tv.reqc[c1] : z;
+	k.sh2 = c2 != kNone ? tv.reqc[c2] : z;
+	k.sh3 = c3 != kNone ? tv.reqc[c3] : z;
+}
+__device__ __forceinline__ bool commit_used_pre(const Tv &tv, const DevGeom &g, uint32_t st, const uint4 &sh, uint32_t c,
+		uint32_t b, uint32_t *eff)
+{
+	return round_commit_used_pre(st, sh, tv.undo, tv.chain_logs, g, c, b, eff);
+}
 
 // the candidates of bucket b from its reservation words (kNone: none of this pass): its lowest registrant of
 // round 1, of round 2, and the mark pass's second-lowest (a self-help commit of round 1)
@@ -1858,11 +1894,15 @@ __device__ __forceinline__ uint32_t later_commit_from(const Tv &tv, const DevGeo
 {
 	uint32_t c1, c2, c3, e = 0;
 	candidates_of(tv, v1, v2, v3, c1, c2, c3);
-	if (c1 != kNone && commit_used(tv, g, c1, b, &e) && e > idx)
+	if (c2 == c1)
+		c2 = kNone;
+	Cands k;
+	load_cands(tv, c1, c2, c3, k);
+	if (c1 != kNone && commit_used_pre(tv, g, k.st1, k.sh1, c1, b, &e) && e > idx)
 		return c1;
-	if (c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx)
+	if (c2 != kNone && commit_used_pre(tv, g, k.st2, k.sh2, c2, b, &e) && e > idx)
 		return c2;
-	if (c3 != kNone && commit_used(tv, g, c3, b, &e) && e > idx)
+	if (c3 != kNone && commit_used_pre(tv, g, k.st3, k.sh3, c3, b, &e) && e > idx)
 		return c3;
 	return kNone;
 }
@@ -1884,11 +1924,15 @@ __device__ __forceinline__ bool conflict_on(const Tv &tv, const DevGeom &g, uint
 {
 	uint32_t c1, c2, c3, e = 0;
 	candidates_of(tv, ld_agent(&tv.owner1[b]), ld_agent(&tv.owner2[b]), ld_agent(&tv.second[b]), c1, c2, c3);
-	if (c1 != kNone && commit_used(tv, g, c1, b, &e) && e > idx && (any || tv.reqc[c1].x == sig))
+	if (c2 == c1)
+		c2 = kNone;
+	Cands k;
+	load_cands(tv, c1, c2, c3, k);
+	if (c1 != kNone && commit_used_pre(tv, g, k.st1, k.sh1, c1, b, &e) && e > idx && (any || k.sh1.x == sig))
 		return true;
-	if (c2 != kNone && c2 != c1 && commit_used(tv, g, c2, b, &e) && e > idx && (any || tv.reqc[c2].x == sig))
+	if (c2 != kNone && commit_used_pre(tv, g, k.st2, k.sh2, c2, b, &e) && e > idx && (any || k.sh2.x == sig))
 		return true;
-	return c3 != kNone && commit_used(tv, g, c3, b, &e) && e > idx && (any || tv.reqc[c3].x == sig);
+	return c3 != kNone && commit_used_pre(tv, g, k.st3, k.sh3, c3, b, &e) && e > idx && (any || k.sh3.x == sig);
 }
 
 // The check a pending request makes ONCE (kCheckedBit), before anything later than it in its region
@@ -1937,11 +1981,13 @@ __device__ __forceinline__ int apply_static_late(uint32_t *table, const DevGeom 
 	}
 	// (a request that has been through the rounds' early check, kCheckedBit, has looked already)
 	const bool unchecked = !(r.aux & kCheckedBit);
+	uint4 lo, hi;
+	load_sig_row<true>(table, P, lo, hi);       // (on its way while the bucket's candidates are looked at)
 	if (unchecked && conflict_on(tv, g, P, idx, r.sig, OP == OP_2CHOICE && A == P)) {
 		report_violation(tv, g, P, idx, P);
 		return 1;
 	}
-	if (try_place<true, false>(table, P, r.sig, r.loc, r.sig, nullptr))
+	if (try_place_rows<true, false>(table, P, lo, hi, r.sig, r.loc, r.sig, nullptr))
 		return 0;
 	if (unchecked && A != P && conflict_on(tv, g, A, idx, r.sig, OP == OP_2CHOICE || (r.aux & kLazyBit) != 0u)) {
 		report_violation(tv, g, P, idx, A);
@@ -3563,6 +3609,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	uint32_t *const phase_ticks = nullptr, *const grid_ticks = nullptr;
 #define MKV_PHASE(k) ((void)0)
 #endif
+	static_assert(kTailThreads == 2 * (int)kTlGroups, "a lane of the tail's first work-group per round and work-group of the rounds");
+	const uint32_t my_round = t < kTlGroups ? 0u : 1u, my_wg = t & (kTlGroups - 1u);
 	const uint32_t total_all = ctl->total;
 	if (round2_hint >= 0 && OP != OP_DELETE && ctl->any_loser != 0u) {
 		// (every work-group reads the same flag: round 1, the kernel before, set it)
@@ -3576,7 +3624,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// every work-group reads the one flag (final: only kernels before this one in the stream -- or the
 	// phase above, behind its meeting -- set it) and work-group 0 leaves the control block ready for the
 	// next pass.
-	if (ld_agent32(&ctl->any_tail) == 0u) {
+	const uint32_t p_any_tail = ld_agent32(&ctl->any_tail);
+	if (p_any_tail == 0u) {
 		if (wg == 0)
 			tail_epilogue<true>(ctl, nullptr, 0u, total_all, 0u, 0u, 0u, 0u, first_chunk, last_chunk, host_flag);
 		return;
@@ -3586,18 +3635,16 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// what the grid-wide rounds left, listed by themselves (tail_list_add) -- unless a work-group left
 	// more than its place holds, shadows without a leader are about (not listed), or the call runs in
 	// several passes.  Every work-group of this launch reads the counts and decides alike.
-	static_assert(kTailThreads == 2 * (int)kTlGroups, "a lane of the tail's first work-group per round and work-group of the rounds");
 	__shared__ uint32_t s_tl_total, s_tl_over;
 	if (t == 0) {
 		s_tl_total = 0u;
 		s_tl_over = 0u;
 	}
 	__syncthreads();
-	const bool list_ok = first_chunk && last_chunk && carry_in >= lo_idx && ctl->loose == 0u && ctl->any_tail != 0u;
+	const bool list_ok = first_chunk && last_chunk && carry_in >= lo_idx && ctl->loose == 0u && p_any_tail != 0u;
 	const uint32_t tl_g1 = list_ok ? ctl->tl_groups[0] : 0u;
 	const uint32_t tl_g2 = list_ok && ctl->any_loser != 0u ? ctl->tl_groups[1] : 0u;    // (round 2 leaves at once without losers)
 	uint32_t my_cnt = 0, my_base = 0;
-	const uint32_t my_round = t < kTlGroups ? 0u : 1u, my_wg = t & (kTlGroups - 1u);
 	if (list_ok) {
 		if (tl_g1 > kTlGroups || tl_g2 > kTlGroups) {
 			s_tl_over = 1u;
@@ -3614,7 +3661,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	const uint32_t tln = s_tl_total;
 	if (carry_in < lo_idx)
 		lo_idx = carry_in;                        // this pass also covered the carried requests
-	const bool work_left = ctl->any_tail != 0u;   // round 2 has retagged every LOSER
+	const bool work_left = p_any_tail != 0u;      // round 2 has retagged every LOSER
 	const unsigned long long stamp1 = ctl->stamp_base;    // round-1 stamp of this pass
 	if (t == 0) {
 		s_n = 0;
@@ -3645,12 +3692,18 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		return;
 	const uint32_t nwg_eff = use_helpers ? nwg : 1u;     // work-groups taking part from here on
 	bool grid_mode = false;
+	bool lds_ready = false;                   // the first work list is in lkeys already
 	if (work_left && listed) {
 		MKV_PHASE(0);
-		for (uint32_t k = 0; k < my_cnt; k++)
-			glist[my_base + k] = ctl->tl[my_round][my_wg][k];
+		// (the list goes into LDS as well: the work list of a short list is read from there at once)
+		for (uint32_t k = 0; k < my_cnt; k++) {
+			const uint32_t e = ctl->tl[my_round][my_wg][k];
+			glist[my_base + k] = e;
+			lkeys[my_base + k] = e;
+		}
 		if (t == 0)
 			s_n = tln;
+		lds_ready = true;
 		MKV_PHASE(6);
 		wg_sync();
 	} else if (work_left) {
@@ -3732,16 +3785,19 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			while (n2 < m)
 				n2 <<= 1;
 			if (in_lds) {
-				for (uint32_t i = t; i < m; i += blockDim.x)
-					lkeys[i] = glist[i];
+				if (!lds_ready)
+					for (uint32_t i = t; i < m; i += blockDim.x)
+						lkeys[i] = glist[i];
 				for (uint32_t i = m + t; i < n2; i += blockDim.x)
 					lkeys[i] = kNone;
 			}
+			lds_ready = false;
 			wg_sync();
 			// a handful of requests: the in-order replay is done before a round would be
-			left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
-					&s_par, &s_left, &s_dupw, m <= (uint32_t)kTailReplayMax ? 0 : max_rounds, &used, tv, rounds_total,
-					reinterpret_cast<uint32_t *>(lreg));
+			left = m;
+			if (m > (uint32_t)kTailReplayMax && max_rounds > 0)
+				left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
+						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total, reinterpret_cast<uint32_t *>(lreg));
 		}
 		rounds_total += used;
 		MKV_PHASE(4);

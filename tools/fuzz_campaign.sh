@@ -16,3 +16,6 @@ run MKV_FUZZ_DEBUG_SKIP=2 MKV_FUZZ_TAIL_GROUPS=5 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZ
 # rounds 1 and 2 on few work-groups (their queues of held-back requests run over), every chain left to the tail
 run MKV_FUZZ_ROUND_BLOCKS=2 MKV_FUZZ_DEBUG_SKIP=4 MKV_FUZZ_TAIL_GROUPS=32
 run MKV_FUZZ_ROUND_BLOCKS=1 MKV_FUZZ_DEBUG_SKIP=0
+# round 4: round 2 always inside the tail launch / never; no self-help of second registrants
+run MKV_FUZZ_MERGE_ROUND2=2 MKV_FUZZ_SELF_HELP=1 MKV_FUZZ_TAIL_GROUPS=32
+run MKV_FUZZ_MERGE_ROUND2=0 MKV_FUZZ_SELF_HELP=0 MKV_FUZZ_TAIL_GROUPS=5
