@@ -185,6 +185,9 @@ def main():
     args = parse()
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    # (before anything initialises HIP: the host driver of this pool only supports dmabuf IPC -- RCCL's
+    # peer mappings fail with "hipIpcGetMemHandle: invalid argument" without it)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     late_imports()
     sys.stdout.flush()
     json_fd = os.dup(1)

@@ -367,3 +367,60 @@ def test_cycle_workers_one_call_for_all_workers_of_a_cycle(scheme, nworkers):
                 O.delete(og, exp, np.ascontiguousarray(host_w[w][1]))
         O.insert(og, exp, [b for w in range(nworkers) for b in host_w[w][2]])
         assert np.array_equal(idx.table_numpy(), exp), (cycle, "table")
+
+
+def test_update_under_capture_behind_another_streams_update_is_refused():
+    """Updates issued on different streams are put in issue order with a library-owned event or a
+    device synchronisation.  Neither may go into a hipGraph: an update on a stream that is being
+    captured, with the device's last update on ANOTHER stream, is refused (nothing enqueued, the
+    capture stays valid); once the stream has had an update of its own before the capture, the same
+    call is captured, and replaying the graph inserts."""
+    import numpy as np
+    import torch
+    from megakv_amd import Geometry, HashIndex
+    from megakv_amd.index import MkvError
+    from oracle import oracle as O
+    from tests.gpu_util import dev, ogeom, random_requests
+    g = Geometry(mem_p=16)
+    og = ogeom(g)
+    rng = np.random.default_rng(5)
+    idx = HashIndex(g)
+    exp = O.new_table(og)
+    s1, s2 = torch.cuda.Stream(), torch.cuda.Stream()
+    idx.reserve(8192, s1)
+    idx.reserve(8192, s2)
+    e1, e2 = random_requests(g, rng, 3000, 1 << 31), random_requests(g, rng, 3000, 1 << 31)
+    p1, c1, k1 = idx.stage_blocks([dev(e1)])
+    p2, c2, k2 = idx.stage_blocks([dev(e2)])
+    torch.cuda.synchronize()
+    idx.insert_staged(p1, c1, 1, s1, 3000)               # the device's last update: stream 1
+    O.insert(og, exp, [e1])
+    s1.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s2):
+        graph.capture_begin()
+        try:
+            with pytest.raises(MkvError):
+                idx.insert_staged(p2, c2, 1, s2, 3000)   # would need ordering behind stream 1: refused
+        finally:
+            graph.capture_end()
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.table_numpy(), exp)        # nothing of it ran
+    # one update of its own on stream 2 (ordered behind stream 1's by the library), then the capture
+    e3 = random_requests(g, rng, 10, 1 << 31)
+    p3, c3, k3 = idx.stage_blocks([dev(e3)])
+    torch.cuda.synchronize()
+    idx.insert_staged(p3, c3, 1, s2, 10)
+    O.insert(og, exp, [e3])
+    s2.synchronize()
+    graph2 = torch.cuda.CUDAGraph()
+    with torch.cuda.stream(s2):
+        graph2.capture_begin()
+        idx.insert_staged(p2, c2, 1, s2, 3000)
+        graph2.capture_end()
+    torch.cuda.synchronize()
+    assert np.array_equal(idx.table_numpy(), exp)        # captured, not run
+    graph2.replay()
+    torch.cuda.synchronize()
+    O.insert(og, exp, [e2])
+    assert np.array_equal(idx.table_numpy(), exp)

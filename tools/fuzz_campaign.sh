@@ -3,7 +3,7 @@
 # usage: fuzz_campaign.sh [cases]
 n=${1:-2000}
 export MKV_FUZZ_CASES=$n
-run() { echo -n "$*: "; env "$@" timeout 1200 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | grep -E "passed|failed" | tail -1; }
+run() { echo -n "$*: "; env "$@" timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | grep -E "passed|failed" | tail -1; }
 run MKV_X=0
 run MKV_FUZZ_TAIL_GROUPS=1 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=1000000000
 run MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_GRID_MIN=0
@@ -13,6 +13,7 @@ run MKV_FUZZ_TAIL_GROUPS=2 MKV_FUZZ_TAIL_ROUNDS=0 MKV_FUZZ_INSERT_CHUNK=65536
 # how order violations of late chains are taken back: always the general way / the region suffix
 run MKV_FUZZ_DEBUG_SKIP=1 MKV_FUZZ_TAIL_GROUPS=32 MKV_FUZZ_TAIL_ROUNDS=48
 run MKV_FUZZ_DEBUG_SKIP=2 MKV_FUZZ_TAIL_GROUPS=5 MKV_FUZZ_TAIL_ROUNDS=48 MKV_FUZZ_INSERT_CHUNK=8192
+run MKV_FUZZ_DEBUG_SKIP=2 MKV_FUZZ_TAIL_GROUPS=2 MKV_FUZZ_GRID_MIN=0 MKV_FUZZ_CALM_FACTOR=1 MKV_FUZZ_ROUND_BLOCKS=1
 # rounds 1 and 2 on few work-groups (their queues of held-back requests run over), every chain left to the tail
 run MKV_FUZZ_ROUND_BLOCKS=2 MKV_FUZZ_DEBUG_SKIP=4 MKV_FUZZ_TAIL_GROUPS=32
 run MKV_FUZZ_ROUND_BLOCKS=1 MKV_FUZZ_DEBUG_SKIP=0
