@@ -975,6 +975,13 @@ extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const 
 	if (blocks)
 		hipLaunchKernelGGL(mkv::k_search_multi, dim3(blocks), dim3(256), 0, s, ms, reinterpret_cast<const uint4 *>(table),
 				d.hash_mask, d.blk_mask);
+	if (nblk || ndel) {
+		// (the gathered lists are one set per device: a call on another stream must not rewrite them
+		// under this device's last update -- the order the updates below would take anyway, taken now)
+		const int orc = mkv::order_updates(s);
+		if (orc != MKV_OK)
+			return orc;
+	}
 	if (nblk || ndel)
 		hipLaunchKernelGGL(mkv::k_gather_blocks, dim3(1), dim3(1024), 0, s, gb, wa.ins_ptrs, wa.ins_cnts, wa.del_ptrs,
 				wa.del_cnts);

@@ -369,6 +369,60 @@ def test_cycle_workers_one_call_for_all_workers_of_a_cycle(scheme, nworkers):
         assert np.array_equal(idx.table_numpy(), exp), (cycle, "table")
 
 
+def test_cycle_workers_calls_on_alternating_streams_keep_issue_order():
+    """Calls of mkv_cycle_workers on two streams, back to back with no host synchronisation between
+    them: the gathered block lists are one set per device, so a call may only rewrite them behind the
+    device's last update -- the library orders the calls like any other updates.  Final table against
+    the oracle run in issue order."""
+    import ctypes
+    from megakv_amd.lib import MkvWorker
+    from megakv_amd.index import _dev_ptr, _stream_ptr
+    g = M.Geometry(mem_p=18)
+    og = O.geom(mem_p=18)
+    idx = M.HashIndex(g)
+    exp = O.new_table(og)
+    rng = np.random.default_rng(77)
+    pool = rng.integers(1, 2**32, size=(30000, 3), dtype=np.uint64).astype(np.uint32)
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    nworkers, calls, keep = 4, [], []
+    for c in range(8):
+        ws = (MkvWorker * nworkers)()
+        host = []
+        for w in range(nworkers):
+            nd = int(rng.integers(0, 400)) if c else 0
+            dl = pool[rng.integers(0, len(pool), size=nd)].copy()
+            blocks = []
+            for b in range(4):
+                e = pool[rng.integers(0, len(pool), size=int(rng.integers(1, 900)))].copy()
+                e[:, 2] = rng.integers(1, 2**32, size=len(e), dtype=np.uint64)
+                blocks.append(np.ascontiguousarray(e))
+            td = dev(dl) if nd else None
+            tb = [dev(b.reshape(-1, 3)) for b in blocks]
+            ptrs, cnts, kp = idx.stage_blocks(tb)
+            keep.append((td, tb, ptrs, cnts, kp))
+            host.append((dl, blocks))
+            ws[w].search_in = None
+            ws[w].search_out = None
+            ws[w].num_search = 0
+            ws[w].delete_in = _dev_ptr(td).value if nd else None
+            ws[w].num_delete = nd
+            ws[w].blk_input = _dev_ptr(ptrs).value
+            ws[w].blk_elem_num = _dev_ptr(cnts).value
+            ws[w].num_blks = 4
+        calls.append((ws, host))
+    torch.cuda.synchronize()
+    for c, (ws, host) in enumerate(calls):                   # issued back to back, streams alternating
+        rc = idx.lib.mkv_cycle_workers(ctypes.byref(idx._g), _dev_ptr(idx.table), ws, nworkers, _stream_ptr(streams[c & 1]))
+        assert rc == 0
+    torch.cuda.synchronize()
+    for ws, host in calls:
+        for dl, _ in host:
+            if len(dl):
+                O.delete(og, exp, np.ascontiguousarray(dl))
+        O.insert(og, exp, [b for _, blocks in host for b in blocks])
+    assert np.array_equal(idx.table_numpy(), exp)
+
+
 def test_update_under_capture_behind_another_streams_update_is_refused():
     """Updates issued on different streams are put in issue order with a library-owned event or a
     device synchronisation.  Neither may go into a hipGraph: an update on a stream that is being
