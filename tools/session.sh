@@ -1,5 +1,11 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s47; mkdir -p $d
-timeout 900 python -m pytest tests/test_gpu_abi.py tests/test_gpu_sharded.py -m gpu -x -q 2>&1 | grep -E "passed|failed|rror|assert" | tail -5 | tee $d/pytest.txt
-for i in 1 2 3; do timeout 300 python -m pytest "tests/test_gpu_abi.py::test_cycle_workers_calls_on_alternating_streams_keep_issue_order" -m gpu -x -q 2>&1 | grep -E "passed|failed" | tail -1; done
-timeout 300 python tools/workers_rate.py 2>&1 | tail -6
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s49; mkdir -p $d
+line() { python bench.py --no-cpu --no-pcie --no-abi "$@" 2>&1 | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('$*', j['value'], round(j['ms_per_step']*1000,1), j.get('repeats',{}).get('mops'))"; }
+for m in 1 2 1 2; do
+ echo "== MKV_MERGE_ROUND2=$m"
+ export MKV_MERGE_ROUND2=$m
+ line --steps 20 --warmup 5 --lf 0.5
+ line --steps 20 --warmup 5 --lf 0.35
+ line --steps 40 --warmup 5 --lf 0.85
+done 2>&1 | tee $d/merge.txt
