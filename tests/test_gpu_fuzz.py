@@ -35,7 +35,10 @@ def _defaults():
         L.mkv_set_tuning(b"merge_round2", 1)
 
 
-@pytest.mark.parametrize("seed", range(int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
+_FIRST = int(__import__("os").environ.get("MKV_FUZZ_FIRST", "0"))       # (campaigns: a later range of seeds)
+
+
+@pytest.mark.parametrize("seed", range(_FIRST, _FIRST + int(__import__("os").environ.get("MKV_FUZZ_CASES", "48"))))
 def test_fuzz_sequence(seed):
     _run(seed, {})
 

@@ -1,11 +1,10 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s50; mkdir -p $d
-( time python -m pytest tests -x -q -m gpu 2>&1 | grep -E "passed|failed|rror" | tail -3 ) 2>&1 | tail -6 | tee $d/pytest.txt
-python -c "import __graft_entry__ as g; g.smoke(); print('smoke ok')" 2>&1 | tail -1
-( time python bench.py --steps 20 --warmup 5 > $d/driver.json 2> $d/driver.err ) 2>&1 | grep real
-python -c "
-import json; j=json.load(open('$d/driver.json')); print(j['value'], j['ms_per_step'], j['repeats'], j['roofline']['frac'], j['roofline']['traffic_source'], j['cpu_baseline']['value'], j['abi_three_call']['value'], j['engine'])"
-( time python bench.py > $d/default.json 2> $d/default.err ) 2>&1 | grep real
-python -c "
-import json; j=json.load(open('$d/default.json')); print(j['value'], j['ms_per_step'], j['repeats'], j['roofline']['frac'])"
-ldd megakv_amd/_lib/libmegakv_hip.so | head -5
+# the GPU session of the moment (rewritten per gpurun call): a long soak of the seeded fuzz test on the product library
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s52; mkdir -p $d
+{
+echo "soak on the round-4 final kernels ($(cat .head)): the default configuration, seeds 0 .. 119 999 in four processes of 30 000 (MKV_FUZZ_FIRST), + big tables 2 000"
+for first in 0 30000 60000 90000; do
+  echo -n "seeds $first .. $((first+29999)): "; MKV_FUZZ_FIRST=$first MKV_FUZZ_CASES=30000 MKV_FUZZ_CYCLE_CASES=2 MKV_FUZZ_NODEL_CASES=2 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -x -k "test_fuzz_sequence" 2>&1 | grep -E "passed|failed" | tail -1
+done
+echo -n "big tables, seeds 0 .. 1999: "; MKV_FUZZ_BIG=1 MKV_FUZZ_CASES=2000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -x -k "test_fuzz_sequence" 2>&1 | grep -E "passed|failed" | tail -1
+} 2>&1 | tee $d/soak.txt
