@@ -1,10 +1,13 @@
 #!/bin/bash
-# the GPU session of the moment (rewritten per gpurun call): a long soak of the seeded fuzz test on the product library
-cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s52; mkdir -p $d
-{
-echo "soak on the round-4 final kernels ($(cat .head)): the default configuration, seeds 0 .. 119 999 in four processes of 30 000 (MKV_FUZZ_FIRST), + big tables 2 000"
-for first in 0 30000 60000 90000; do
-  echo -n "seeds $first .. $((first+29999)): "; MKV_FUZZ_FIRST=$first MKV_FUZZ_CASES=30000 MKV_FUZZ_CYCLE_CASES=2 MKV_FUZZ_NODEL_CASES=2 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -x -k "test_fuzz_sequence" 2>&1 | grep -E "passed|failed" | tail -1
-done
-echo -n "big tables, seeds 0 .. 1999: "; MKV_FUZZ_BIG=1 MKV_FUZZ_CASES=2000 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -x -k "test_fuzz_sequence" 2>&1 | grep -E "passed|failed" | tail -1
-} 2>&1 | tee $d/soak.txt
+cd "$GRAFT_REPO_ROOT"; d=gpurun_out/s53; mkdir -p $d
+line() { python bench.py --no-cpu --no-pcie --no-abi "$@" 2>&1 | tail -1 | python -c "
+import sys,json; j=json.loads(sys.stdin.read()); print('$*', j['value'], round(j['ms_per_step']*1000,1), j.get('repeats',{}).get('mops'))"; }
+for tr in 48 0 1 48 0 1; do
+ echo "== MKV_TAIL_ROUNDS=$tr"
+ export MKV_TAIL_ROUNDS=$tr
+ line --workload zipf50 --lf 0.5 --steps 10 --warmup 3
+ line --workload zipf50 --steps 100 --warmup 5
+ line --steps 40 --warmup 5 --lf 0.85
+ line --steps 20 --warmup 5 --lf 0.5
+ line --workload zipf50 --sets upd --steps 20 --warmup 5
+done 2>&1 | tee $d/tail_rounds.txt
