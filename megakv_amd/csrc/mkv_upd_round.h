@@ -157,8 +157,17 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	uint4 *reqw = const_cast<uint4 *>(reqc);    // (the flag word of a request's cache entry is written here)
 	// whole waves go round together (the re-registration folds the atomics of lanes on one
 	// bucket): the loop variable is the work-group's first index
+#ifdef MKV_DIAGNOSTICS
+	const unsigned long long dg_t0 = wall_clock64();
+	unsigned long long dg_p2acc = 0;
+	uint32_t dg_qmax = 0;
+#endif
 	uint32_t base = start + block * blockDim.x;
+	uint32_t pf_a = 0u, pf_b = 0u;
+	// (Fetching a turn's requests and tags a turn ahead was built and measured: no difference -- the turns of a
+	// long pass are bound by the memory system's rate of random accesses, not by their round trips.)
 	for (bool more = base < count && base >= start; ; ) {
+		asm volatile("" ::"v"(pf_a), "v"(pf_b));       // (last turn's touches have long arrived)
 		if (more) {
 			const uint32_t idx = base + threadIdx.x;
 			const bool in_range = idx < count;
@@ -214,6 +223,14 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 						const uint32_t at = atomicAdd(&s_qn, 1u);
 						s_q[at] = make_uint4(r.sig, r.hash, ra.loc, idx | ((rc.w & kLazyBit) << 31));
 						s_qg[at] = grp;
+						// what phase 2 will ask about the alternate bucket first -- its reservation word, its
+						// signature row -- is asked for NOW and looked at a turn later (pf_a / pf_b are only
+						// there to keep the loads alive): beside the other work-groups' traffic a dependent
+						// access costs 2 - 3 us, and phase 2 is a chain of them at the very end of the
+						// work-group (a quarter of round 1's time for a handful of queued requests: diagnostics
+						// build, phases 8 / 11 of mkv_debug_tail_phases).  Worth 0.5 - 0.7 % of a 95/5 step.
+						pf_a = (uint32_t)owner[A];
+						pf_b = table[sig_word(A, 0u)];
 					}
 				} else {
 					lose = true;
@@ -351,6 +368,9 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		const uint32_t qn = s_qn;
 		if (more && qn + blockDim.x <= (uint32_t)QCAP)
 			continue;                                   // room for another turn's worth
+#ifdef MKV_DIAGNOSTICS
+		const unsigned long long dg_p2 = wall_clock64();
+#endif
 		// phase 2: the queued requests, one per lane
 		for (uint32_t q0 = 0; q0 < qn; q0 += blockDim.x) {
 			const uint32_t q = q0 + threadIdx.x;
@@ -449,6 +469,10 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			}
 			tail_list_add(s_tl, &s_tln, idx, to_tail);
 		}
+#ifdef MKV_DIAGNOSTICS
+		dg_p2acc += wall_clock64() - dg_p2;
+		dg_qmax = qn > dg_qmax ? qn : dg_qmax;
+#endif
 		if (!more)
 			break;
 		__syncthreads();
@@ -456,6 +480,15 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			s_qn = 0u;
 		__syncthreads();
 	}
+#ifdef MKV_DIAGNOSTICS
+	// (round 1: the slowest work-group's time in all, its share in phase 2, the longest queue -- in ticks of
+	// 10 ns / requests; they come out as phases 8, 11, 15 of mkv_debug_tail_phases)
+	if (ROUND == 1 && threadIdx.x == 0) {
+		atomicMax(&ctl->dbg[0], (uint32_t)(wall_clock64() - dg_t0));
+		atomicMax(&ctl->dbg[3], (uint32_t)dg_p2acc);
+		atomicMax(&ctl->dbg[7], dg_qmax);
+	}
+#endif
 	count_add(&ctl->committed[ROUND - 1][0].n, ndone);
 	if (ROUND == 1 && help_on) {
 		count_add(&ctl->committed[0][0].n, ndone_help);

@@ -4,7 +4,8 @@ build (per-phase clocks in k_tail), update info and phase times per step.
 usage: tail_phases.py [zipf95|zipf50] [new|upd] [steps, default 8] [lf, default 0.2] [tuning=value ...]
 phases (us): 0 roll-back, 1 gather, 2 exact replay below a barrier, 3 retag, 4 in-group rounds, 5 serial replay,
 6-7 gather details; 8.. inside the grid-wide rounds: register, meeting, decide, meeting, election + meeting,
-commit, meeting."""
+commit, meeting -- or, when no grid-wide round ran, the diagnostics words: 8 = round 1's slowest work-group (ticks
+of 10 ns), 11 = its phase 2 (the queued requests), 15 = the longest queue; 9 / 10 / 12 - 14 = in-group rounds' counters."""
 import argparse
 import os
 import sys
