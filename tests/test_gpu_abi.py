@@ -423,6 +423,7 @@ def test_cycle_workers_calls_on_alternating_streams_keep_issue_order():
     assert np.array_equal(idx.table_numpy(), exp)
 
 
+@pytest.mark.filterwarnings("ignore:The CUDA Graph is empty")      # (the refused call leaves the first capture empty: the point)
 def test_update_under_capture_behind_another_streams_update_is_refused():
     """Updates issued on different streams are put in issue order with a library-owned event or a
     device synchronisation.  Neither may go into a hipGraph: an update on a stream that is being
