@@ -75,6 +75,12 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		ctl->committed[2][t].n = 0;
 		ctl->committed[3][t].n = 0;
 	}
+	// (round 1's places in the rounds' lists for the tail: its work-groups share them, adding to the counts,
+	// when the round runs on more than kTlGroups of them -- tuning "round_blocks"; round 2's are cleared by
+	// round 1.  Same rule: by a kernel before the one that counts.)
+	if (block == 0)
+		for (uint32_t q = t; q < kTlGroups; q += blockDim.x)
+			ctl->tl_cnt[0][q] = 0u;
 	const uint32_t end = hi_idx < total ? hi_idx : total;
 	// requests an earlier chunk pass of this call left unresolved ride along: they have
 	// lower indices, so they win every reservation they share with this chunk's requests

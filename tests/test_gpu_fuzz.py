@@ -93,6 +93,33 @@ def test_order_violations_of_late_chains(path, chunk):
     assert late > 0 and violations > 0, (late, violations)     # the paths in question were taken
 
 
+@pytest.mark.parametrize("blocks", [1024, 4096])
+def test_rounds_on_more_work_groups_than_list_places(blocks):
+    """Rounds 1 and 2 list what they leave to the tail per work-group, 512 places; on more work-groups
+    (tuning round_blocks) several share a place and ADD to its count -- which a kernel before them
+    must have cleared.  Several passes in a row on a well-filled table (every pass leaves the tail
+    requests), whole table against the oracle after each."""
+    L = load_library()
+    L.mkv_set_tuning(b"round_blocks", blocks)
+    g = Geometry(mem_p=20)
+    og = ogeom(g)
+    rng = np.random.default_rng(4242 + blocks)
+    exp = random_table(g, rng, 0.7, 1 << 31)
+    idx = HashIndex(g)
+    idx.load_table(exp)
+    listed = 0
+    for step in range(5):
+        e = random_requests(g, rng, 60000, 1 << 31, hot=0.05 * step)
+        blocks_ = split_blocks(e, g, rng, "region")
+        O.insert(og, exp, blocks_)
+        idx.insert([dev(b) for b in blocks_])
+        info = idx.last_update_info()
+        listed += info["tail_parallel"] + info["tail_serial"]
+        got = idx.table_numpy()
+        assert np.array_equal(got, exp), (blocks, step, first_diff(got, exp), info)
+    assert listed > 0                                    # the tail did have work
+
+
 def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
     env = __import__("os").environ
@@ -121,6 +148,8 @@ def _run(seed, forced):
         assert L.mkv_set_tuning(b"debug_skip", skip) == 0
     # work-groups of rounds 1 and 2: few make a work-group's queue of held-back requests run over
     L.mkv_set_tuning(b"round_blocks", int(rng3.choice([1, 3, 64, 512, 512])))
+    if seed % 7 == 3:
+        L.mkv_set_tuning(b"round_blocks", 2048)      # (more work-groups than places in the rounds' lists for the tail)
     # round 1's self-help of a bucket's second registrant, round 2 inside the tail launch: on (the default) or off
     rng4 = np.random.default_rng(17000 + seed)
     L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
