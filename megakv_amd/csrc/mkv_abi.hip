@@ -187,7 +187,7 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 	}
 	if (overlap || fused)
 		rc = mkv_cycle_insert_end(geom, table, blk_input, blk_elem_num, num_blks, insert_hint, stream,
-				overlap ? 1 : 0);
+				(overlap ? 1 : 0) | (num_delete > 0 ? 2 : 0));
 	else if (num_blks > 0)
 		rc = mkv_insert_hinted(geom, table, blk_input, blk_elem_num, num_blks, insert_hint, stream);
 	return rc;

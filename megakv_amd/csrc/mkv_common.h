@@ -105,6 +105,8 @@ struct Tuning {
 	                        // not register on its alternate bucket (0: every request registers on both)
 	int self_help;          // round 1: a bucket's second-lowest registrant commits beside the lowest one when it can tell
 	                        // what that one will do there (self-help, mkv_update.hip); 0: it waits for round 2
+	int plans;              // the mark pass plans what a request does in its primary bucket and flags who is not a bucket's lowest
+	                        // registrant; round 1 carries the plans out without reading bucket or reservation (kPlanBit); 0: as before
 	int merge_round2;       // round 2 runs as the first phase of the tail launch (0: a launch of its own, as before)
 	long long merge_max;    // ... for passes announced with at most this many requests
 	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)

@@ -487,7 +487,10 @@ __global__ __launch_bounds__(THREADS) void k_pack_tiles(const uint32_t *__restri
 				c += s_wcnt[wv][t];
 			__hip_atomic_store(&tile_counts[(size_t)tile * kPackBins + t], c, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 		}
-		__syncthreads();                       // (waits for those stores)
+		// (the stores have LEFT before the barrier: a work-group barrier alone does not wait for them -- its
+		// release is of work-group scope -- and lane 0 signals for all of them)
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+		__syncthreads();
 		if (t == 0) {
 			atomicAdd(arrive, 1u);
 			while (pack_ld(arrive) < set_tiles)

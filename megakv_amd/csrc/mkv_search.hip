@@ -129,7 +129,7 @@ Tuning &tuning()
 		v.grid_progress = 96;
 		v.mark_alone_blocks = 1024;
 		s = getenv("MKV_MARK_BLOCKS");
-		v.mark_blocks = s ? atoi(s) : 128;
+		v.mark_blocks = s ? atoi(s) : 208;
 		if (v.mark_blocks < 1) v.mark_blocks = 1;
 		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
 		v.pack_three_pass = 0;                 // (diagnostics builds: mkv_set_tuning forces the fall-back)
@@ -161,6 +161,8 @@ Tuning &tuning()
 		if (v.lazy_alt < 0 || v.lazy_alt > 8) v.lazy_alt = 2;
 		s = getenv("MKV_SELF_HELP");
 		v.self_help = s ? atoi(s) != 0 : 1;
+		s = getenv("MKV_PLANS");
+		v.plans = s ? atoi(s) != 0 : 1;
 		s = getenv("MKV_MERGE_ROUND2");
 		v.merge_round2 = s ? atoi(s) : 1;      // (2: even when round 1 has been leaving round 2 a lot)
 		s = getenv("MKV_MERGE_MAX");
@@ -291,9 +293,15 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		t.lazy_alt = (int)value;
 	} else if (!strcmp(name, "self_help")) {
 		t.self_help = value != 0;
+	} else if (!strcmp(name, "plans")) {
+		t.plans = value != 0;
 	} else if (!strcmp(name, "merge_round2")) {
+		if (value < 0 || value > 2)
+			return MKV_EINVAL;
 		t.merge_round2 = (int)value;
 	} else if (!strcmp(name, "merge_max")) {
+		if (value < 0)
+			return MKV_EINVAL;
 		t.merge_max = value;
 #ifdef MKV_DIAGNOSTICS
 	} else if (!strcmp(name, "debug_skip")) {

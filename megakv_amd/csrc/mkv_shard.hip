@@ -388,6 +388,10 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		if (n >= 1 && n <= 3)
 			e->nsvc = n;
 	}
+	// (the epilogue of a run records an event of lane k behind service stream k: never more service streams
+	// than buffer sets -- MKV_SHARD_LANES=2 with several ranks)
+	if (e->nsvc > e->nlanes)
+		e->nsvc = e->nlanes;
 	if (const char *v = getenv("MKV_SHARD_DELAY_UNPACK_US"))
 		e->delay_unpack_us = atoi(v);
 	e->slot_words = mkv_pack_slot_words(cap_get, cap_set);

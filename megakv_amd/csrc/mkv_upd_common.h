@@ -18,6 +18,8 @@ constexpr int kGridRoundsMax = 4096;   // grid-wide rounds of a final tail with 
 constexpr int kStampsPerCall = 2 + kMaxTailRounds + 2;   // first pass after initialisation; later passes take what they use
 constexpr uint32_t kTlGroups = 512;  // the grid-wide rounds list what they leave to the tail: per work-group of a round
 constexpr uint32_t kTlPer = 8;       // ... this many entries (a work-group with more, or more work-groups: the tail scans the tags)
+constexpr uint32_t kLlPer = 4;       // (static_assert below: the record is 32 bytes)       // round 1 lists what it leaves to ROUND 2 too: per work-group this many
+constexpr uint32_t kFewLosers = 8;   // ... and the tail launch's first work-group alone runs round 2 over a list this short
 constexpr int kTailReplayMax = 24;  // the tail replays this many unfinished requests in order without trying rounds
 constexpr int kTailAloneSpan = 131072; // ... or beyond this many request tags to scan
 constexpr int kTailAloneMax = 1024; // the tail keeps its helper work-groups only beyond this many unfinished requests
@@ -72,6 +74,22 @@ constexpr int kShards = 64;         // statistics counters are spread over this 
 constexpr uint32_t kFollowBit = 2u, kLeadBit = 4u;
 constexpr uint32_t kCheckedBit = 8u;   // tail: the request has looked at the grid-wide rounds' commits on its alternate bucket
 constexpr uint32_t kLazyBit = 1u;      // (the number of free slots asked for: Tuning::lazy_alt, 2 by default: 1 / 2 / 3 measured alike)
+// The mark pass loads a new request's primary bucket anyway (for the decision above).  It also works out what the
+// request would do there as the table stands -- overwrite its duplicate's location, or take the preferred empty
+// slot -- and leaves that PLAN where the commit's undo record goes (it IS that record: the words to write and what
+// they hold).  Round 1 carries the plan out without reading the bucket again when the request is the bucket's lowest
+// registrant -- nobody else may write there before it, and a second registrant that helps itself writes other words
+// -- and the table has not changed since the mark pass (no delete of the same cycle in between: the host says so).
+// And it knows that without reading the reservation either: every registration of the mark pass is a returning
+// atomicMin, and whoever sees two keys of the pass on one word -- its own and the one it displaced or lost to --
+// FLAGS the larger one's request (`lost`: a word per request holding the low half of the pass's stamp; never
+// cleared).  A request is displaced from a word by exactly one atomic, which then sees its key; a request that never
+// got onto the word saw a smaller key itself: so a request nobody flagged is the lowest registrant of every bucket it
+// registered on.  (Folded registrations flag on the way: the lanes of a wave that share a bucket, the entries of a
+// work-group's table.)  Chains that walk ahead (prewalk_register) register without a returning atomic; a pass in
+// which one did says so (Ctl::hint_stamp) and round 1 reads every reservation as before.
+// Round 1 of a 52 K-request pass: three dependent round trips (request; reservation + bucket; stores) -> two.
+constexpr uint32_t kPlanBit = 16u;
 
 // Reservation entries are 64 bits: a 40-bit round stamp over a 24-bit payload
 // (request index in the owner tables, registrant count in the count table).
@@ -99,19 +117,35 @@ struct ChainLog {
 };
 
 struct Ctl {
-	unsigned long long next_stamp;   // persists across calls
-	unsigned long long stamp_base;   // stamp of round 1 of the current call
+	// -- head: what the kernels of a pass read when they start (one 64-byte line)
+	// Round stamps.  A pass takes three (round 1, round 2, one spare) plus what its tail's rounds use.  Its MARK
+	// pass works out its round-1 stamp -- stamp_base, plus three if the pass before ended without its epilogue
+	// (ep_pending: a tail launch that finds nothing to do leaves at once, k_tail) -- and publishes it in stamp_cur,
+	// which nobody reads in that kernel; ROUND 1 reads stamp_cur, and its first work-group moves it to stamp_base
+	// and sets ep_pending (nobody reads those in that kernel); round 2 and the tail read stamp_base; the tail's
+	// epilogue, when it runs, moves stamp_base past the pass and clears ep_pending.  No kernel reads a word that
+	// another work-group of the same kernel writes.
+	unsigned long long stamp_base;
+	unsigned long long stamp_cur;
+	uint32_t ep_pending;
 	uint32_t total;
 	uint32_t overflow;
-	uint32_t any_loser;              // plain flags, set by whoever produces such work
-	uint32_t any_tail;
+	uint32_t carry_lo;               // lowest request index carried over from earlier chunk passes (kNone: none)
+	// plain flags, set by whoever produces such work: the four words the tail launch decides by what to do (one load)
+	uint32_t any_loser;              // round 1 left requests to round 2
+	uint32_t any_tail;               // the grid-wide rounds left requests to the tail
 	uint32_t loose;                  // round 2: a follower at the head of its bucket did not get to lead -- its
 	                                 // shadows are pending requests (the tail's first gather looks for them)
+	uint32_t force_tail;             // the tail launch runs its epilogue although nothing was left to it: set by the mark
+	                                 // pass (batch dropped, a host flag word that would change, stamps running low)
+	uint32_t hint_stamp;             // low word of the round-1 stamp of the last pass whose mark pass walked ahead for a
+	                                 // chain (prewalk_register): round 1 then reads every request's reservation
+	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
+	uint32_t pad_head[2];
 	uint32_t first_hard;
 	uint32_t chain_n;                // chain-log entries handed out this call
 	uint32_t chain_ok;               // chains committed optimistically
 	uint32_t bar_chain, bar_class;
-	uint32_t carry_lo;               // lowest request index carried over from earlier chunk passes (kNone: none)
 	uint32_t barrier[kMaxRegions];   // B per closed region (kNone = none)
 	Info last;                       // snapshot of the previous call, for diagnostics
 	uint32_t sync[2];                // arrival counters of the tail launch's two grid-wide sync points
@@ -125,7 +159,6 @@ struct Ctl {
 	uint32_t g_below[2][kMaxRegions];//   requests before the round's barrier that the round has left pending
 	uint32_t g_progress[2], g_left[2];
 	uint32_t g_dupw[2];              // a duplicate writer was tagged in the round: the election is worth its meeting
-	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
 	uint32_t viol[kMaxRegions];      // tail: lowest index per region whose chain met a bucket a LATER request already used
 	uint32_t vlist_n;                // ... and the violations themselves: {index, bucket} (the first kViolCap of a turn)
 	uint2 vlist[kViolCap];
@@ -144,6 +177,11 @@ struct Ctl {
 	// first version with ONE counter (an atomic per wave that had any) made round 2 of a 50/50 Zipf-SET
 	// batch 23 -> 52 us with 650 entries -- returning atomics on one word, beside the words every wave
 	// reads when it starts.
+	// round 1 on at most kTlGroups work-groups: each leaves ONE 32-byte record in its place -- {entries it left to the
+	// tail (may exceed kTlPer), requests it committed, of those by self-help, requests it left to round 2} and the first
+	// kLlPer of the latter by index (k_tail: a short list is run by one work-group -- no scan of the pass's tags, no
+	// meeting) -- instead of a count here and atomics on the commit counters below (cleared by the mark pass, like those)
+	struct alignas(32) WgRec { uint4 stat; uint32_t ll[kLlPer]; } wg_rec[kTlGroups];
 	uint32_t tl_groups[2];               // work-groups of round 1 / round 2 of this pass
 	uint32_t tl_cnt[2][kTlGroups];       // entries a work-group left (may exceed kTlPer: not all listed)
 	uint32_t tl[2][kTlGroups][kTlPer];
@@ -317,6 +355,31 @@ __device__ __forceinline__ bool delete_in(uint32_t *table, uint32_t b, uint32_t 
 		}
 	}
 	return any;
+}
+
+// What place_loaded would do on bucket b as held in k -- as an undo record (see kPlanBit); false: the bucket
+// cannot take the request.
+__device__ __forceinline__ bool plan_primary(uint32_t b, const Bkt &k, uint32_t sig, Undo *u)
+{
+	const uint32_t m = eq_mask(k.s0, k.s1, sig);
+	if (m) {
+		const uint32_t s = (uint32_t)__ffs((int)m) - 1u;
+		u->word0 = (uint32_t)loc_word(b, s);
+		u->old0 = loc_at(k, s);
+		u->word1 = kNoWord;
+		u->old1 = 0u;
+		return true;
+	}
+	const uint32_t e = eq_mask(k.s0, k.s1, 0u);
+	if (e) {
+		const uint32_t s = preferred_slot(e, sig);
+		u->word0 = (uint32_t)sig_word(b, s);
+		u->old0 = 0u;
+		u->word1 = (uint32_t)loc_word(b, s);
+		u->old1 = loc_at(k, s);
+		return true;
+	}
+	return false;
 }
 
 // try_place on a bucket already in registers (grid-wide rounds).
@@ -740,19 +803,34 @@ __device__ __forceinline__ void fold_max_dedup(const Fold &f, unsigned long long
 // work-group's table -- the fold keeps the two lowest keys it has seen and hands both on.  (The insert
 // blocks of a batch are its closed regions: two requests of one bucket are 6 500 indices apart at most,
 // not 52 000, and meet in one work-group's turn of 256 four times in a hundred.)
-__device__ __forceinline__ void note_second(unsigned long long *second, uint32_t b, unsigned long long old,
-		unsigned long long key)
+// (Lost: the flags of the requests that are NOT the lowest registrant of a bucket they registered on, kPlanBit)
+struct Lost {
+	uint32_t *flag;     // a word per request (null: not kept -- deletes)
+	uint32_t s32;       // low half of the pass's round-1 stamp
+};
+
+__device__ __forceinline__ void flag_lost(const Lost &lost, unsigned long long key)
 {
-	// (same stamp field: an entry of this pass)
-	if ((old >> kIdxBits) == (key >> kIdxBits) && old != key)
-		atomicMin(&second[b], old > key ? old : key);
+	if (lost.flag)
+		lost.flag[(uint32_t)(key & ((1ull << kIdxBits) - 1ull))] = lost.s32;
 }
 
-// key2: a key the caller knows to be another, higher registrant of the bucket (~0: none)
-__device__ __forceinline__ void register_one(unsigned long long *owner, unsigned long long *second, uint32_t b,
-		unsigned long long key, unsigned long long key2 = ~0ull)
+__device__ __forceinline__ void note_second(unsigned long long *second, uint32_t b, unsigned long long old,
+		unsigned long long key, const Lost &lost)
 {
-	note_second(second, b, atomicMin(&owner[b], key), key);
+	// (same stamp field: an entry of this pass)
+	if ((old >> kIdxBits) == (key >> kIdxBits) && old != key) {
+		const unsigned long long larger = old > key ? old : key;
+		atomicMin(&second[b], larger);
+		flag_lost(lost, larger);
+	}
+}
+
+// key2: a key the caller knows to be another, higher registrant of the bucket (~0: none; flagged by the caller)
+__device__ __forceinline__ void register_one(unsigned long long *owner, unsigned long long *second, uint32_t b,
+		unsigned long long key, const Lost &lost, unsigned long long key2 = ~0ull)
+{
+	note_second(second, b, atomicMin(&owner[b], key), key, lost);
 	if (key2 != ~0ull)
 		atomicMin(&second[b], key2);
 }
@@ -774,7 +852,7 @@ __device__ __forceinline__ void wave_two_lowest(unsigned long long key, bool sam
 
 // atomic_min_dedup with the second table behind it (mark pass without the fold table)
 __device__ __forceinline__ void register_dedup(unsigned long long *owner, unsigned long long *second, uint32_t b,
-		unsigned long long key, bool active)
+		unsigned long long key, bool active, const Lost &lost)
 {
 #pragma unroll
 	for (int peel = 0; peel < 2; peel++) {
@@ -787,19 +865,21 @@ __device__ __forceinline__ void register_dedup(unsigned long long *owner, unsign
 		unsigned long long k = key, k2 = ~0ull;
 		if (__popcll(__ballot(same)) > 1)
 			wave_two_lowest(key, same, k, k2);
+		if (same && key != k)
+			flag_lost(lost, key);                   // (not the lowest of the lanes that go as one)
 		if ((int)(threadIdx.x & 63u) == first)
-			register_one(owner, second, fb, k, k2);
+			register_one(owner, second, fb, k, lost, k2);
 		active = active && !same;
 	}
 	if (active)
-		register_one(owner, second, b, key);
+		register_one(owner, second, b, key, lost);
 }
 
 // fold_enter / fold_min_dedup / fold_flush of the mark pass with the second table behind them: a slot
 // keeps the lowest key entered (tk) and the lowest of the others (tk2)
 template <int LOG2>
 __device__ __forceinline__ bool mark_fold_enter(const Fold &f, unsigned long long *tk2, uint32_t b, unsigned long long key,
-		unsigned long long key2)
+		unsigned long long key2, const Lost &lost)
 {
 	uint32_t slot = (b * 2654435761u) >> (32 - LOG2);
 	for (int probe = 0; probe < 2; probe++) {
@@ -807,6 +887,8 @@ __device__ __forceinline__ bool mark_fold_enter(const Fold &f, unsigned long lon
 		if (old == kNone || old == b) {
 			const unsigned long long prev = atomicMin(&f.tk[slot], key);
 			unsigned long long other = prev == ~0ull ? ~0ull : (prev > key ? prev : key);
+			if (other != ~0ull && prev != key)
+				flag_lost(lost, other);             // (the larger of two keys that met in the slot)
 			other = key2 < other ? key2 : other;
 			if (other != ~0ull)
 				atomicMin(&tk2[slot], other);
@@ -819,7 +901,7 @@ __device__ __forceinline__ bool mark_fold_enter(const Fold &f, unsigned long lon
 
 template <int LOG2>
 __device__ __forceinline__ void mark_fold_min_dedup(const Fold &f, unsigned long long *tk2, unsigned long long *owner,
-		unsigned long long *second, uint32_t b, unsigned long long key, bool active)
+		unsigned long long *second, uint32_t b, unsigned long long key, bool active, const Lost &lost)
 {
 #pragma unroll
 	for (int peel = 0; peel < 2; peel++) {
@@ -832,23 +914,25 @@ __device__ __forceinline__ void mark_fold_min_dedup(const Fold &f, unsigned long
 		unsigned long long k = key, k2 = ~0ull;
 		if (__popcll(__ballot(same)) > 1)
 			wave_two_lowest(key, same, k, k2);
-		if ((int)(threadIdx.x & 63u) == first && !mark_fold_enter<LOG2>(f, tk2, fb, k, k2))
-			register_one(owner, second, fb, k, k2);
+		if (same && key != k)
+			flag_lost(lost, key);                   // (not the lowest of the lanes that go as one)
+		if ((int)(threadIdx.x & 63u) == first && !mark_fold_enter<LOG2>(f, tk2, fb, k, k2, lost))
+			register_one(owner, second, fb, k, lost, k2);
 		active = active && !same;
 	}
-	if (active && !mark_fold_enter<LOG2>(f, tk2, b, key, ~0ull))
-		register_one(owner, second, b, key);
+	if (active && !mark_fold_enter<LOG2>(f, tk2, b, key, ~0ull, lost))
+		register_one(owner, second, b, key, lost);
 }
 
 template <int LOG2>
 __device__ __forceinline__ void mark_fold_flush(const Fold &f, unsigned long long *tk2, unsigned long long *owner,
-		unsigned long long *second)
+		unsigned long long *second, const Lost &lost)
 {
 	__syncthreads();
 	for (uint32_t s = threadIdx.x; s < (1u << LOG2); s += blockDim.x) {
 		const uint32_t b = f.tb[s];
 		if (b != kNone) {
-			register_one(owner, second, b, f.tk[s], tk2[s]);
+			register_one(owner, second, b, f.tk[s], lost, tk2[s]);
 			f.tb[s] = kNone;
 			tk2[s] = ~0ull;
 		}
@@ -874,7 +958,7 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 // through the ordinary reservation instead of being committed under the chain's feet.  Only
 // a hint: nothing depends on the walk being right (the table may change before the turn).
 __device__ __forceinline__ void prewalk_register(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P,
-		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi)
+		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi, uint32_t *hint_stamp, uint32_t s32)
 {
 	// (lo, hi: the signature row of P, loaded by the caller)
 	if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
@@ -885,6 +969,8 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 			return;
 	}
 	const uint32_t v = r.sig & 7u;              // victim slot: ORIGINAL signature (ref :360)
+	if (g.max_cuckoo != 0u)
+		*hint_stamp = s32;                      // (registrations without a returning atomic: round 1 reads every reservation, kPlanBit)
 	for (uint32_t k = 0; k < g.max_cuckoo; k++) {
 		const uint4 q = (v & 4u) ? hi : lo;
 		const uint32_t a = (v & 1u) ? q.y : q.x, c = (v & 1u) ? q.w : q.z;

@@ -9,10 +9,11 @@
 namespace mkv {
 
 // ---- K1: mark -----------------------------------------------------------------
+// (undo, lost_flags: where the plans and the flags of kPlanBit go -- null: none are made)
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap,
-		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, uint32_t lazy_free)
+		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, uint32_t lazy_free, Undo *undo, uint32_t *lost_flags)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
@@ -36,7 +37,13 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	}
 	const uint32_t t = threadIdx.x;
 	const uint32_t nblk = src.nblk;
-	const unsigned long long stamp = ctl->stamp_base;
+	// this pass's round-1 stamp (Ctl, head: the pass before may have ended without its epilogue)
+	const unsigned long long stamp_prev = ctl->stamp_base;
+	const uint32_t ep_pending = ctl->ep_pending;
+	const unsigned long long stamp = stamp_prev + (ep_pending ? 3ull : 0ull);
+	Lost lost;
+	lost.flag = OP != OP_DELETE && undo ? lost_flags : nullptr;
+	lost.s32 = (uint32_t)stamp;
 	if (src.single) {
 		if (t == 0) {
 			const unsigned long long n = src.single_n > 0 ? (unsigned long long)src.single_n : 0ull;
@@ -64,8 +71,21 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	const bool over = s_total == kNone;
 	const uint32_t total = over ? 0u : s_total;
 	if (block == 0 && t == 0) {
+		ctl->stamp_cur = stamp;
 		ctl->total = total;
 		ctl->overflow = over ? 1u : 0u;
+		// The tail launch of this pass leaves at once if the rounds leave it nothing -- unless its epilogue has
+		// something to tell the host (a dropped batch to count, a flag word that may have to change back, round
+		// stamps running low) or a score to run down
+		ctl->force_tail = (over || ctl->hf_last[0] != 0u || ctl->hf_last[1] != 0u || ctl->hf_losers != 0u || ctl->late_score != 0u ||
+				stamp > kStampMax - kStampReserve) ? 1u : 0u;
+		if (ep_pending) {
+			// ... in which case what the epilogue would have reset is reset here
+			ctl->first_hard = kNone;
+			ctl->chain_n = 0u;
+			ctl->chain_ok = 0u;
+			ctl->any_loser = 0u;        // (a handful of losers that round 2 saw through, k_tail)
+		}
 	}
 	if (block == 0 && t < (uint32_t)kShards) {
 		// commit counters of the rounds that follow (the tail reads them: statistics, and how
@@ -79,8 +99,10 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	// when the round runs on more than kTlGroups of them -- tuning "round_blocks"; round 2's are cleared by
 	// round 1.  Same rule: by a kernel before the one that counts.)
 	if (block == 0)
-		for (uint32_t q = t; q < kTlGroups; q += blockDim.x)
+		for (uint32_t q = t; q < kTlGroups; q += blockDim.x) {
 			ctl->tl_cnt[0][q] = 0u;
+			ctl->wg_rec[q].stat = make_uint4(0u, 0u, 0u, 0u);
+		}
 	const uint32_t end = hi_idx < total ? hi_idx : total;
 	// requests an earlier chunk pass of this call left unresolved ride along: they have
 	// lower indices, so they win every reservation they share with this chunk's requests
@@ -145,25 +167,35 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		// the primary bucket's signature row as the table stands (a hint: deletes of the same cycle
 		// may still be running): room enough there -> no registration on the alternate bucket
 		uint4 plo = make_uint4(1u, 1u, 1u, 1u), phi = plo;
-		bool lazy = false;
+		bool lazy = false, planned = false;
 		if (OP != OP_DELETE && live && table && (fresh || OP == OP_CUCKOO)) {
-			load_sig_row<false>(table, P, plo, phi);
+			// (the whole bucket: the same 64-byte request as its signature row)
+			const Bkt kP = load_bucket(table, P);
+			plo = kP.s0;
+			phi = kP.s1;
 			lazy = fresh && lazy_free != 0u && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= lazy_free;
+			// what the request would do in P as the table stands (kPlanBit)
+			Undo u;
+			if (fresh && undo && plan_primary(P, kP, rq.sig, &u)) {
+				undo[idx] = u;
+				planned = true;
+			}
 		}
 		if (fresh)
-			reqc[idx] = make_uint4(rq.sig, rq.hash, rq.loc, lazy ? kLazyBit : 0u);
+			reqc[idx] = make_uint4(rq.sig, rq.hash, rq.loc, (lazy ? kLazyBit : 0u) | (planned ? kPlanBit : 0u));
 		const unsigned long long key = owner_key(stamp, idx);
-		// (every registration notes the bucket's second-lowest registrant: note_second)
+		// (every registration notes the bucket's second-lowest registrant, note_second, and flags whoever is
+		// not a bucket's lowest one, flag_lost)
 		if (use_fold) {
-			mark_fold_min_dedup<kMarkFoldLog2>(fold, s_tk2, owner, second, P, key, live);
-			mark_fold_min_dedup<kMarkFoldLog2>(fold, s_tk2, owner, second, A, key, live && A != P && !lazy);
-			mark_fold_flush<kMarkFoldLog2>(fold, s_tk2, owner, second);
+			mark_fold_min_dedup<kMarkFoldLog2>(fold, s_tk2, owner, second, P, key, live, lost);
+			mark_fold_min_dedup<kMarkFoldLog2>(fold, s_tk2, owner, second, A, key, live && A != P && !lazy, lost);
+			mark_fold_flush<kMarkFoldLog2>(fold, s_tk2, owner, second, lost);
 		} else {
-			register_dedup(owner, second, P, key, live);
-			register_dedup(owner, second, A, key, live && A != P && !lazy);
+			register_dedup(owner, second, P, key, live, lost);
+			register_dedup(owner, second, A, key, live && A != P && !lazy, lost);
 		}
 		if (OP == OP_CUCKOO && live && table && !lazy)
-			prewalk_register(table, g, rq, P, A, owner, key, plo, phi);
+			prewalk_register(table, g, rq, P, A, owner, key, plo, phi, &ctl->hint_stamp, (uint32_t)stamp);
 	}
 }
 
@@ -272,9 +304,10 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 template <Op OP>
 __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t lo_idx,
-		uint32_t hi_idx, const uint32_t *table, int lazy_on)
+		uint32_t hi_idx, const uint32_t *table, int lazy_on, Undo *undo, uint32_t *lost)
 {
-	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, second, reqc, state, req_cap, lo_idx, hi_idx, table, (uint32_t)lazy_on);
+	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, second, reqc, state, req_cap, lo_idx, hi_idx, table, (uint32_t)lazy_on,
+			undo, lost);
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -284,13 +317,17 @@ template <Op OP>
 __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ in,
 		uint32_t *__restrict__ out, const uint4 *__restrict__ table, int64_t n, uint32_t search_blocks,
 		Ctl *ctl, ReqSrc src, DevGeom g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state,
-		uint32_t req_cap, uint32_t hi_idx, int lazy_on)
+		uint32_t req_cap, uint32_t hi_idx, int lazy_on, Undo *undo, uint32_t *lost)
 {
 	// mark blocks first: they are few and latency-bound, let them start early
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
+#ifdef MKV_EXP_NOMARK
+	if (blockIdx.x < mark_blocks)       // launch-floor experiment (timing only): the mark work-groups leave at once
+		return;
+#endif
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on);
+				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost);
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
 }
@@ -302,12 +339,12 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 		int64_t slot_words, uint32_t cap_get, uint32_t *__restrict__ out, const uint4 *__restrict__ table,
 		uint32_t chunks_per_slot, uint32_t search_blocks, Ctl *ctl, ReqSrc src, DevGeom g,
 		unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap, uint32_t hi_idx,
-		uint32_t self, uint32_t *__restrict__ self_out, int lazy_on)
+		uint32_t self, uint32_t *__restrict__ self_out, int lazy_on, Undo *undo, uint32_t *lost)
 {
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on);
+				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost);
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
 				g.blk_mask, chunks_per_slot, self, self_out);

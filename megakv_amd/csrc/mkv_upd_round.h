@@ -28,6 +28,16 @@ __device__ __forceinline__ void tail_list_add(uint32_t *s_tl, uint32_t *s_tln, u
 	}
 }
 
+// ... and round 1 what it leaves to round 2: the first kLlPer per work-group (the count is in its record, Ctl::wg_rec)
+__device__ __forceinline__ void loser_list_add(uint32_t *s_ll, uint32_t *s_lln, uint32_t idx, bool add)
+{
+	if (add) {
+		const uint32_t at = atomicAdd(s_lln, 1u);
+		if (at < kLlPer)
+			s_ll[at] = idx;
+	}
+}
+
 template <int ROUND>
 __device__ __forceinline__ void tail_list_flush(Ctl *ctl, const uint32_t *s_tl, const uint32_t *s_tln, uint32_t block,
 		uint32_t nblocks)
@@ -68,8 +78,9 @@ struct RoundLds {
 	static constexpr size_t qg = ftk + sizeof(unsigned long long) * 2u * kRFold;    // uint32_t[QCAP]
 	static constexpr size_t ftb = qg + sizeof(uint32_t) * QCAP;                     // uint32_t[2 * kRFold]
 	static constexpr size_t tl = ftb + sizeof(uint32_t) * 2u * kRFold;              // uint32_t[kTlPer]
-	static constexpr size_t words = tl + sizeof(uint32_t) * kTlPer;                 // s_qn, s_fused, s_tln
-	static constexpr size_t bytes = words + 4u * sizeof(uint32_t);
+	static constexpr size_t ll = tl + sizeof(uint32_t) * kTlPer;                    // uint32_t[kLlPer]
+	static constexpr size_t words = ll + sizeof(uint32_t) * kLlPer;                 // s_qn, s_fused, s_tln, s_lln, then the work-group's three counts
+	static constexpr size_t bytes = words + 8u * sizeof(uint32_t);
 };
 
 // (block of nblocks: the work-group's place among those that share the round -- the launch's own for
@@ -79,8 +90,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		const DevGeom &g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax, const unsigned long long *second)
+		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, const uint32_t *list = nullptr,
+		uint32_t list_n = 0u)
 {
+	// (list: the round's requests by index, at most a lane each -- one turn over them instead of the scan of the
+	// pass's tags: round 2 run by the tail launch's first work-group over the few losers round 1 listed)
+	// (lost: the mark pass's flags of the requests that are not the lowest registrant of their buckets, kPlanBit)
 	// (second: the mark pass's second-lowest registrant per bucket, note_second)
 	// (emax: a word per bucket -- the followers of a bucket's round-1 owner elect the last of them there,
 	// kFollowBit; the tail's elections use the same words under its own, later stamps)
@@ -89,23 +104,40 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	// work-group's first index turns out to be what was guessed (no carried requests).
 	const uint32_t pre_base = lo_idx + block * blockDim.x;
 	const uint32_t pre_idx = pre_base + threadIdx.x;
-	const bool pre_ok = pre_idx < req_cap && pre_idx >= lo_idx;
+	const bool pre_ok = pre_idx < req_cap && pre_idx >= lo_idx && list == nullptr;
 	const uint8_t pre_st = pre_ok ? state[pre_idx] : (uint8_t)ST_DONE;
 	const uint4 pre_rc = pre_ok ? reqc[pre_idx] : make_uint4(0u, 0u, 0u, 0u);
+	// (round 1: the mark pass's plans stand -- bit 6 of the hint: the host knows of nothing that wrote the
+	// table since -- so the request's plan and its flag travel with the request)
+	const bool plans = ROUND == 1 && OP != OP_DELETE && (record_hint & 64) != 0 && lost != nullptr;
+	const uint32_t pre_lost = plans && pre_ok ? lost[pre_idx] : 0u;
+	Undo pre_plan;
+	if (plans && pre_ok)
+		pre_plan = undo[pre_idx];
+	else
+		pre_plan.word0 = pre_plan.old0 = pre_plan.word1 = pre_plan.old1 = kNoWord;
 	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
 	const bool groups_on = (record_hint & 8) == 0;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
 	const bool help_on = (record_hint & 32) == 0;         // Tuning::self_help = 0: the second registrant waits for round 2, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
+	// (round 1 reads the stamp its mark pass published; its first work-group makes it the pass's stamp for the
+	// kernels that follow and notes that the pass's epilogue is still to come: Ctl, head)
+	const unsigned long long stamp1 = ROUND == 1 ? ctl->stamp_cur : ctl->stamp_base;
 	if (ROUND == 1 && block == 0) {
-		if (threadIdx.x == 0)
-			reset_tail_scratch(ctl);
+		reset_tail_scratch(ctl);
+		if (threadIdx.x == 0) {
+			ctl->stamp_base = stamp1;
+			ctl->ep_pending = 1u;
+		}
 		for (uint32_t q = threadIdx.x; q < kTlGroups; q += blockDim.x)
 			ctl->tl_cnt[1][q] = 0u;                 // (round 2's places: its work-groups may have to share them, tail_list_flush)
 	}
 	const uint32_t count = hi_idx < ctl->total ? hi_idx : ctl->total;
-	const unsigned long long stamp1 = ctl->stamp_base;
 	const unsigned long long stamp = stamp1 + (ROUND - 1);
+	// (... unless a chain walked ahead in this pass's mark pass: it registers without flagging, prewalk_register)
+	const bool plans_on = plans && ctl->hint_stamp != (uint32_t)stamp1;
+	const uint32_t s32 = (uint32_t)stamp1;
 	const uint32_t span = nblocks * blockDim.x;
 	uint32_t ndone = 0, ndone_help = 0, nlosers = 0;
 	// owner table holding the round-1 registrations of every request of this pass (chains claim there)
@@ -142,10 +174,14 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	fmax.tk = s_ftk + kRFold;
 	uint32_t *s_tl = reinterpret_cast<uint32_t *>(lds + Lds::tl);   // what this work-group leaves to the tail (tail_list_add)
 	uint32_t &s_tln = s_words[2];
+	uint32_t *s_ll = reinterpret_cast<uint32_t *>(lds + Lds::ll);   // round 1: what this work-group leaves to round 2 (the first kLlPer)
+	uint32_t &s_lln = s_words[3];
 	if (threadIdx.x == 0) {
 		s_qn = 0u;
 		s_fused = 0u;
 		s_tln = 0u;
+		s_lln = 0u;
+		s_words[4] = s_words[5] = s_words[6] = 0u;
 	}
 	if (ROUND == 1) {
 		for (uint32_t q = threadIdx.x; q < 2u * kRFold; q += blockDim.x) {
@@ -166,11 +202,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	uint32_t pf_a = 0u, pf_b = 0u;
 	// (Fetching a turn's requests and tags a turn ahead was built and measured: no difference -- the turns of a
 	// long pass are bound by the memory system's rate of random accesses, not by their round trips.)
-	for (bool more = base < count && base >= start; ; ) {
+	for (bool more = list ? list_n != 0u : (base < count && base >= start); ; ) {
 		asm volatile("" ::"v"(pf_a), "v"(pf_b));       // (last turn's touches have long arrived)
 		if (more) {
-			const uint32_t idx = base + threadIdx.x;
-			const bool in_range = idx < count;
+			const bool listed = list != nullptr && threadIdx.x < list_n;
+			const uint32_t idx = list ? (listed ? list[threadIdx.x] : 0u) : base + threadIdx.x;
+			const bool in_range = list ? listed : idx < count;
 			// first round trip: request and its state -- independent loads
 			const bool pre = base == pre_base && pre_ok;
 			const uint8_t st = !in_range ? (uint8_t)ST_DONE : pre ? pre_st : state[idx];
@@ -185,7 +222,45 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			// exclusive use of exactly the buckets it touches.
 			bool lose = false, follower = false, shadow = false;
 			uint32_t lead_of = kNone;                   // round 2: the request this one is a shadow of
-			if (pending) {
+			// Round 1, the usual request: it has a plan and nobody flagged it -- the lowest registrant of its
+			// primary bucket, which is as the mark pass saw it: the plan's stores, no further load (kPlanBit)
+			bool planned = false;
+			if (ROUND == 1 && plans_on && pending && (rc.w & kPlanBit)) {
+				const uint32_t lf = pre ? pre_lost : lost[idx];
+				if (lf != s32) {
+					Undo u;
+					if (pre)
+						u = pre_plan;
+					else
+						u = undo[idx];
+#if defined(MKV_EXP_R1) && (MKV_EXP_R1 & 16)
+					if (u.word1 == kNoWord) {       // experiment: write-through stores
+						__hip_atomic_store(&table[u.word0], r.loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					} else {
+						__hip_atomic_store(&table[u.word0], r.sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+						__hip_atomic_store(&table[u.word1], r.loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+					}
+#elif defined(MKV_EXP_R1) && (MKV_EXP_R1 & 32)
+					if (u.word1 == kNoWord) {       // experiment: non-temporal stores
+						__builtin_nontemporal_store(r.loc, &table[u.word0]);
+					} else {
+						__builtin_nontemporal_store(r.sig, &table[u.word0]);
+						__builtin_nontemporal_store(r.loc, &table[u.word1]);
+					}
+#else
+					if (u.word1 == kNoWord) {
+						table[u.word0] = r.loc;
+					} else {
+						table[u.word0] = r.sig;
+						table[u.word1] = r.loc;
+					}
+#endif
+					state[idx] = ST_ROUND1;
+					ndone++;
+					planned = true;
+				}
+			}
+			if (pending && !planned) {
 				const unsigned long long oP = owner[P];
 				const Bkt kP = load_bucket(table, P);
 				if (oP == key) {
@@ -354,8 +429,10 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			}
 			if (ROUND == 2)
 				tail_list_add(s_tl, &s_tln, idx, lose && !shadow);
+			else
+				loser_list_add(s_ll, &s_lln, idx, lose);
 			base += span;
-			more = base < count && base >= start;
+			more = list == nullptr && base < count && base >= start;
 		}
 		__syncthreads();
 		if (ROUND == 1 && s_fused) {
@@ -457,6 +534,8 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 				nlosers++;
 				ctl->any_loser = 1u;
 			}
+			if (ROUND == 1)
+				loser_list_add(s_ll, &s_lln, idx, lose);
 			if (to_tail) {
 				state[idx] = ST_TAIL;
 				ctl->any_tail = 1u;
@@ -489,6 +568,34 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		atomicMax(&ctl->dbg[7], dg_qmax);
 	}
 #endif
+	if (ROUND == 1 && nblocks <= kTlGroups) {
+		// Round 1 with a place of its own per work-group (the usual launch): what it counted and what it leaves to
+		// the tail go there in one record, no atomics on global memory -- 800 waves adding to the sharded counters and
+		// 512 work-groups each storing a count cost a 52 K-request pass 0.9 us (profiles/r05_launch_floor.txt)
+		uint32_t a = ndone + ndone_help, b = ndone_help, c = nlosers;
+		for (int off = 32; off > 0; off >>= 1) {
+			a += __shfl_down(a, off);
+			b += __shfl_down(b, off);
+			c += __shfl_down(c, off);
+		}
+		if ((threadIdx.x & 63u) == 0u) {
+			if (a) atomicAdd(&s_words[4], a);
+			if (b) atomicAdd(&s_words[5], b);
+			if (c) atomicAdd(&s_words[6], c);
+		}
+		__syncthreads();
+		const uint32_t n = s_tln;
+		if (threadIdx.x < kTlPer && threadIdx.x < n)
+			ctl->tl[0][block][threadIdx.x] = s_tl[threadIdx.x];
+		if (threadIdx.x < kLlPer && threadIdx.x < s_lln)
+			ctl->wg_rec[block].ll[threadIdx.x] = s_ll[threadIdx.x];
+		if (threadIdx.x == 0) {
+			ctl->wg_rec[block].stat = make_uint4(n, s_words[4], s_words[5], s_words[6]);
+			if (block == 0)
+				ctl->tl_groups[0] = nblocks;
+		}
+		return;
+	}
 	count_add(&ctl->committed[ROUND - 1][0].n, ndone);
 	if (ROUND == 1 && help_on) {
 		count_add(&ctl->committed[0][0].n, ndone_help);
@@ -504,11 +611,11 @@ template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax, const unsigned long long *second)
+		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost)
 {
 	__shared__ __align__(16) unsigned char lds[RoundLds<ROUND, kDeferCap>::bytes];
 	round_body<OP, ROUND, kDeferCap>(blockIdx.x, gridDim.x, lds, ctl, g, table, owner, owner_next, reqc, state, undo,
-			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax, second);
+			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax, second, lost);
 }
 
 }  // namespace mkv

@@ -305,24 +305,28 @@ __device__ __forceinline__ void grid_sync(uint32_t *counter, uint32_t nwg)
 // counter when work-group 0 is already through.
 __device__ __forceinline__ void reset_tail_scratch(Ctl *ctl)
 {
-	ctl->sync[0] = ctl->sync[1] = 0;
-	ctl->sync_r2 = 0;
-	ctl->g_sync = 0;
-	ctl->glist_n = 0;
-	ctl->loose = 0;
-	ctl->carry_next = kNone;
-	ctl->undone_acc = 0;
-	ctl->g_progress[0] = ctl->g_progress[1] = 0;
-	ctl->g_left[0] = ctl->g_left[1] = 0;
-	ctl->g_dupw[0] = ctl->g_dupw[1] = 0;
-	ctl->tail_rounds_used = 0;
-	ctl->tflags = 0;
-	ctl->vlist_n = 0;
-	for (int k = 0; k < kMaxRegions; k++) {
-		ctl->g_rbar[0][k] = ctl->g_rbar[1][k] = kNone;
-		ctl->g_rmin[0][k] = ctl->g_rmin[1][k] = kNone;
-		ctl->g_below[0][k] = ctl->g_below[1][k] = 0u;
-		ctl->viol[k] = kNone;
+	// (called by every lane of a work-group: the per-region words a lane each)
+	const uint32_t t = threadIdx.x;
+	if (t == 0) {
+		ctl->sync[0] = ctl->sync[1] = 0;
+		ctl->sync_r2 = 0;
+		ctl->g_sync = 0;
+		ctl->glist_n = 0;
+		ctl->loose = 0;
+		ctl->carry_next = kNone;
+		ctl->undone_acc = 0;
+		ctl->g_progress[0] = ctl->g_progress[1] = 0;
+		ctl->g_left[0] = ctl->g_left[1] = 0;
+		ctl->g_dupw[0] = ctl->g_dupw[1] = 0;
+		ctl->tail_rounds_used = 0;
+		ctl->tflags = 0;
+		ctl->vlist_n = 0;
+	}
+	if (t < (uint32_t)kMaxRegions) {
+		ctl->g_rbar[0][t] = ctl->g_rbar[1][t] = kNone;
+		ctl->g_rmin[0][t] = ctl->g_rmin[1][t] = kNone;
+		ctl->g_below[0][t] = ctl->g_below[1][t] = 0u;
+		ctl->viol[t] = kNone;
 	}
 }
 
@@ -1078,7 +1082,8 @@ __device__ __forceinline__ uint32_t grid_rounds(Ctl *ctl, const DevGeom &g, uint
 		int max_rounds, uint32_t *rounds_used, uint32_t *par_total, uint32_t *ticks, const Tv &tv, uint32_t stamp_skip,
 		const Fold &fold, uint32_t min_progress)
 {
-	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+	const uint32_t t = threadIdx.x, wg = blockIdx.x;
+	uint32_t nwg = gridDim.x;
 	const uint32_t first = wg * blockDim.x + t, span = nwg * blockDim.x;
 	fold_clear<false, kFoldLog2>(fold);
 	// ticks[0..7]: register, its meeting, decide, its meeting, election + meeting, commit, its meeting
@@ -1700,11 +1705,18 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 	if (t < 64) {
 		// statistics shards: one wave sums them
 		uint32_t c1 = ctl->committed[0][t].n, c2 = ctl->committed[1][t].n;      // (cleared by the next mark pass)
+		uint32_t w3 = 0, w4 = 0;
+		for (uint32_t q = t; q < kTlGroups; q += 64u) {      // (round 1's records, one per work-group: Ctl::wg_rec)
+			const uint4 ws = ctl->wg_rec[q].stat;
+			c1 += ws.y;
+			w3 += ws.z;
+			w4 += ws.w;
+		}
 		for (int off = 32; off > 0; off >>= 1) {
 			c1 += __shfl_down(c1, off);
 			c2 += __shfl_down(c2, off);
 		}
-		uint32_t c3 = ctl->committed[2][t].n, c4 = ctl->committed[3][t].n;
+		uint32_t c3 = ctl->committed[2][t].n + w3, c4 = ctl->committed[3][t].n + w4;
 		for (int off = 32; off > 0; off >>= 1) {
 			c3 += __shfl_down(c3, off);
 			c4 += __shfl_down(c4, off);
@@ -1777,9 +1789,8 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 		ctl->first_hard = kNone;
 		ctl->total = 0;
 		// stamps: rounds 1 and 2, what the tail's rounds took, one spare
-		const unsigned long long st = ctl->stamp_base + 3ull + rounds_total;
-		ctl->stamp_base = st;
-		ctl->next_stamp = st;
+		ctl->stamp_base = ctl->stamp_base + 3ull + rounds_total;
+		ctl->ep_pending = 0u;
 		ctl->carry_lo = kNone;
 	}
 }
@@ -1817,7 +1828,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
 	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
-	const uint32_t t = threadIdx.x, wg = blockIdx.x, nwg = gridDim.x;
+	const uint32_t t = threadIdx.x, wg = blockIdx.x;
+	uint32_t nwg = gridDim.x;
 	// (time per phase: diagnostics builds only, make DIAG=1 -- sixteen registers held for the whole
 	// launch are more than this kernel has to spare)
 #ifdef MKV_DIAGNOSTICS
@@ -1831,16 +1843,79 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 #endif
 	static_assert(kTailThreads == 2 * (int)kTlGroups, "a lane of the tail's first work-group per round and work-group of the rounds");
 	const uint32_t my_round = t < kTlGroups ? 0u : 1u, my_wg = t & (kTlGroups - 1u);
+	// The rounds left nothing and the epilogue has nothing to tell anybody (the usual batch, three passes in
+	// four): every work-group reads the four flag words -- one load; final: only kernels before this one in the
+	// stream set them -- and leaves.  Nothing is written: the pass's epilogue stays pending (Ctl::ep_pending), the
+	// next pass's mark pass steps over its stamps and resets what is to be reset, and whoever asks for the pass's
+	// statistics meanwhile works them out from the rounds' counters (mkv_last_update_info_ex).  An extra launch of
+	// this grid with nothing to do costs 1.3 - 1.5 us in this chain (profiles/r05_launch_floor.txt); the epilogue --
+	// five dependent round trips on one lane -- made it 4.1 - 4.8.
+	// (round 1's record for this lane, should round 2 have anything to do: asked for beside the flags)
+	uint4 rec_stat = make_uint4(0u, 0u, 0u, 0u), rec_ll = rec_stat;
+	if (round2_hint >= 0 && OP != OP_DELETE && t < kTlGroups && first_chunk && last_chunk) {
+		const uint4 *rp = reinterpret_cast<const uint4 *>(&ctl->wg_rec[t]);
+		rec_stat = rp[0];
+		rec_ll = rp[1];
+	}
+	static_assert(sizeof(Ctl::WgRec) == 32 && offsetof(Ctl, wg_rec) % 32 == 0, "two 16-byte loads");
+	const uint4 flags = *reinterpret_cast<const uint4 *>(&ctl->any_loser);     // {any_loser, any_tail, loose, force_tail}
+	static_assert(offsetof(Ctl, any_loser) % 16 == 0 && offsetof(Ctl, force_tail) == offsetof(Ctl, any_loser) + 12, "one load");
+	if ((flags.x | flags.y | flags.z | flags.w) == 0u && first_chunk && last_chunk)
+		return;
 	const uint32_t total_all = ctl->total;
-	if (round2_hint >= 0 && OP != OP_DELETE && ctl->any_loser != 0u) {
+	// Round 1 left round 2 a handful (the usual pass has one loser in two cases of three: a third registrant of a
+	// bucket, a request behind one that holds the bucket as its alternate, a second registrant of a full bucket) and
+	// listed them (Ctl::ll): this work-group runs round 2 over the list and goes on alone -- no scan of the pass's
+	// tags by 32 work-groups, no meeting behind it; the others read the same records, decide alike and leave.
+	__shared__ uint32_t s_few_n, s_few_bad, s_few[kFewLosers];
+	bool few = false;
+	if (round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u && first_chunk && last_chunk) {
+		if (t == 0) {
+			s_few_n = 0u;
+			s_few_bad = 0u;
+		}
+		__syncthreads();
+		if (t < kTlGroups) {
+			const uint32_t nl = rec_stat.w;
+			if (nl > kLlPer) {
+				s_few_bad = 1u;
+			} else if (nl) {
+				const uint32_t at = atomicAdd(&s_few_n, nl);
+				if (at + nl > kFewLosers) {
+					s_few_bad = 1u;
+				} else {
+					s_few[at] = rec_ll.x;
+					if (nl > 1u) s_few[at + 1u] = rec_ll.y;
+					if (nl > 2u) s_few[at + 2u] = rec_ll.z;
+					if (nl > 3u) s_few[at + 3u] = rec_ll.w;
+				}
+			}
+		}
+		__syncthreads();
+		few = s_few_bad == 0u && s_few_n != 0u;      // (none listed: round 1 ran on more work-groups than it has records for)
+	}
+	if (few) {
+		if (wg != 0)
+			return;
+		nwg = 1u;
+		round_body<OP, 2, kTailThreads>(0u, 1u, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
+				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
+				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, s_few, s_few_n);
+		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (every lane's stores have left before anybody reads on)
+		wg_sync();
+		// ... and that was it, as a rule: the pass's epilogue stays pending then, as on the way out above
+		// (the next mark pass resets the round's flag; its commits are counted where the host finds them)
+		if (ld_agent32(&ctl->any_tail) == 0u && flags.w == 0u)
+			return;
+	} else if (round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u) {
 		// (every work-group reads the same flag: round 1, the kernel before, set it)
 		static_assert(RoundLds<2, kTailThreads>::bytes <= sizeof(lkeys), "round 2's LDS in the work list's");
 		round_body<OP, 2, kTailThreads>(wg, nwg, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
 				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
-				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second);
+				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr);
 		grid_sync(&ctl->sync_r2, nwg);
 	}
-	// The rounds left nothing (the usual batch, three passes in four): no lists, no scans, no meetings --
+	// Round 2 left nothing (or the epilogue is wanted for its own sake): no lists, no scans, no meetings --
 	// every work-group reads the one flag (final: only kernels before this one in the stream -- or the
 	// phase above, behind its meeting -- set it) and work-group 0 leaves the control block ready for the
 	// next pass.
@@ -1869,7 +1944,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		if (tl_g1 > kTlGroups || tl_g2 > kTlGroups) {
 			s_tl_over = 1u;
 		} else if (my_wg < (my_round ? tl_g2 : tl_g1)) {
-			my_cnt = ctl->tl_cnt[my_round][my_wg];
+			my_cnt = ctl->tl_cnt[my_round][my_wg] + (my_round == 0u ? ctl->wg_rec[my_wg].stat.x : 0u);    // (round 1: one or the other, round_body)
 			if (my_cnt > kTlPer)
 				s_tl_over = 1u;
 			else if (my_cnt)
@@ -1898,6 +1973,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// counters (final: only the kernels before this one in the stream change them).
 	if (t < 64u) {
 		uint32_t c = ctl->committed[0][t].n + ctl->committed[1][t].n;
+		for (uint32_t q = t; q < kTlGroups; q += 64u)
+			c += ctl->wg_rec[q].stat.y;
 		for (int off = 32; off > 0; off >>= 1)
 			c += __shfl_down(c, off);
 		if (t == 0)
@@ -2188,13 +2265,17 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 	if (t == 0) {
 		if (host_flag)
 			host_flag[0] = host_flag[1] = host_flag[3] = 0;     // (in step with hf_last / hf_losers below)
-		ctl->stamp_base = first_stamp;
-		ctl->next_stamp = first_stamp + kStampsPerCall;
+		ctl->stamp_base = ctl->stamp_cur = first_stamp;
+		ctl->ep_pending = 0;
 		ctl->total = 0;
 		ctl->overflow = 0;
 		ctl->any_loser = ctl->any_tail = 0;
+		ctl->force_tail = 0;
+		ctl->hint_stamp = 0;
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k].n = ctl->committed[1][k].n = ctl->committed[2][k].n = ctl->committed[3][k].n = 0;
+		for (uint32_t k = 0; k < kTlGroups; k++)
+			ctl->wg_rec[k].stat = make_uint4(0u, 0u, 0u, 0u);
 		ctl->first_hard = kNone;
 		ctl->last = Info{0, 0, 0, 0, 0, 0, kNone, 0, 0, 0, 0, 0, 0, 0};
 		ctl->bar_chain = ctl->bar_class = 0;
@@ -2209,8 +2290,8 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->hf_losers = 0;
 		for (int k = 0; k < 8; k++)
 			ctl->dbg[k] = 0;
-		reset_tail_scratch(ctl);
 	}
+	reset_tail_scratch(ctl);
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
 }

@@ -107,6 +107,7 @@ struct Workspace {
 	uint8_t *state = nullptr;
 	uint4 *reqc = nullptr;
 	Undo *undo = nullptr;
+	uint32_t *lost = nullptr;              // the mark pass's flags: not the lowest registrant of a bucket (kPlanBit)
 	uint32_t *glist = nullptr;
 	ChainLog *chain_logs = nullptr;        // kChainLogCap logs of the grid-wide rounds' chains, then one per lane
 	                                       // of the tail launch (kTailLanes)
@@ -148,6 +149,7 @@ static void free_ws(Workspace *w)
 	if (w->state) (void)hipFree(w->state);
 	if (w->reqc) (void)hipFree(w->reqc);
 	if (w->undo) (void)hipFree(w->undo);
+	if (w->lost) (void)hipFree(w->lost);
 	if (w->glist) (void)hipFree(w->glist);
 	if (w->chain_logs) (void)hipFree(w->chain_logs);
 	if (w->ctl) (void)hipFree(w->ctl);
@@ -232,6 +234,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	ok = ok && hipMalloc(&w->reqc, (size_t)rc * sizeof(uint4)) == hipSuccess;
 	ok = ok && hipMalloc(&w->undo, (size_t)rc * sizeof(Undo)) == hipSuccess;
 	ok = ok && hipMalloc(&w->glist, (size_t)rc * 4) == hipSuccess;
+	ok = ok && hipMalloc(&w->lost, (size_t)rc * 4) == hipSuccess;
 	ok = ok && hipMalloc(&w->chain_logs, ((size_t)kChainLogCap + kTailLanes) * sizeof(ChainLog)) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
 	if (ok) {
@@ -252,6 +255,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		for (int i = 0; i < 5; i++)
 			ok = ok && hipMemsetAsync(w->owner[i], 0xff, nb * 8, stream) == hipSuccess;
 		ok = ok && hipMemsetAsync(w->cnt, 0, nb * 16, stream) == hipSuccess;
+		ok = ok && hipMemsetAsync(w->lost, 0, (size_t)rc * 4, stream) == hipSuccess;
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
 					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1), w->host_flag_dev);
@@ -399,13 +403,14 @@ static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipSt
 		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
 	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)tuning().mark_alone_blocks), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt);
+			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt,
+			tuning().plans ? w->undo : nullptr, w->lost);
 }
 
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
 		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1, hipEvent_t done_ev = nullptr,
-		long long hint = 0);
+		long long hint = 0, bool plans_ok = true);
 
 // Canonical-index passes of one call.  With a size hint from the caller a large batch runs
 // pass after pass (stream order = canonical order), Tuning::insert_chunk requests each; no
@@ -538,24 +543,59 @@ static unsigned tail_groups_for()
 	return (unsigned)(g < 1 ? 1 : g);
 }
 
+#if defined(MKV_EXP_EXTRA_LAUNCH) || defined(MKV_EXP_TAIL) || defined(MKV_EXP_ROUND1)
+__global__ __launch_bounds__(kTailThreads) void k_exp_trivial_tail(Ctl *ctl, DevGeom g, uint32_t *table,
+		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, const unsigned long long *owner1,
+		const unsigned long long *owner2, const unsigned long long *second, const uint4 *reqc, uint8_t *state, const Undo *undo,
+		const ChainLog *chain_logs, uint32_t *glist, int max_rounds, uint32_t lo_idx, uint32_t hi_idx, int first_chunk,
+		int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress, int dbg_path, int round2_hint,
+		uint32_t req_cap)
+{
+	__shared__ uint32_t big[43u * 256u];
+	if (ld_agent32(&ctl->any_tail) == 0x12345u)     // (never)
+		big[threadIdx.x] = g.hash_mask + lo_idx, glist[threadIdx.x] = big[(threadIdx.x * 7u) & 1023u];
+}
+
+__global__ void k_exp_trivial(Ctl *ctl)
+{
+	if (ld_agent32(&ctl->any_tail) == 0x12345u)
+		ctl->dbg[0] = 1u;
+}
+#endif
+
 // K2..K4
 // done_ev: an event that completes with the LAST kernel of the pass (the tail launch delivers its
 // end into it, hipExtLaunchKernelGGL): what a hipEventRecord behind the launch would give, without
 // the marker packet of its own (3 us between two kernels of a stream, tools/probes/event_probe.hip)
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
-		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev, long long hint)
+		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev, long long hint, bool plans_ok)
 {
 	// (hint: the caller's upper bound on the pass's requests, 0 = unknown)
+	// (plans_ok: nothing has written the table since this pass's mark pass read it -- false for the insert of a
+	// cycle whose mark pass rode in the search launch ahead of the cycle's deletes)
 	int tail_rounds = tuning().tail_rounds;
 	if (tail_rounds > kMaxTailRounds)
 		tail_rounds = kMaxTailRounds;
 	// what the rounds are told about the tuning: bit 2 -- every eviction chain left to the tail (tests);
 	// bit 3 -- no groups of duplicates; bit 5 -- no self-help of a bucket's second registrant
-	const int rhint = (tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32);
-	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl, g, table,
+	// bit 6 -- round 1 carries out the mark pass's plans (kPlanBit)
+	const int rhint = (tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32) |
+			(plans_ok && tuning().plans ? 64 : 0);
+#if defined(MKV_EXP_ROUND1) && MKV_EXP_ROUND1 == 1
+	if (0)      // launch-floor experiment (timing only): no round 1
+#elif defined(MKV_EXP_ROUND1) && MKV_EXP_ROUND1 == 2
+	hipLaunchKernelGGL(k_exp_trivial, dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl);
+	if (0)      // ... a launch of its grid with nothing to do in its place
+#endif
+	// (a pass announced with fewer requests than round 1's grid has lanes: as many work-groups as it takes --
+	// 208 instead of 512 are 0.5 us of a 52 K-request pass)
+	long long r1_blocks = tuning().round_blocks;
+	if (hint > 0 && (hint + 255) / 256 < r1_blocks)
+		r1_blocks = (hint + 255) / 256;
+	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4]);
+			rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost);
 	// round 2: inside the tail launch (k_tail's first phase), unless the pass is announced with more
 	// requests than that launch has lanes for in a few turns, or is a delete
 	// (word 3 of the tail kernel's flags, read without synchronising -- a pass late, which only costs time:
@@ -569,12 +609,32 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (!merged)
 		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4]);
+				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr);
+#if defined(MKV_EXP_TAIL) && MKV_EXP_TAIL == 1
+	if (0)      // launch-floor experiment (timing only): no tail launch at all
+#elif defined(MKV_EXP_TAIL) && MKV_EXP_TAIL == 2
+	hipLaunchKernelGGL(k_exp_trivial, dim3(1), dim3(64), 0, stream, w->ctl);
+	if (0)      // ... a one-wave launch in its place
+#endif
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
 			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3,
 			merged ? rhint : -1, (uint32_t)w->req_cap);
+#ifdef MKV_EXP_EXTRA_LAUNCH
+	// launch-floor experiment (timing only; tools/probes/README): one more launch behind the tail --
+	// 1: the tail's grid, LDS and argument list, nothing done; 2: one wave, no arguments to speak of;
+	// 3: round 1's grid
+	if (MKV_EXP_EXTRA_LAUNCH == 1)
+		hipLaunchKernelGGL(k_exp_trivial_tail, dim3(tail_groups_for<OP>()), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[2],
+				w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+				tail_rounds, lo, hi, first_chunk, last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min,
+				(uint32_t)tuning().grid_progress, tuning().debug_skip & 3, merged ? rhint : -1, (uint32_t)w->req_cap);
+	else if (MKV_EXP_EXTRA_LAUNCH == 2)
+		hipLaunchKernelGGL(k_exp_trivial, dim3(1), dim3(64), 0, stream, w->ctl);
+	else
+		hipLaunchKernelGGL(k_exp_trivial, dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl);
+#endif
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -701,11 +761,11 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
-				mkv::tuning().lazy_alt);
+				mkv::tuning().lazy_alt, mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
-				mkv::tuning().lazy_alt);
+				mkv::tuning().lazy_alt, mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -720,7 +780,10 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 	int rc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, 0, s, mkv::kCycleSalt);
 	if (rc != MKV_OK)
 		return rc;
-	if (joined && hipStreamWaitEvent(s, w->ev_join, 0) != hipSuccess)
+	// (joined bit 0: the mark pass ran on the side stream; bit 1: a delete of the cycle ran since the mark pass
+	// read the table -- the plans it made for chunk 0 do not hold)
+	const bool stale = (joined & 2) != 0;
+	if ((joined & 1) && hipStreamWaitEvent(s, w->ev_join, 0) != hipSuccess)
 		return MKV_EHIP;
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	mkv::ReqSrc src;
@@ -739,11 +802,13 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 		if (d.scheme == MKV_SCHEME_2CHOICE) {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint);
+			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint,
+					c > 0 || !stale);
 		} else {
 			if (c > 0)
 				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
-			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint);
+			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint,
+					c > 0 || !stale);
 		}
 		if (rc != MKV_OK)
 			return rc;
@@ -796,7 +861,7 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), dim3(search_blocks), dim3(256), s, tm ? tm->ev[2 * slot] : nullptr, tm ? tm->ev[2 * slot + 1] : nullptr,
 				recvbuf, slot_words, (uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks,
 				(mkv::Ctl *)nullptr, none, d, (unsigned long long *)nullptr, (unsigned long long *)nullptr, (uint4 *)nullptr,
-				(uint8_t *)nullptr, 0u, 0u, self_u, self_out, 0);
+				(uint8_t *)nullptr, 0u, 0u, self_u, self_out, 0, (mkv::Undo *)nullptr, (uint32_t *)nullptr);
 		if (done_event && hipEventRecord((hipEvent_t)done_event, s) != hipSuccess)
 			return MKV_EHIP;
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
@@ -829,11 +894,13 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 	if (cuckoo)
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
+				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt,
+				mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt);
+				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt,
+				mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
 		mkv::chunk_range(c, ck, &lo, &hi);
@@ -896,7 +963,7 @@ struct GatherBlocks {
 	int nw;
 };
 
-__global__ void k_gather_blocks(GatherBlocks a, const uint32_t **ins_ptrs, int *ins_cnts, const uint32_t **del_ptrs,
+__global__ __launch_bounds__(1024) void k_gather_blocks(GatherBlocks a, const uint32_t **ins_ptrs, int *ins_cnts, const uint32_t **del_ptrs,
 		int *del_cnts)
 {
 	const uint32_t t = threadIdx.x;
@@ -920,6 +987,15 @@ struct WorkerArrays {
 	int *ins_cnts = nullptr, *del_cnts = nullptr;
 };
 static WorkerArrays g_wk[64];
+
+static void free_worker_arrays(WorkerArrays *a)
+{
+	if (a->ins_ptrs) (void)hipFree(a->ins_ptrs);
+	if (a->ins_cnts) (void)hipFree(a->ins_cnts);
+	if (a->del_ptrs) (void)hipFree(a->del_ptrs);
+	if (a->del_cnts) (void)hipFree(a->del_cnts);
+	*a = WorkerArrays();
+}
 
 }  // namespace mkv
 
@@ -954,6 +1030,8 @@ extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const 
 		gb.ins_ptrs[w] = reinterpret_cast<const uint32_t *const *>(k.blk_input);
 		gb.ins_cnts[w] = k.blk_elem_num;
 		gb.ins_first[w] = nblk;
+		if (k.num_blks > mkv::kMaxBlocks)
+			return MKV_EINVAL;                 // (before it is summed: the sum must not wrap)
 		nblk += (uint32_t)k.num_blks;
 		gb.del_ptr[w] = reinterpret_cast<const uint32_t *>(k.delete_in);
 		gb.del_cnt[w] = (int)k.num_delete;
@@ -966,22 +1044,35 @@ extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const 
 	mkv::CallGuard call;                        // (the parts below are one turn)
 	mkv::WorkerArrays &wa = mkv::g_wk[dev];
 	if (!wa.ins_ptrs) {
+		// (all four or none: a call that finds the first pointer set takes the set for complete)
+		mkv::WorkerArrays na;
 		const size_t n = (size_t)mkv::kMaxBlocks;
-		if (hipMalloc(&wa.ins_ptrs, n * sizeof(void *)) != hipSuccess || hipMalloc(&wa.ins_cnts, n * sizeof(int)) != hipSuccess ||
-				hipMalloc(&wa.del_ptrs, mkv::kMaxWorkers * sizeof(void *)) != hipSuccess ||
-				hipMalloc(&wa.del_cnts, mkv::kMaxWorkers * sizeof(int)) != hipSuccess)
+		if (hipMalloc(&na.ins_ptrs, n * sizeof(void *)) != hipSuccess || hipMalloc(&na.ins_cnts, n * sizeof(int)) != hipSuccess ||
+				hipMalloc(&na.del_ptrs, mkv::kMaxWorkers * sizeof(void *)) != hipSuccess ||
+				hipMalloc(&na.del_cnts, mkv::kMaxWorkers * sizeof(int)) != hipSuccess) {
+			mkv::free_worker_arrays(&na);
 			return MKV_ENOMEM;
+		}
+		wa = na;
+	}
+	if (nblk || ndel) {
+		// A call that is refused enqueues nothing: whatever can refuse it comes before the search launch.
+		// (The gathered lists are one set per device: a call on another stream must not rewrite them under this
+		// device's last update -- the order the updates below would take anyway, taken now; and the update
+		// workspace is sized for what the cycle carries.)
+		const int orc = mkv::order_updates(s);
+		if (orc != MKV_OK)
+			return orc;
+		mkv::Workspace *w = nullptr;
+		mkv::ReqSrc probe = {};
+		probe.single_n = ndel;
+		const int wrc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(probe, 0), s);
+		if (wrc != MKV_OK)
+			return wrc;
 	}
 	if (blocks)
 		hipLaunchKernelGGL(mkv::k_search_multi, dim3(blocks), dim3(256), 0, s, ms, reinterpret_cast<const uint4 *>(table),
 				d.hash_mask, d.blk_mask);
-	if (nblk || ndel) {
-		// (the gathered lists are one set per device: a call on another stream must not rewrite them
-		// under this device's last update -- the order the updates below would take anyway, taken now)
-		const int orc = mkv::order_updates(s);
-		if (orc != MKV_OK)
-			return orc;
-	}
 	if (nblk || ndel)
 		hipLaunchKernelGGL(mkv::k_gather_blocks, dim3(1), dim3(1024), 0, s, gb, wa.ins_ptrs, wa.ins_cnts, wa.del_ptrs,
 				wa.del_cnts);
@@ -1077,6 +1168,8 @@ extern "C" void mkv_release_all(void)
 		delete kv.second;
 	}
 	mkv::g_ws.clear();
+	for (int dev = 0; dev < 64; dev++)
+		mkv::free_worker_arrays(&mkv::g_wk[dev]);
 	for (auto &kv : mkv::g_order)
 		if (kv.second.ev)
 			(void)hipEventDestroy(kv.second.ev);
@@ -1106,7 +1199,7 @@ extern "C" long long mkv_workspace_bytes(void)
 		if (!w || w->device != dev)
 			continue;
 		total += (long long)w->nbuckets * 56 +
-				(long long)w->req_cap * (1 + 16 + 16 + 4) +
+				(long long)w->req_cap * (1 + 16 + 16 + 4 + 4) +
 				(long long)(((size_t)mkv::kChainLogCap + mkv::kTailLanes) * sizeof(mkv::ChainLog)) + (long long)sizeof(mkv::Ctl);
 	}
 	return total;
@@ -1139,6 +1232,26 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 		return MKV_EHIP;
 	if (hipMemcpy(&h, w->ctl, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
 		return MKV_EHIP;
+	if (h.ep_pending) {
+		// the pass's tail launch found nothing to do and left without its epilogue (k_tail): the statistics
+		// are what the rounds counted -- nothing reached round 2 or the tail
+		memset(info, 0, sizeof(*info));
+		info->total = h.total;
+		for (int k = 0; k < mkv::kShards; k++) {
+			info->round1 += h.committed[0][k].n;
+			info->round2 += h.committed[1][k].n;
+			info->helped += h.committed[2][k].n;
+			info->losers += h.committed[3][k].n;
+		}
+		for (uint32_t k = 0; k < mkv::kTlGroups; k++) {
+			info->round1 += h.wg_rec[k].stat.y;
+			info->helped += h.wg_rec[k].stat.z;
+			info->losers += h.wg_rec[k].stat.w;
+		}
+		info->first_hard = h.first_hard;
+		info->chains = h.chain_ok;
+		return MKV_OK;
+	}
 	info->total = h.last.overflow ? 0xffffffffu : h.last.total;
 	info->round1 = h.last.round1;
 	info->round2 = h.last.round2;
@@ -1178,6 +1291,26 @@ extern "C" int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9]
 			hipMemcpy(out + 5, w->undo + idx, 16, hipMemcpyDeviceToHost) != hipSuccess)
 		return MKV_EHIP;
 	out[0] = st;
+	return MKV_OK;
+}
+
+// diagnostics (tools/loser_probe.py): the tags and cache entries of requests 0 .. n-1 after the last pass
+extern "C" int mkv_debug_dump(int cycle_insert, uint8_t *state_out, uint32_t *reqc_out, uint32_t n)
+{
+	int dev = 0;
+	if (!state_out || !reqc_out || hipGetDevice(&dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+		return MKV_EINVAL;
+	mkv::Workspace *w = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+		auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
+		if (it == mkv::g_ws.end() || !it->second->ctl || (int64_t)n > it->second->req_cap)
+			return MKV_EINVAL;
+		w = it->second;
+	}
+	if (hipMemcpy(state_out, w->state, n, hipMemcpyDeviceToHost) != hipSuccess ||
+			hipMemcpy(reqc_out, w->reqc, (size_t)n * 16, hipMemcpyDeviceToHost) != hipSuccess)
+		return MKV_EHIP;
 	return MKV_OK;
 }
 
@@ -1234,6 +1367,11 @@ extern "C" int mkv_debug_tail_phases(void *stream, int cycle_insert, float out_u
 		return MKV_EHIP;
 	for (int k = 0; k < 16; k++)
 		out_us[k] = (float)h.tail_phase[k] * 0.01f;
+	if (h.ep_pending)
+		// (the tail launch left at once, without its epilogue: no phase took any time; the rounds'
+		// diagnostic counts are still where they put them)
+		for (int k = 0; k < 16; k++)
+			out_us[k] = k < 8 ? 0.0f : (float)h.dbg[k - 8];
 	return MKV_OK;
 }
 #endif  // MKV_DIAGNOSTICS

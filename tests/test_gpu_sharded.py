@@ -158,6 +158,8 @@ def test_native_engine_one_rank_through_rccl(scheme, selfd, monkeypatch):
     # the own slot past the exchange, the peers' slots by grouped send / receive) and its variants
     (4, 0, 3, 1, 2, 1, 0), (8, 0, 3, 1, 2, 1, 0), (2, 1, 3, 1, 1, 1, 0), (8, 0, 2, 1, 1, 1, 0), (4, 0, 4, 1, 3, 1, 0),
     (4, 0, 3, 0, 2, 1, 0), (8, 0, 3, 0, 1, 1, 0), (8, 0, 2, 1, 2, 1, 0), (2, 0, 2, 1, 1, 1, 0), (4, 1, 2, 0, 1, 1, 0),
+    # more service streams asked for than buffer sets (the default of several ranks beside MKV_SHARD_LANES=2): clamped
+    (4, 0, 2, 1, 3, 1, 0),
     # the un-pack of a batch held back (a slow or skewed exchange) while the stream, not the host, paces the
     # local phases: the local phase of the batch B later writes this rank's own answers while that un-pack
     # has not read its batch's yet -- into the buffer of the other parity
