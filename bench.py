@@ -391,17 +391,37 @@ def main():
                 and args.overlap == "fused"):
             # side measurement, same table image, same batches, same clock: the reference's own call sequence
             # (src/mega_scheduler.c:393-502: memset, gpu_hash_search, gpu_hash_insert as three calls)
-            barrier()
-            t0 = time.perf_counter()
-            for b in timed:
-                engine.step_three_call(b, run_stream)
-            barrier()
-            dt = time.perf_counter() - t0
-            abi = {"value": round((1 << args.batch_log2) * args.steps / dt / 1e6, 1), "unit": "Mops",
-                   "us_per_step": round(dt / args.steps * 1e6, 2),
-                   "calls": "hipMemsetAsync(out) + mkv_search(KEEP_MISS) + mkv_insert_hinted per step (the entry points "
-                            "gpu_hash_search / gpu_hash_insert are thin calls of), same batches and table image as `value`"}
-            engine.restore_table(image)
+            # When the geometry is the one baked into the library's drop-in entry points (MEM_P 30, cuckoo, like the
+            # reference's header) the calls are the literal symbols an unchanged host links -- cudaMemsetAsync,
+            # gpu_hash_search, gpu_hash_insert -- eager, and once more with the library's deferred mode
+            # (mkv_set_defer: the calls are recorded and issued as one cycle by the flush a synchronisation makes).
+            literal = args.mem_p == 30 and args.scheme == "cuckoo"
+
+            def abi_run(step):
+                barrier()
+                t0 = time.perf_counter()
+                for b in timed:
+                    step(b, run_stream)
+                barrier()
+                dt = time.perf_counter() - t0
+                engine.restore_table(image)
+                return {"value": round((1 << args.batch_log2) * args.steps / dt / 1e6, 1), "unit": "Mops",
+                        "us_per_step": round(dt / args.steps * 1e6, 2)}
+            if literal:
+                abi = abi_run(engine.step_abi_literal)
+                abi["calls"] = ("cudaMemsetAsync(out) + gpu_hash_search + gpu_hash_insert per step: the drop-in symbols "
+                                "themselves, eager; same batches and table image as `value`")
+                engine.idx.lib.mkv_set_defer(1)
+                try:
+                    abi["deferred"] = abi_run(engine.step_abi_deferred)
+                finally:
+                    engine.idx.lib.mkv_set_defer(0)
+                abi["deferred"]["calls"] = ("the same three calls with the library's deferred mode on (MKV_DEFER=1) and an mkv_flush() "
+                                            "per step where the reference's scheduler synchronises: issued as one mkv_cycle")
+            else:
+                abi = abi_run(engine.step_three_call)
+                abi["calls"] = ("hipMemsetAsync(out) + mkv_search(KEEP_MISS) + mkv_insert_hinted per step (what gpu_hash_search / "
+                                "gpu_hash_insert call with their baked-in geometry), same batches and table image as `value`")
         elapsed_runs, t_submit = [], 0.0
         for rep in range(max(1, args.repeats)):
             if rep:
@@ -746,6 +766,21 @@ class SingleGpu:
         """the reference's sequence for one worker and cycle: memset(out), search, insert -- three calls"""
         self.idx.cycle(b["q"], b["out"], b.get("ptrs"), b.get("cnts"), len(b["keep"]) if "keep" in b else 0,
                        memset=True, overlap="none", stream=stream, insert_hint=b.get("n_set", 0))
+
+    def step_abi_literal(self, b, stream):
+        """the same through the drop-in symbols an unchanged host links (geometry baked in: MEM_P 30, cuckoo)"""
+        import ctypes
+        from megakv_amd.index import _dev_ptr, _stream_ptr
+        L = self.idx.lib
+        n = b["q"].shape[0]
+        L.cudaMemsetAsync(_dev_ptr(b["out"]), 0, ctypes.c_size_t(n * 8), _stream_ptr(stream))
+        L.gpu_hash_search(_dev_ptr(b["q"]), _dev_ptr(b["out"]), _dev_ptr(self.idx.table), n, 24576, 256, _stream_ptr(stream))
+        if "keep" in b:
+            L.gpu_hash_insert(_dev_ptr(self.idx.table), _dev_ptr(b["ptrs"]), _dev_ptr(b["cnts"]), len(b["keep"]), _stream_ptr(stream))
+
+    def step_abi_deferred(self, b, stream):
+        self.step_abi_literal(b, stream)
+        assert self.idx.lib.mkv_flush() == 0
 
     def prewarm(self, batches, ms, stream):
         """untimed read-only searches of the staged batches into a scratch buffer"""

@@ -11,7 +11,9 @@
  * It is the build's own counterpart of the caller (the reference's .c files
  * are not copied) and doubles as the link test of lib/libgpuhash.a:
  *   gcc -Iinclude examples/scheduler_cycle.c -Llib -lgpuhash -lamdhip64 -lstdc++
- * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0] [one call, default 0]
+ * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0] [one call, default 0] [digest, default 0]
+ *   digest = 1: a checksum of the whole table is printed at the end (runs with and without MKV_DEFER=1 --
+ *   the library's deferred mode, megakv_hip.h -- must print the same).
  *   mapped = 1: no staging copies; the library gets the pinned host buffers themselves
  *   (mapped into the device's address space), same calls, same checks.
  *   one call = 1: the cycle's library work -- every worker's search, delete and insert -- is ONE
@@ -78,6 +80,7 @@ int main(int argc, char **argv)
 	 * the requests and write the results over PCIe.  0: the reference's copies. */
 	int MAPPED = argc > 3 ? atoi(argv[3]) : 0;
 	int ONECALL = argc > 4 ? atoi(argv[4]) : 0;
+	int DIGEST = argc > 5 ? atoi(argv[5]) : 0;
 	mkv_geom_t geom = {MEM_P, IBLOCK_P,
 #if defined(HASH_2CHOICE)
 		MKV_SCHEME_2CHOICE, 0
@@ -308,5 +311,16 @@ int main(int argc, char **argv)
 			(unsigned long long)total_search, (unsigned long long)total_insert,
 			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors,
 			free_setup > free_end ? (double)(free_setup - free_end) / 1048576.0 : 0.0);
+	if (DIGEST) {
+		uint64_t *host = (uint64_t *)malloc(HT_SIZE), h = 1469598103934665603ULL;
+		size_t q;
+		if (!host)
+			return 3;
+		CUDA_SAFE_CALL(cudaMemcpy(host, table, HT_SIZE, cudaMemcpyDeviceToHost));
+		for (q = 0; q < HT_SIZE / 8; q++)
+			h = (h ^ host[q]) * 1099511628211ULL;
+		printf("table digest %016llx\n", (unsigned long long)h);
+		free(host);
+	}
 	return errors ? 1 : 0;
 }

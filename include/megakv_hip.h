@@ -101,6 +101,19 @@ typedef struct mkv_worker_s {
 } mkv_worker_t;
 int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const mkv_worker_t *workers, int nworkers, void *stream);
 
+/* Deferred launches for a host that keeps to the three drop-in entry points (MKV_DEFER=1 in the
+ * environment, or mkv_set_defer(1); off by default).  gpu_hash_search / gpu_hash_delete /
+ * gpu_hash_insert then only record their arguments, per stream; a device-to-host cudaMemcpyAsync issued
+ * through the library's cuda_runtime.h names behind recorded work is queued; cudaDeviceSynchronize,
+ * cudaStreamSynchronize, the synchronous copies and frees, and mkv_flush() issue everything recorded as
+ * ONE cycle -- mkv_cycle for one worker, mkv_cycle_workers for several (every search sees the table as
+ * the cycle found it, then the deletes, then the inserts, worker by worker in the order the workers'
+ * streams first appeared: reference src/mega_scheduler.c:393-504 issues exactly that sequence and
+ * synchronises once) -- and then the queued copies.  mkv_flush() does not wait; a host that synchronises
+ * with the HIP runtime's own calls instead of the cuda* names calls it first. */
+void mkv_set_defer(int on);
+int mkv_flush(void);
+
 /* Measurement aid: `slots` HIP event pairs; mkv_cycle(timer, slot) records pair
  * `slot` on the caller's stream around its search launch.  timer may be NULL. */
 void *mkv_timer_create(int slots);

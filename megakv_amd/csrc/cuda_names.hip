@@ -17,35 +17,78 @@ static hipMemcpyKind kind_of(enum cudaMemcpyKind k)
 	}
 }
 
+// The deferred mode of the drop-in entry points (mkv_abi.hip, MKV_DEFER=1): what the three entry points have
+// recorded is issued by whatever makes the host wait, and a device-to-host copy behind recorded work waits
+// its turn.  Without the mode mkv_flush() finds nothing and mkv_defer_copy() says "now".
+extern "C" int mkv_flush(void);
+extern "C" int mkv_defer_copy(void *dst, const void *src, size_t n, void *stream);
+extern "C" int mkv_defer_memset(void *p, int value, size_t n, void *stream);
+extern "C" void mkv_defer_touch(void);
+
+static cudaError_t flushed(void)
+{
+	return mkv_flush() == 0 ? (cudaError_t)hipSuccess : (cudaError_t)hipErrorLaunchFailure;
+}
+
 extern "C" {
 
 cudaError_t cudaMalloc(void **p, size_t n) { return (cudaError_t)hipMalloc(p, n); }
-cudaError_t cudaFree(void *p) { return (cudaError_t)hipFree(p); }
+cudaError_t cudaFree(void *p)
+{
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipFree(p);
+}
 cudaError_t cudaHostAlloc(void **p, size_t n, unsigned int flags)
 {
 	return (cudaError_t)hipHostMalloc(p, n, flags);
 }
-cudaError_t cudaFreeHost(void *p) { return (cudaError_t)hipHostFree(p); }
-cudaError_t cudaMemset(void *p, int v, size_t n) { return (cudaError_t)hipMemset(p, v, n); }
+cudaError_t cudaFreeHost(void *p)
+{
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipHostFree(p);
+}
+cudaError_t cudaMemset(void *p, int v, size_t n)
+{
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipMemset(p, v, n);
+}
 cudaError_t cudaMemsetAsync(void *p, int v, size_t n, cudaStream_t s)
 {
+	if (mkv_defer_memset(p, v, n, (void *)s))
+		return (cudaError_t)hipSuccess;     // (held: the search that follows may make it superfluous, mkv_abi.hip)
 	return (cudaError_t)hipMemsetAsync(p, v, n, (hipStream_t)s);
 }
 cudaError_t cudaMemcpy(void *d, const void *s, size_t n, enum cudaMemcpyKind k)
 {
-	return (cudaError_t)hipMemcpy(d, s, n, kind_of(k));
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipMemcpy(d, s, n, kind_of(k));
 }
 cudaError_t cudaMemcpyAsync(void *d, const void *s, size_t n, enum cudaMemcpyKind k, cudaStream_t st)
 {
+	if (k == cudaMemcpyDeviceToHost) {
+		if (mkv_defer_copy(d, s, n, (void *)st))
+			return (cudaError_t)hipSuccess;
+	} else {
+		mkv_defer_touch();
+	}
 	return (cudaError_t)hipMemcpyAsync(d, s, n, kind_of(k), (hipStream_t)st);
 }
 cudaError_t cudaStreamCreate(cudaStream_t *s) { return (cudaError_t)hipStreamCreate((hipStream_t *)s); }
-cudaError_t cudaStreamDestroy(cudaStream_t s) { return (cudaError_t)hipStreamDestroy((hipStream_t)s); }
+cudaError_t cudaStreamDestroy(cudaStream_t s)
+{
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipStreamDestroy((hipStream_t)s);
+}
 cudaError_t cudaStreamSynchronize(cudaStream_t s)
 {
-	return (cudaError_t)hipStreamSynchronize((hipStream_t)s);
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipStreamSynchronize((hipStream_t)s);
 }
-cudaError_t cudaDeviceSynchronize(void) { return (cudaError_t)hipDeviceSynchronize(); }
+cudaError_t cudaDeviceSynchronize(void)
+{
+	const cudaError_t f = flushed();
+	return f ? f : (cudaError_t)hipDeviceSynchronize();
+}
 cudaError_t cudaGetLastError(void) { return (cudaError_t)hipGetLastError(); }
 cudaError_t cudaMemGetInfo(size_t *f, size_t *t) { return (cudaError_t)hipMemGetInfo(f, t); }
 const char *cudaGetErrorString(cudaError_t e) { return hipGetErrorString((hipError_t)e); }

@@ -4,6 +4,10 @@
 #include <assert.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <string.h>
+
+#include <mutex>
+#include <vector>
 
 #include <hip/hip_runtime.h>
 
@@ -30,6 +34,221 @@ static void die_on(int rc, const char *what)
 	}
 }
 
+// ---- deferred launches: the fused cycle for a host that keeps to the three entry points ---------------
+// The reference's scheduler issues, per worker and stream, memset + gpu_hash_search + a copy of the
+// results, then gpu_hash_delete, then gpu_hash_insert, and synchronises the device ONCE per cycle
+// (src/mega_scheduler.c:393-504).  Launched as they come that is three to nine small launches per worker,
+// the updates of all workers serialised -- 188 Mops device-resident with 16 workers at the scheduler's batch
+// sizes, where ONE mkv_cycle_workers call for the whole cycle reaches 1 728.  With
+// MKV_DEFER=1 in the environment (or mkv_set_defer(1)) the three entry points only RECORD their arguments,
+// per stream; device-to-host copies issued through the library's cudaMemcpyAsync on a stream with recorded
+// work are queued behind it; and whatever makes the host wait -- cudaDeviceSynchronize,
+// cudaStreamSynchronize, a synchronous copy, cudaFree -- or mkv_flush() issues everything recorded as one
+// cycle: one worker -> mkv_cycle on its stream (search and mark pass in one launch); several -> the streams'
+// earlier work (the host's request copies) is waited for, then ONE mkv_cycle_workers call on the first
+// worker's stream -- every search sees the table as the cycle found it, then all deletes, then all inserts,
+// worker by worker in the order their streams first appeared: the order the library gives the eager calls'
+// updates anyway (they are serialised in issue order) -- then the queued copies.  Host-to-device copies and
+// memsets go out at once, as they do without the mode.  Off by default: the eager calls are the reference's
+// semantics to the letter (a search on one stream may see another stream's earlier update, as there).
+namespace {
+
+struct DeferredCopy {
+	void *dst;
+	const void *src;
+	size_t n;
+};
+
+struct DeferredWorker {
+	hipStream_t stream;
+	bucket_t *table;
+	mkv_worker_t w;
+	bool has_search, has_delete, has_insert;
+};
+
+std::mutex g_defer_mutex;
+int g_defer_mode = -1;                     // -1: not looked up yet
+std::vector<DeferredWorker> g_defer;
+std::vector<DeferredCopy> g_defer_copies;
+
+// The scheduler clears a worker's result buffer right before its search (cudaMemsetAsync, src/mega_scheduler.c:
+// 406-407): the cycle's search writes every result, zeros for misses, so that launch is for nothing.  A memset to
+// zero is HELD until the next call of the library says what it is for: a gpu_hash_search on the same stream into
+// exactly that buffer drops it, anything else issues it first.
+struct HeldMemset {
+	void *p;
+	size_t n;
+	hipStream_t stream;
+	bool held;
+};
+HeldMemset g_held = {nullptr, 0, nullptr, false};
+
+int release_memset_locked()
+{
+	if (!g_held.held)
+		return MKV_OK;
+	g_held.held = false;
+	return hipMemsetAsync(g_held.p, 0, g_held.n, g_held.stream) == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+bool defer_on_locked()
+{
+	if (g_defer_mode < 0) {
+		const char *e = getenv("MKV_DEFER");
+		g_defer_mode = e && atoi(e) != 0 ? 1 : 0;
+	}
+	return g_defer_mode == 1;
+}
+
+// the entry of `stream` that has no call of this kind yet (a second search on a stream before the
+// cycle is issued starts a new entry: a later worker)
+DeferredWorker *defer_slot(hipStream_t stream, bucket_t *table, int kind)
+{
+	for (auto it = g_defer.rbegin(); it != g_defer.rend(); ++it) {
+		if (it->stream != stream)
+			continue;
+		const bool taken = kind == 0 ? (it->has_search || it->has_delete || it->has_insert) :
+				kind == 1 ? (it->has_delete || it->has_insert) : it->has_insert;
+		// (a worker's calls come search, delete, insert: one out of that order belongs to a new entry)
+		if (!taken && it->table == table)
+			return &*it;
+		break;
+	}
+	DeferredWorker d;
+	memset(&d, 0, sizeof(d));
+	d.stream = stream;
+	d.table = table;
+	g_defer.push_back(d);
+	return &g_defer.back();
+}
+
+// the queued device-to-host copies go out behind the cycle's SEARCH, ahead of its deletes and inserts -- where the
+// host issued them (mkv_cycle / mkv_cycle_workers call this hook once the search launch is enqueued)
+thread_local hipStream_t t_copy_stream = nullptr;
+thread_local bool t_copies_pending = false;
+thread_local int t_copy_rc = MKV_OK;
+
+void issue_deferred_copies(hipStream_t s)
+{
+	if (!t_copies_pending)
+		return;
+	t_copies_pending = false;
+	for (const DeferredCopy &c : g_defer_copies)
+		if (hipMemcpyAsync(c.dst, c.src, c.n, hipMemcpyDeviceToHost, s) != hipSuccess)
+			t_copy_rc = MKV_EHIP;
+	g_defer_copies.clear();
+}
+
+int defer_flush_locked()
+{
+	int rc = release_memset_locked();
+	if (g_defer.empty() && g_defer_copies.empty())
+		return rc;
+	hipStream_t s0 = g_defer.empty() ? nullptr : g_defer[0].stream;
+	size_t i = 0;
+	if (g_defer.size() > 1) {
+		// What the host queued on the workers' own streams (request copies, memsets) is done first: ONE wait for
+		// the device, not one per stream (a blocking wait is tens of microseconds of wake-up each -- sixteen of
+		// them per cycle were a quarter of a staged cycle's time)
+		if (hipDeviceSynchronize() != hipSuccess)
+			rc = MKV_EHIP;
+	}
+	// (one worker: the copies go out behind its search, where the host issued them; several: behind the whole
+	// cycle -- sixteen copies between the search and the updates on the one stream hold the updates up)
+	t_copies_pending = !g_defer_copies.empty() && g_defer.size() == 1;
+	t_copy_rc = MKV_OK;
+	t_copy_stream = s0;
+	while (i < g_defer.size() && rc == MKV_OK) {
+		// a run of entries on one table, within what one call takes
+		size_t j = i;
+		int blocks = 0;
+		while (j < g_defer.size() && g_defer[j].table == g_defer[i].table && j - i < 32 &&
+				blocks + g_defer[j].w.num_blks <= 1024) {
+			blocks += g_defer[j].w.num_blks;
+			j++;
+		}
+		if (j == i)
+			j = i + 1;
+		if (j - i == 1 && g_defer.size() == 1) {
+			const DeferredWorker &d = g_defer[i];
+			rc = mkv_cycle(&kGeom, d.table, d.w.search_in, d.w.search_out, d.w.num_search, d.w.delete_in, d.w.num_delete,
+					d.w.blk_input, d.w.blk_elem_num, d.w.num_blks, 0, 0u, (void *)d.stream, nullptr, 0);
+		} else {
+			mkv_worker_t ws[32];
+			for (size_t k = i; k < j; k++)
+				ws[k - i] = g_defer[k].w;
+			if (rc == MKV_OK)
+				rc = mkv_cycle_workers(&kGeom, g_defer[i].table, ws, (int)(j - i), (void *)s0);
+		}
+		i = j;
+	}
+	// (copies the cycle's search did not take with it: no search in the cycle, or no cycle at all)
+	t_copies_pending = !g_defer_copies.empty();
+	issue_deferred_copies(s0);
+	if (rc == MKV_OK)
+		rc = t_copy_rc;
+	g_defer.clear();
+	g_defer_copies.clear();
+	return rc;
+}
+
+}  // namespace
+
+// called by mkv_cycle / mkv_cycle_workers behind their search launch (nothing to do outside a deferred flush)
+extern "C" void mkv_after_search(void *stream)
+{
+	if (t_copies_pending)
+		issue_deferred_copies((hipStream_t)stream);
+}
+
+extern "C" void mkv_set_defer(int on)
+{
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	if (!on)
+		die_on(defer_flush_locked(), "mkv_set_defer/flush");
+	g_defer_mode = on ? 1 : 0;
+}
+
+// issues whatever the deferred mode has recorded (no wait); MKV_OK when there is nothing
+extern "C" int mkv_flush(void)
+{
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	return defer_flush_locked();
+}
+
+// for the library's cudaMemsetAsync: 1 = held back (see HeldMemset), 0 = issue it now
+extern "C" int mkv_defer_memset(void *p, int value, size_t n, void *stream)
+{
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	if (!defer_on_locked())
+		return 0;
+	die_on(release_memset_locked(), "cudaMemsetAsync/held memset");
+	if (value != 0 || !p || !n)
+		return 0;
+	g_held = HeldMemset{p, n, (hipStream_t)stream, true};
+	return 1;
+}
+
+// ... and for its other asynchronous calls: whatever is held goes out first
+extern "C" void mkv_defer_touch(void)
+{
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	die_on(release_memset_locked(), "held memset");
+}
+
+// for the library's cudaMemcpyAsync: a device-to-host copy on a stream with recorded work waits its turn
+// (1: queued; 0: issue it now)
+extern "C" int mkv_defer_copy(void *dst, const void *src, size_t n, void *stream)
+{
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	die_on(release_memset_locked(), "held memset");
+	if (g_defer.empty())
+		return 0;
+	(void)stream;           // (any stream: the recorded cycle may write what the copy reads whatever stream it names)
+	g_defer_copies.push_back(DeferredCopy{dst, src, n});
+	return 1;
+}
+
 extern "C" void gpu_hash_search(selem_t *in, loc_t *out, bucket_t *hash_table, int num_elem,
 		int num_thread, int threads_per_blk, cudaStream_t stream)
 {
@@ -39,6 +258,23 @@ extern "C" void gpu_hash_search(selem_t *in, loc_t *out, bucket_t *hash_table, i
 	assert(threads_per_blk <= 1024);
 	(void)num_thread;
 	(void)threads_per_blk;
+	{
+		std::lock_guard<std::mutex> lock(g_defer_mutex);
+		if (defer_on_locked()) {
+			if (g_held.held && g_held.p == (void *)out && g_held.stream == (hipStream_t)stream && num_elem > 0 &&
+					g_held.n == (size_t)num_elem * 2u * sizeof(loc_t))
+				g_held.held = false;            // (the cycle's search writes the zeros itself)
+			die_on(release_memset_locked(), "gpu_hash_search/held memset");
+			if (num_elem <= 0)
+				return;
+			DeferredWorker *d = defer_slot((hipStream_t)stream, hash_table, 0);
+			d->w.search_in = in;
+			d->w.search_out = out;
+			d->w.num_search = num_elem;
+			d->has_search = true;
+			return;
+		}
+	}
 	die_on(mkv_search(&kGeom, in, out, hash_table, num_elem, MKV_SEARCH_KEEP_MISS, (void *)stream),
 			"gpu_hash_search");
 }
@@ -47,6 +283,18 @@ extern "C" void gpu_hash_insert(bucket_t *hash_table, ielem_t **blk_input, int *
 		int num_blks, cudaStream_t stream)
 {
 	assert(ELEM_NUM_P < 5 && ELEM_NUM_P > 0);   // gpu_hash.cu:535
+	{
+		std::lock_guard<std::mutex> lock(g_defer_mutex);
+		die_on(release_memset_locked(), "gpu_hash_insert/held memset");
+		if (defer_on_locked() && num_blks > 0 && num_blks <= 1024) {
+			DeferredWorker *d = defer_slot((hipStream_t)stream, hash_table, 2);
+			d->w.blk_input = blk_input;
+			d->w.blk_elem_num = blk_elem_num;
+			d->w.num_blks = num_blks;
+			d->has_insert = true;
+			return;
+		}
+	}
 	die_on(mkv_insert(&kGeom, hash_table, blk_input, blk_elem_num, num_blks, (void *)stream),
 			"gpu_hash_insert");
 }
@@ -58,6 +306,19 @@ extern "C" void gpu_hash_delete(delem_t *in, bucket_t *hash_table, int num_elem,
 	assert(threads_per_blk <= 1024);
 	(void)num_thread;
 	(void)threads_per_blk;
+	{
+		std::lock_guard<std::mutex> lock(g_defer_mutex);
+		die_on(release_memset_locked(), "gpu_hash_delete/held memset");
+		if (defer_on_locked()) {
+			if (num_elem <= 0)
+				return;
+			DeferredWorker *d = defer_slot((hipStream_t)stream, hash_table, 1);
+			d->w.delete_in = in;
+			d->w.num_delete = num_elem;
+			d->has_delete = true;
+			return;
+		}
+	}
 	die_on(mkv_delete(&kGeom, in, hash_table, num_elem, (void *)stream), "gpu_hash_delete");
 }
 
@@ -67,6 +328,7 @@ extern "C" void gpu_delete_insert(bucket_t *hash_table, delem_t *delete_in, uint
 {
 	(void)num_delete_thread;
 	(void)threads_per_blk;
+	die_on(mkv_flush(), "gpu_delete_insert/flush");     // (issued as it comes, behind whatever is recorded)
 	die_on(mkv_delete(&kGeom, delete_in, hash_table, num_delete_job, (void *)stream),
 			"gpu_delete_insert/delete");
 	die_on(mkv_insert(&kGeom, hash_table, insert_blk_input, insert_blk_elem_num, num_insert_blks,
@@ -114,6 +376,7 @@ extern "C" void mkv_timer_destroy(void *timer)
 }
 
 extern "C" int mkv_tuning_is_default_search(void);
+extern "C" void mkv_after_search(void *stream);
 extern "C" void mkv_call_lock(void);
 extern "C" void mkv_call_unlock(void);
 extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *table, ielem_t **blk_input,
@@ -180,6 +443,7 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 		if (rc != MKV_OK)
 			return rc;
 	}
+	mkv_after_search(stream);
 	if (num_delete > 0) {
 		rc = mkv_delete(geom, delete_in, table, num_delete, stream);
 		if (rc != MKV_OK)

@@ -28,7 +28,6 @@ constexpr int kViolCap = 128;       // order violations recorded per turn of the
 constexpr uint8_t ST_SELECT = 0x80; // tail, transient: flag on a commit tag -- selected for roll-back
 constexpr int kTailThreads = 1024;  // lanes per work-group of the tail launch (its helpers are force-inlined: the
                                     // launch stays free of scratch memory and calls)
-constexpr uint32_t kLateSticky = 16; // calls for which a call whose chains ran late counts as "chains lately" (diagnostics)
 constexpr int kDeferCap = 768;           // k_round: requests a work-group may hold back for its second phase
 constexpr uint32_t kMergeLosersMax = 16;   // round 2 runs inside the tail launch while round 1 leaves it at most this many requests
                                           // (with work to do it costs what its own launch costs, and a little more: 20.7 against 19.0 us
@@ -165,7 +164,6 @@ struct Ctl {
 	uint32_t tflags;                 // tail: bit 0 = a violation was recorded
 	uint32_t violations;             // order violations handled this call (each rolls back a region's later commits)
 	uint32_t hard_tail;              // hard requests the grid-wide rounds left to the tail this call
-	uint32_t late_score;             // > 0: chains ran late in one of the last kLateSticky calls (persists across calls)
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t hf_last[2];             // what the host-mapped flag words hold (they are written only when they change)
 	uint32_t hf_losers;              // ... and word 3: round 1 left many requests to round 2 in the last pass

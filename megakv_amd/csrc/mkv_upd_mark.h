@@ -76,8 +76,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		ctl->overflow = over ? 1u : 0u;
 		// The tail launch of this pass leaves at once if the rounds leave it nothing -- unless its epilogue has
 		// something to tell the host (a dropped batch to count, a flag word that may have to change back, round
-		// stamps running low) or a score to run down
-		ctl->force_tail = (over || ctl->hf_last[0] != 0u || ctl->hf_last[1] != 0u || ctl->hf_losers != 0u || ctl->late_score != 0u ||
+		// stamps running low)
+		ctl->force_tail = (over || ctl->hf_last[0] != 0u || ctl->hf_last[1] != 0u || ctl->hf_losers != 0u ||
 				stamp > kStampMax - kStampReserve) ? 1u : 0u;
 		if (ep_pending) {
 			// ... in which case what the epilogue would have reset is reset here

@@ -1699,29 +1699,26 @@ __device__ __forceinline__ void truncate_groups(uint32_t *table, uint8_t *state,
 template <bool IDLE>     // (IDLE: the launch found nothing to do -- no phase has taken any time)
 __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ticks, uint32_t rounds_total,
 		uint32_t total_all, uint32_t par, uint32_t serial, uint32_t undone, uint32_t viols, int first_chunk, int last_chunk,
-		uint32_t *host_flag)
+		uint32_t *host_flag, const uint32_t *rec_sums)
 {
+	// (rec_sums: round 1's per-work-group records summed -- commits, of those by self-help, losers: Ctl::wg_rec)
 	const uint32_t t = threadIdx.x;
 	if (t < 64) {
 		// statistics shards: one wave sums them
 		uint32_t c1 = ctl->committed[0][t].n, c2 = ctl->committed[1][t].n;      // (cleared by the next mark pass)
-		uint32_t w3 = 0, w4 = 0;
-		for (uint32_t q = t; q < kTlGroups; q += 64u) {      // (round 1's records, one per work-group: Ctl::wg_rec)
-			const uint4 ws = ctl->wg_rec[q].stat;
-			c1 += ws.y;
-			w3 += ws.z;
-			w4 += ws.w;
-		}
 		for (int off = 32; off > 0; off >>= 1) {
 			c1 += __shfl_down(c1, off);
 			c2 += __shfl_down(c2, off);
 		}
-		uint32_t c3 = ctl->committed[2][t].n + w3, c4 = ctl->committed[3][t].n + w4;
+		uint32_t c3 = ctl->committed[2][t].n, c4 = ctl->committed[3][t].n;
 		for (int off = 32; off > 0; off >>= 1) {
 			c3 += __shfl_down(c3, off);
 			c4 += __shfl_down(c4, off);
 		}
 		if (t == 0) {
+			c1 += rec_sums[0];
+			c3 += rec_sums[1];
+			c4 += rec_sums[2];
 			ctl->last.round1 = (first_chunk ? 0u : ctl->last.round1) + c1;
 			ctl->last.round2 = (first_chunk ? 0u : ctl->last.round2) + c2;
 			ctl->last.helped = (first_chunk ? 0u : ctl->last.helped) + c3;
@@ -1761,9 +1758,6 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 		// are nearly used up -- the host clears the reservation tables before a later call
 		// (ensure_ws); word 2: batches that exceeded the workspace and were dropped, so far.  Only
 		// this kernel writes the words; the host only reads them.
-		if (last_chunk)
-			ctl->late_score = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? kLateSticky :
-					(ctl->late_score ? ctl->late_score - 1u : 0u);
 		if (last_chunk && host_flag) {
 			// (a store to host memory makes the end of this kernel wait for the PCIe write: 4 us between
 			// this launch and the next search, every step -- the words are written when they change)
@@ -1850,9 +1844,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// statistics meanwhile works them out from the rounds' counters (mkv_last_update_info_ex).  An extra launch of
 	// this grid with nothing to do costs 1.3 - 1.5 us in this chain (profiles/r05_launch_floor.txt); the epilogue --
 	// five dependent round trips on one lane -- made it 4.1 - 4.8.
-	// (round 1's record for this lane, should round 2 have anything to do: asked for beside the flags)
+	// (round 1's record for this lane -- what it counted, the first of what it left to round 2: asked for beside the
+	// flags, one round trip for both)
 	uint4 rec_stat = make_uint4(0u, 0u, 0u, 0u), rec_ll = rec_stat;
-	if (round2_hint >= 0 && OP != OP_DELETE && t < kTlGroups && first_chunk && last_chunk) {
+	if (t < kTlGroups) {
 		const uint4 *rp = reinterpret_cast<const uint4 *>(&ctl->wg_rec[t]);
 		rec_stat = rp[0];
 		rec_ll = rp[1];
@@ -1867,14 +1862,32 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// bucket, a request behind one that holds the bucket as its alternate, a second registrant of a full bucket) and
 	// listed them (Ctl::ll): this work-group runs round 2 over the list and goes on alone -- no scan of the pass's
 	// tags by 32 work-groups, no meeting behind it; the others read the same records, decide alike and leave.
-	__shared__ uint32_t s_few_n, s_few_bad, s_few[kFewLosers];
+	__shared__ uint32_t s_few_n, s_few_bad, s_few[kFewLosers], s_rec[3];
 	bool few = false;
-	if (round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u && first_chunk && last_chunk) {
-		if (t == 0) {
-			s_few_n = 0u;
-			s_few_bad = 0u;
+	if (t == 0) {
+		s_few_n = 0u;
+		s_few_bad = 0u;
+		s_rec[0] = s_rec[1] = s_rec[2] = 0u;
+	}
+	__syncthreads();
+	{
+		// the records' sums (lanes beyond the records hold zeros)
+		uint32_t a = rec_stat.y, b = rec_stat.z, c = rec_stat.w;
+		if (__ballot(a | b | c)) {
+			for (int off = 32; off > 0; off >>= 1) {
+				a += __shfl_down(a, off);
+				b += __shfl_down(b, off);
+				c += __shfl_down(c, off);
+			}
+			if ((t & 63u) == 0u) {
+				if (a) atomicAdd(&s_rec[0], a);
+				if (b) atomicAdd(&s_rec[1], b);
+				if (c) atomicAdd(&s_rec[2], c);
+			}
 		}
-		__syncthreads();
+	}
+	const bool try_few = round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u && first_chunk && last_chunk;
+	if (try_few) {
 		if (t < kTlGroups) {
 			const uint32_t nl = rec_stat.w;
 			if (nl > kLlPer) {
@@ -1891,9 +1904,9 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				}
 			}
 		}
-		__syncthreads();
-		few = s_few_bad == 0u && s_few_n != 0u;      // (none listed: round 1 ran on more work-groups than it has records for)
 	}
+	__syncthreads();
+	few = try_few && s_few_bad == 0u && s_few_n != 0u;      // (none listed: round 1 ran on more work-groups than it has records for)
 	if (few) {
 		if (wg != 0)
 			return;
@@ -1922,7 +1935,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	const uint32_t p_any_tail = ld_agent32(&ctl->any_tail);
 	if (p_any_tail == 0u) {
 		if (wg == 0)
-			tail_epilogue<true>(ctl, nullptr, 0u, total_all, 0u, 0u, 0u, 0u, first_chunk, last_chunk, host_flag);
+			tail_epilogue<true>(ctl, nullptr, 0u, total_all, 0u, 0u, 0u, 0u, first_chunk, last_chunk, host_flag, s_rec);
 		return;
 	}
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
@@ -1973,12 +1986,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// counters (final: only the kernels before this one in the stream change them).
 	if (t < 64u) {
 		uint32_t c = ctl->committed[0][t].n + ctl->committed[1][t].n;
-		for (uint32_t q = t; q < kTlGroups; q += 64u)
-			c += ctl->wg_rec[q].stat.y;
 		for (int off = 32; off > 0; off >>= 1)
 			c += __shfl_down(c, off);
 		if (t == 0)
-			s_done12 = c;
+			s_done12 = c + s_rec[0];
 	}
 	__syncthreads();
 	const uint32_t span = total > lo_idx ? total - lo_idx : 0u;
@@ -2256,7 +2267,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	}
 	__syncthreads();
 	tail_epilogue<false>(ctl, phase_ticks, rounds_total, total_all, s_par, s_serial, s_undone, s_viols, first_chunk, last_chunk,
-			host_flag);
+			host_flag, s_rec);
 }
 
 __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *host_flag)
@@ -2285,7 +2296,6 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->any_hard = 0;
 		ctl->violations = 0;
 		ctl->hard_tail = 0;
-		ctl->late_score = 0;
 		ctl->hf_last[0] = ctl->hf_last[1] = 0;
 		ctl->hf_losers = 0;
 		for (int k = 0; k < 8; k++)

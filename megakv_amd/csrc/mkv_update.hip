@@ -590,8 +590,11 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 #endif
 	// (a pass announced with fewer requests than round 1's grid has lanes: as many work-groups as it takes --
 	// 208 instead of 512 are 0.5 us of a 52 K-request pass)
+	// (not while round 1 has been leaving round 2 a lot, or chains have been running late: what a work-group
+	// holds back for its second phase is then the round's critical path, and more work-groups share it)
 	long long r1_blocks = tuning().round_blocks;
-	if (hint > 0 && (hint + 255) / 256 < r1_blocks)
+	const bool busy = (w->host_flag && w->host_flag[3]) || w->barrier_score > 0;
+	if (hint > 0 && !busy && (hint + 255) / 256 < r1_blocks)
 		r1_blocks = (hint + 255) / 256;
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
@@ -999,6 +1002,8 @@ static void free_worker_arrays(WorkerArrays *a)
 
 }  // namespace mkv
 
+extern "C" void mkv_after_search(void *stream);
+
 extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const mkv_worker_t *workers, int nworkers,
 		void *stream)
 {
@@ -1073,6 +1078,7 @@ extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const 
 	if (blocks)
 		hipLaunchKernelGGL(mkv::k_search_multi, dim3(blocks), dim3(256), 0, s, ms, reinterpret_cast<const uint4 *>(table),
 				d.hash_mask, d.blk_mask);
+	mkv_after_search(s);        // (the deferred mode's queued result copies: mkv_abi.hip)
 	if (nblk || ndel)
 		hipLaunchKernelGGL(mkv::k_gather_blocks, dim3(1), dim3(1024), 0, s, gb, wa.ins_ptrs, wa.ins_cnts, wa.del_ptrs,
 				wa.del_cnts);

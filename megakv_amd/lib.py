@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_parse_scratch_bytes", "mkv_parse_packets",
-    "mkv_forget_stream", "mkv_dropped_batches", "mkv_workspace_bytes", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
+    "mkv_set_defer", "mkv_flush", "mkv_forget_stream", "mkv_dropped_batches", "mkv_workspace_bytes", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -98,6 +98,12 @@ def _load(LIB_PATH, diagnostics):
     L.mkv_cycle_workers.argtypes = [G, P, ctypes.POINTER(MkvWorker), INT, P]
     L.mkv_insert_hinted.restype = INT
     L.mkv_insert_hinted.argtypes = [G, P, P, P, INT, ctypes.c_longlong, P]
+    L.cudaMemsetAsync.restype = INT
+    L.cudaMemsetAsync.argtypes = [P, INT, ctypes.c_size_t, P]
+    L.mkv_set_defer.restype = None
+    L.mkv_set_defer.argtypes = [INT]
+    L.mkv_flush.restype = INT
+    L.mkv_flush.argtypes = []
     L.mkv_dropped_batches.restype = ctypes.c_ulonglong
     L.mkv_dropped_batches.argtypes = []
     L.mkv_workspace_bytes.restype = ctypes.c_longlong

@@ -102,6 +102,31 @@ def test_plain_c_scheduler_driver_runs_clean():
         assert r.returncode == 0 and "errors 0" in r.stdout and "one library call" in r.stdout, r.stdout + r.stderr
 
 
+@pytest.mark.parametrize("workers,mapped", [("1", "0"), ("16", "0"), ("16", "1"), ("4", "0")])
+def test_deferred_launch_mode_gives_an_unchanged_host_the_fused_cycle(workers, mapped):
+    """MKV_DEFER=1: the three drop-in entry points only record, cudaDeviceSynchronize issues the whole
+    cycle as one call (mkv_abi.hip).  The same plain-C host, the same call sequence (mode 0 of
+    examples/scheduler_cycle.c: per worker and stream copy + memset + gpu_hash_search + copy back,
+    gpu_hash_delete, gpu_hash_insert, one synchronisation per cycle, reference
+    src/mega_scheduler.c:393-504): 0 errors against its own model and the SAME table, bit for bit, as
+    the eager run."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "megakv_amd", "_lib", "scheduler_cycle")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    digests, rates = [], []
+    for defer in ("0", "1"):
+        env = dict(os.environ, MKV_DEFER=defer)
+        r = subprocess.run([exe, "12", workers, mapped, "0", "1"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "errors 0" in r.stdout, r.stdout + r.stderr
+        digests.append(re.search(r"table digest ([0-9a-f]+)", r.stdout).group(1))
+        rates.append(float(re.search(r"-> ([0-9.]+) Mops", r.stdout).group(1)))
+    assert digests[0] == digests[1], (digests, rates)
+    print(f"workers {workers} mapped {mapped}: eager {rates[0]} Mops, deferred {rates[1]} Mops")
+
+
 def test_cycle_captured_into_a_hipgraph_through_the_c_api():
     """examples/graph_cycle.c (gcc, HIP's C header): one mkv_cycle captured with
     hipStreamBeginCapture, replayed, against the same cycles issued eagerly from the same start:

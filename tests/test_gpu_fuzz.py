@@ -33,6 +33,7 @@ def _defaults():
         L.mkv_set_tuning(b"round_blocks", 512)
         L.mkv_set_tuning(b"self_help", 1)
         L.mkv_set_tuning(b"merge_round2", 1)
+        L.mkv_set_tuning(b"plans", 1)
 
 
 _FIRST = int(__import__("os").environ.get("MKV_FUZZ_FIRST", "0"))       # (campaigns: a later range of seeds)
@@ -154,8 +155,10 @@ def _run(seed, forced):
     rng4 = np.random.default_rng(17000 + seed)
     L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
     L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
+    # round 1 carrying out the mark pass's plans (round 5): on (the default) or off
+    L.mkv_set_tuning(b"plans", int(np.random.default_rng(19000 + seed).choice([1, 1, 1, 0])))
     for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"round_blocks",
-                 b"self_help", b"merge_round2"):   # bisecting aid
+                 b"self_help", b"merge_round2", b"plans"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
             L.mkv_set_tuning(name, int(v))
@@ -225,7 +228,7 @@ def test_fuzz_cycles_without_deletes(seed):
     try:
         _run_cycles(seed, deletes=False)
     finally:
-        L.mkv_set_tuning(b"mark_blocks", 128)
+        L.mkv_set_tuning(b"mark_blocks", 208)
 
 
 def _run_cycles(seed, deletes):
@@ -243,6 +246,7 @@ def _run_cycles(seed, deletes):
     rng4 = np.random.default_rng(17000 + seed)
     L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
     L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
+    L.mkv_set_tuning(b"plans", int(np.random.default_rng(19000 + seed).choice([1, 1, 1, 0])))
     if not deletes:
         L.mkv_set_tuning(b"insert_chunk", 65536)     # (one pass)
     sig_space = int(rng.choice([40, 5000, 1 << 20]))

@@ -20,11 +20,12 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 REF = os.path.join(ROOT, "oracle", "_ref")
 
 
-def run(exe, *args, timeout=900):
+def run(exe, *args, timeout=900, env=None):
     path = os.path.join(REF, exe)
     if not os.path.exists(path):
         pytest.skip(f"{path} not built (needs /root/reference at build time)")
-    return subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=timeout)
+    return subprocess.run([path, *map(str, args)], capture_output=True, text=True, timeout=timeout,
+                          env=dict(os.environ, **(env or {})))
 
 
 @pytest.mark.parametrize("elems,threads", [(16384 * 64, 16384), (262144, 24576)])
@@ -42,6 +43,18 @@ def test_reference_insert_test_runs_clean(elems, threads):
     assert len(p1) <= 1 and len(p2) <= 1, (len(p1), len(p2), out[-1500:])
     speeds = [float(x) for x in re.findall(r"speed is ([0-9.]+) Mops", out)]
     assert speeds and min(speeds) > 0
+
+
+def test_reference_insert_test_runs_clean_with_deferred_launches():
+    """The same binary with the library's deferred mode on (MKV_DEFER=1, mkv_abi.hip): its calls are
+    recorded and issued by the synchronous copies it reads its results with -- P1 and P2 hold."""
+    r = run("ref_insert_test", 262144, 24576, env={"MKV_DEFER": "1"})
+    assert r.returncode == 0, r.stderr[-2000:]
+    out = r.stdout
+    assert len(re.findall(r"Load factor", out)) >= 10, out[-500:]
+    p1 = re.findall(r"not found insertion", out)
+    p2 = re.findall(r"(?<!not )found insertion", out)
+    assert len(p1) <= 1 and len(p2) <= 1, (len(p1), len(p2), out[-1500:])
 
 
 def test_reference_search_driver_runs():

@@ -20,3 +20,6 @@ run MKV_FUZZ_ROUND_BLOCKS=1 MKV_FUZZ_DEBUG_SKIP=0
 # round 4: round 2 always inside the tail launch / never; no self-help of second registrants
 run MKV_FUZZ_MERGE_ROUND2=2 MKV_FUZZ_SELF_HELP=1 MKV_FUZZ_TAIL_GROUPS=32
 run MKV_FUZZ_MERGE_ROUND2=0 MKV_FUZZ_SELF_HELP=0 MKV_FUZZ_TAIL_GROUPS=5
+# round 5: round 1 never / always carries out the mark pass's plans; cycles (the mark pass inside the search launch, deletes between it and round 1)
+run MKV_FUZZ_PLANS=0 MKV_FUZZ_TAIL_GROUPS=32
+run MKV_FUZZ_PLANS=1 MKV_FUZZ_ROUND_BLOCKS=512 MKV_FUZZ_MERGE_ROUND2=1
