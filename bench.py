@@ -80,6 +80,13 @@ def parse(argv=None):
                          "from the same table image and over the same batches; `value` is the median")
     ap.add_argument("--no-abi", action="store_true",
                     help="skip the side measurement of the reference's three-call sequence (abi_three_call)")
+    ap.add_argument("--allow-fallback", action="store_true",
+                    help="N > 1: if the C shard engine cannot be set up, go on with the Python-driven step over "
+                         "torch.distributed instead of giving up (the default with several GPUs is to give up: a "
+                         "fall-back line on an 8-GPU node is a wasted lease)")
+    ap.add_argument("--preflight", action="store_true", help=argparse.SUPPRESS)     # (the child of preflight_check)
+    ap.add_argument("--no-preflight", action="store_true",
+                    help="skip the transport check a sharded run makes in a child process before it builds its table")
     ap.add_argument("--strict-engine", action="store_true",
                     help="N > 1: exit non-zero if the C shard engine cannot be set up or fails its warm-up check "
                          "(default: report the phase that failed, fall back to the Python-driven step and tag the "
@@ -178,13 +185,107 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
+PREFLIGHT_S = 60.0
+
+
+def preflight_child(args):
+    """The transport of a sharded run, alone, on a table of 1 MiB: the process group over RCCL, a 64-KiB
+    send / receive ring over torch.distributed, then the C shard engine's own communicator -- create, connect
+    (its one-word all-to-all and grouped send / receive with every peer) -- and two batches through
+    mkv_shard_run against what a single table answers.  Every phase is announced on stderr before it starts:
+    the parent reports the last one if this process dies or does not come back."""
+    def phase(name):
+        print(f"preflight phase: {name}", file=sys.stderr, flush=True)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    late_imports()
+    rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    phase("process group (RCCL)")
+    torch.cuda.set_device(local_rank)
+    device = torch.device(f"cuda:{local_rank}")
+    import torch.distributed as dist
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+    if world > 1:
+        phase("64-KiB send / receive ring (torch.distributed over RCCL)")
+        a = torch.full((16384,), rank, dtype=torch.int32, device=device)
+        b = torch.empty_like(a)
+        ops = [dist.P2POp(dist.isend, a, (rank + 1) % world), dist.P2POp(dist.irecv, b, (rank - 1) % world)]
+        for r in dist.batch_isend_irecv(ops):
+            r.wait()
+        torch.cuda.synchronize()
+        assert int(b[0].item()) == (rank - 1) % world and bool((b == b[0]).all().item()), "ring: wrong payload"
+    phase("C shard engine: create / connect (own RCCL communicator, first exchange)")
+    scheme = M.SCHEME_CUCKOO if args.scheme == "cuckoo" else M.SCHEME_2CHOICE
+    from megakv_amd.sharded import NcclComm
+    n_get, n_set = 4096, 512
+    eng = sharded_engine(20, world, rank, scheme, device, n_get, n_set, NcclComm(dist), cap_factor=2.0 * max(1, world // 2))
+    eng.enable_native(dist)
+    phase("C shard engine: two batches through mkv_shard_run")
+    rng = np.random.default_rng(77 + rank)
+    keys = rng.integers(1, 1 << 30, size=n_set, dtype=np.uint64).astype(np.uint32)
+    sets = W.make_ielem(keys, None, W.KEYING_MIX)
+    gets = W.make_selem(keys[rng.integers(0, n_set, size=n_get)], W.KEYING_MIX)
+    b0 = eng.stage(np.zeros((0, 2), np.uint32), sets)           # this rank's keys in ...
+    b1 = eng.stage(gets, np.zeros((0, 3), np.uint32))           # ... and looked up again, wherever their shard is
+    eng.run_pipelined([b0, b1])
+    torch.cuda.synchronize()
+    assert not eng.overflowed(), "a slot overflowed"
+    o = b1["out"].cpu().numpy().view(np.uint32)
+    found = np.where(o[:, 0] != 0, o[:, 0], o[:, 1])
+    want = gets[:, 0] * 0
+    look = {int(k): int(l) for k, l in zip(sets[:, 0].tolist(), sets[:, 2].tolist())}
+    want = np.array([look[int(sg)] for sg in gets[:, 0].tolist()], dtype=np.uint32)
+    assert np.array_equal(found, want), f"{int((found != want).sum())} of {n_get} GETs came back wrong"
+    eng.native.close()
+    dist.destroy_process_group()
+    print("preflight ok", file=sys.stderr, flush=True)
+    return 0
+
+
+def preflight_check(args):
+    """Before a sharded run over RCCL touches the GPU or builds its table: the transport check above in a CHILD
+    process of this rank (the children of all ranks meet on the next port) under a deadline.  Returns None, or
+    the phase that failed or hung and what the child said last."""
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["MASTER_ADDR"] = env.get("MASTER_ADDR", "127.0.0.1")
+    env["MASTER_PORT"] = str(int(env.get("MASTER_PORT", "29517")) + 1)
+    env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # (rank 0's child serves the children's store itself)
+    cmd = [sys.executable, os.path.abspath(__file__), "--preflight", "--scheme", args.scheme]
+    child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+    try:
+        _, err = child.communicate(timeout=PREFLIGHT_S)
+        timed_out = False
+    except subprocess.TimeoutExpired:
+        child.kill()                                 # (this very process: the PID we started)
+        _, err = child.communicate()
+        timed_out = True
+    phases = [ln.split(":", 1)[1].strip() for ln in err.splitlines() if ln.startswith("preflight phase:")]
+    if child.returncode == 0 and not timed_out:
+        return None
+    last = phases[-1] if phases else "start-up (importing torch)"
+    tail = " | ".join(ln for ln in err.splitlines()[-6:] if not ln.startswith("preflight phase:"))
+    return (f"{'no answer within %.0f s in' % PREFLIGHT_S if timed_out else 'failed in'} phase \"{last}\""
+            + (f": {tail}" if tail else ""))
+
+
 def main():
     # Libraries (RCCL prints a version banner) must not share the channel of the one JSON
     # line: everything written to fd 1 from here on goes to stderr, the line is written
     # to the saved descriptor at the end.
     args = parse()
+    if args.preflight:
+        raise SystemExit(preflight_child(args))
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(launch_ranks(args.gpus))
+    if ((int(os.environ.get("WORLD_SIZE", "1")) > 1 or args.force_sharded) and args.comm == "nccl" and not args.no_native
+            and not args.no_pipeline and not args.no_preflight):
+        # (this process has not touched the GPU yet: the check runs in a child, nothing is exec'ed here)
+        why = preflight_check(args)
+        if why:
+            print(f"[rank {os.environ.get('RANK', '0')}] bench.py: the transport check before the run {why}; giving up "
+                  f"(--no-preflight skips the check)", file=sys.stderr, flush=True)
+            raise SystemExit(23)
     # (before anything initialises HIP: the host driver of this pool only supports dmabuf IPC -- RCCL's
     # peer mappings fail with "hipIpcGetMemHandle: invalid argument" without it)
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
@@ -253,6 +354,7 @@ def main():
                               cap_factor=slot_factor)
     native = False
     engine_error = None               # why the C shard engine is not what ran (phase and message), if it is not
+    strict = args.strict_engine or (world > 1 and not args.allow_fallback)
     if sharded and args.comm == "nccl" and not args.no_native and not args.no_pipeline:
         # the step as ONE library call per run (own RCCL communicator); all ranks agree, or all
         # fall back to the Python-driven step over torch.distributed
@@ -277,8 +379,9 @@ def main():
                 engine.native.close()
             engine.native = None
             engine_error = engine_error or "set-up: another rank failed (see its message)"
-            if args.strict_engine:
-                print(f"[rank {rank}] --strict-engine: giving up ({engine_error})", file=sys.stderr, flush=True)
+            if strict:
+                print(f"[rank {rank}] giving up ({engine_error}); --allow-fallback goes on with the Python-driven step",
+                      file=sys.stderr, flush=True)
                 dist.destroy_process_group()
                 os._exit(21)
             print(f"[rank {rank}] falling back to the Python-driven step over torch.distributed; the line will say "
@@ -349,7 +452,7 @@ def main():
                 engine_error = "warm-up check: GETs of pre-loaded keys did not all come back with their key (on some rank)"
                 print(f"[rank {rank}] C shard engine FAILED its warm-up check (hit rate of pre-loaded keys "
                       f"{float((res0 == check_keys).mean()):.4f} on this rank)", file=sys.stderr, flush=True)
-                if args.strict_engine:
+                if strict:
                     dist.destroy_process_group()
                     os._exit(22)
                 print(f"[rank {rank}] falling back to the Python-driven step; the line will say "
@@ -535,6 +638,26 @@ def main():
             roofline["inside_timed_region"] = {"launches_timed": int(len(inside)),
                                                "median_us": round(float(np.median(inside)) * 1e3, 2)}
 
+    # The C shard engine's own device timestamps, per rank: mean microseconds of a batch's pack, exchange (one
+    # grouped launch: results of batch i back, requests of batch i+B out), local phase and un-pack over eight
+    # batches of one more run with events around every operation (they cost 3 - 5 us each: weights of the
+    # phases, not a ledger of the timed region) -- what a SCALE record is read against BASELINE.md section 4 with.
+    phases = None
+    if sharded and native and args.steps >= 26:
+        try:
+            with torch.cuda.stream(run_stream):
+                mine = engine.native.phases_us(batches[args.warmup:args.warmup + args.steps], run_stream)
+            barrier()
+            t = torch.tensor([mine["pack"], mine["exchange"], mine["local"], mine["unpack"]], dtype=torch.float32, device=device)
+            allr = [torch.zeros_like(t) for _ in range(world)]
+            if world > 1:
+                dist.all_gather(allr, t)
+            else:
+                allr = [t]
+            phases = [{k: round(float(v), 2) for k, v in zip(("pack", "exchange", "local", "unpack"), a.tolist())} for a in allr]
+        except Exception as ex:                                   # noqa: BLE001
+            phases = {"error": f"{type(ex).__name__}: {ex}"}
+
     # side measurements: whatever happens in them, the line with `value` is still printed
     pcie = None
     if rank == 0 and not sharded and not args.no_pcie:
@@ -576,7 +699,7 @@ def main():
             "repeats": repeats, "abi_three_call": abi,
             "engine": ("single table (mkv_cycle)" if not sharded else "C shard engine (mkv_shard_run)" if native else
                        "python-fallback" if engine_error else "python-driven step"),
-            "engine_error": engine_error,
+            "engine_error": engine_error, "phases_us_per_rank": phases,
             "get_hit_rate": hit_rate, "get_loc_correct": loc_ok, "get_loc_correct_last_timed": loc_ok_last,
             "set_loc_correct_last_timed": set_ok, "table_entries": entries,
             "table_entries_ok": entries.get("ok") if isinstance(entries, dict) else None,

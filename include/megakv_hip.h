@@ -314,6 +314,11 @@ int mkv_shard_run(mkv_shard_t *e, int nbatches, const selem_t *const *gets, cons
 		const ielem_t *const *sets, const int64_t *n_set, loc_t *const *outs, void *stream, void *timer,
 		int timer_every);
 int mkv_shard_overflowed(mkv_shard_t *e, int *flag);   /* synchronises the device */
+/* Device time per phase of a batch (pack, exchange, local, un-pack; microseconds, mean over the spans
+ * seen): mkv_shard_trace(n) arms events around every operation of n batches near the end of the next
+ * runs, mkv_shard_phases() reads the means and disarms.  A pass of its own: the events cost time. */
+void mkv_shard_trace(int nbatches);
+int mkv_shard_phases(float out_us[4], int counts[4]);
 const char *mkv_shard_error(const mkv_shard_t *e);
 void mkv_shard_destroy(mkv_shard_t *e);
 

@@ -94,9 +94,13 @@ namespace {
 struct TraceRec { const char *what; int lane, batch; hipEvent_t a, b; };
 struct Trace {
 	int on = -1, n = 0;
+	bool quiet = false;             // mkv_shard_trace: the spans are summed per phase instead of printed
+	double sum_us[4] = {0, 0, 0, 0};
+	int cnt[4] = {0, 0, 0, 0};
 	TraceRec rec[512];
 };
 Trace g_trace;
+const char *const kPhaseNames[4] = {"pack", "exchange", "local", "unpack"};
 
 struct Span {
 	TraceRec *r = nullptr;
@@ -608,6 +612,14 @@ static void print_trace()
 			float t0 = 0, t1 = 0;
 			(void)hipEventElapsedTime(&t0, g_trace.rec[0].a, g_trace.rec[k].a);
 			(void)hipEventElapsedTime(&t1, g_trace.rec[0].a, g_trace.rec[k].b);
+			if (g_trace.quiet) {
+				for (int p = 0; p < 4; p++)
+					if (!strcmp(g_trace.rec[k].what, kPhaseNames[p])) {
+						g_trace.sum_us[p] += (double)(t1 - t0) * 1e3;
+						g_trace.cnt[p]++;
+					}
+				continue;
+			}
 			fprintf(stderr, "%8.1f -> %8.1f  lane %d %*s%-8s batch %d (%.1f us)\n", t0 * 1e3, t1 * 1e3,
 					g_trace.rec[k].lane, g_trace.rec[k].lane * 6, "", g_trace.rec[k].what, g_trace.rec[k].batch,
 					(t1 - t0) * 1e3);
@@ -826,6 +838,37 @@ extern "C" int mkv_shard_run(mkv_shard *e, int nbatches, const selem_t *const *g
 	else
 		(void)hipDeviceSynchronize();
 	return rc;
+}
+
+// Device time per phase of a batch, for a host that wants to read a run against a prediction without a
+// profiler (bench.py: "phases_us").  mkv_shard_trace(n) arms the NEXT runs of the process: events around every
+// operation of n batches near each run's end (as MKV_SHARD_TRACE=n does, without the table on stderr);
+// mkv_shard_phases() returns the mean duration of the spans seen since -- pack, exchange (one grouped launch:
+// results of batch i back, requests of batch i+B out), local (slot search + mark, rounds, tail), un-pack -- in
+// microseconds, and disarms.  The events themselves cost 3 - 5 us each between two kernels of a stream
+// (tools/probes/event_probe.hip): run it on a pass of its own, never inside a timed region.
+extern "C" void mkv_shard_trace(int nbatches)
+{
+	g_trace.on = nbatches > 0 ? (nbatches > 64 ? 64 : nbatches) : 0;
+	g_trace.quiet = nbatches > 0;
+	for (int p = 0; p < 4; p++) {
+		g_trace.sum_us[p] = 0;
+		g_trace.cnt[p] = 0;
+	}
+}
+
+extern "C" int mkv_shard_phases(float out_us[4], int counts[4])
+{
+	if (!out_us)
+		return MKV_EINVAL;
+	for (int p = 0; p < 4; p++) {
+		out_us[p] = g_trace.cnt[p] ? (float)(g_trace.sum_us[p] / g_trace.cnt[p]) : 0.0f;
+		if (counts)
+			counts[p] = g_trace.cnt[p];
+	}
+	g_trace.on = 0;
+	g_trace.quiet = false;
+	return MKV_OK;
 }
 
 // synchronises; *flag = a slot overflowed since the engine was created (results invalid)

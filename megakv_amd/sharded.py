@@ -127,8 +127,10 @@ class NativeEngine:
         import os
         self.sh, self.lib = sh, sh.idx.lib
         self.h = ctypes.c_void_p(0)
-        rccl = os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
-        path = b"loopback" if loopback else (rccl.encode() if os.path.exists(rccl) else None)
+        # (MKV_RCCL_PATH: another RCCL than the one the host framework loaded -- tests point it nowhere to see
+        # the set-up fail loudly)
+        rccl = os.environ.get("MKV_RCCL_PATH") or os.path.join(os.path.dirname(torch.__file__), "lib", "librccl.so")
+        path = b"loopback" if loopback else (rccl.encode() if (os.path.exists(rccl) or "MKV_RCCL_PATH" in os.environ) else None)
         rc = self.lib.mkv_shard_create(ctypes.byref(self.h), ctypes.byref(sh.idx._g), sh.world, sh.rank,
                                        _dev_ptr(sh.idx.table), sh.n_get, sh.n_set, sh.cap_get, sh.cap_set,
                                        path)
@@ -177,6 +179,19 @@ class NativeEngine:
         flag = ctypes.c_int(0)
         self._check(self.lib.mkv_shard_overflowed(self.h, ctypes.byref(flag)), "mkv_shard_overflowed")
         return bool(flag.value)
+
+    def phases_us(self, batches, stream=None, traced=8):
+        """One more run of `batches` with device timestamps around every operation of `traced` of them: mean
+        microseconds of pack / exchange / local / un-pack (mkv_shard_trace; a pass of its own -- the events
+        cost time -- and only with more than traced + 16 batches)."""
+        self.lib.mkv_shard_trace(int(traced))
+        try:
+            self.run(batches, stream)
+        finally:
+            out, cnt = (ctypes.c_float * 4)(), (ctypes.c_int * 4)()
+            self.lib.mkv_shard_phases(out, cnt)
+        return {k: round(float(out[i]), 2) for i, k in enumerate(("pack", "exchange", "local", "unpack"))} | \
+            {"spans": int(cnt[2])}
 
     def close(self):
         if self.h:

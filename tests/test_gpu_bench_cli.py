@@ -69,3 +69,26 @@ def test_one_rank_through_the_rccl_engine():
     d = run_bench("--force-sharded", "--steps", "6", "--warmup", "2", *SMALL)
     check_common(d, 1, 6, 2)
     assert "library-owned RCCL communicator" in d["config"]["launch"]
+
+
+def test_one_rank_through_the_rccl_engine_reports_its_phases():
+    """... and with enough steps the line carries the engine's own device time per phase of a batch
+    (mkv_shard_trace / mkv_shard_phases: pack, exchange, local, un-pack)."""
+    d = run_bench("--force-sharded", "--steps", "30", "--warmup", "2", *SMALL)
+    check_common(d, 1, 30, 2)
+    ph = d["phases_us_per_rank"]
+    assert isinstance(ph, list) and len(ph) == 1, ph
+    assert ph[0]["local"] > 0 and ph[0]["pack"] > 0 and ph[0]["unpack"] > 0, ph
+
+
+def test_transport_check_fails_loudly_before_the_table_is_built():
+    """The sharded run checks its transport in a child process first (RCCL ring, the engine's connect and first
+    batches).  With the engine pointed at an RCCL that does not exist the run ends there: non-zero exit, the
+    failing phase named, no line on stdout -- not a fall-back line."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["MKV_RCCL_PATH"] = "/nonexistent/librccl.so"
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--force-sharded", "--steps", "4", "--warmup", "2",
+                        *SMALL], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 23, (p.returncode, p.stderr[-2000:])
+    assert "transport check" in p.stderr and "C shard engine: create / connect" in p.stderr, p.stderr[-2000:]
+    assert not p.stdout.strip()
