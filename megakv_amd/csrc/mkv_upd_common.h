@@ -956,7 +956,8 @@ __device__ __forceinline__ void count_add(uint32_t *shards, uint32_t n)
 // through the ordinary reservation instead of being committed under the chain's feet.  Only
 // a hint: nothing depends on the walk being right (the table may change before the turn).
 __device__ __forceinline__ void prewalk_register(const uint32_t *table, const DevGeom &g, const Req &r, uint32_t P,
-		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi, uint32_t *hint_stamp, uint32_t s32)
+		uint32_t A, unsigned long long *owner, unsigned long long key, uint4 lo, uint4 hi, uint32_t *hint_stamp, const Lost &lost,
+		bool flagging)
 {
 	// (lo, hi: the signature row of P, loaded by the caller)
 	if (eq_mask(lo, hi, r.sig) | eq_mask(lo, hi, 0u))
@@ -967,8 +968,12 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 			return;
 	}
 	const uint32_t v = r.sig & 7u;              // victim slot: ORIGINAL signature (ref :360)
-	if (g.max_cuckoo != 0u)
-		*hint_stamp = s32;                      // (registrations without a returning atomic: round 1 reads every reservation, kPlanBit)
+	// (flagging: the walk's registrations are returning atomics too and flag whom they displace, like all the
+	// others -- the plans of the pass stand, kPlanBit; else they are not, and the pass says so: round 1 then reads
+	// every reservation.  The host asks for the second form while chains have been running late -- a well-filled
+	// table, thousands of walks per pass: the returning atomic per step made the fused launch a third longer there.)
+	if (g.max_cuckoo != 0u && !flagging)
+		*hint_stamp = lost.s32;
 	for (uint32_t k = 0; k < g.max_cuckoo; k++) {
 		const uint4 q = (v & 4u) ? hi : lo;
 		const uint32_t a = (v & 1u) ? q.y : q.x, c = (v & 1u) ? q.w : q.z;
@@ -978,8 +983,15 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 		// it the fused launch of a well-filled table, a third longer -- 34 -> 46 us at load factor 0.85.
 		// A bucket's second registrant that helps itself behind a chain's hint commits where it would
 		// have committed in round 2, and the chain, should it ever come, finds it like any later commit.)
-		atomicMin(&owner[nb], key);
-		load_sig_row<false>(table, nb, lo, hi);
+		if (flagging) {
+			const unsigned long long old = atomicMin(&owner[nb], key);
+			load_sig_row<false>(table, nb, lo, hi);
+			if ((old >> kIdxBits) == (key >> kIdxBits) && old > key)
+				flag_lost(lost, old);
+		} else {
+			atomicMin(&owner[nb], key);
+			load_sig_row<false>(table, nb, lo, hi);
+		}
 		if (eq_mask(lo, hi, vsig) | eq_mask(lo, hi, 0u))
 			return;
 	}

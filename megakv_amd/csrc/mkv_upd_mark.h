@@ -10,6 +10,7 @@ namespace mkv {
 
 // ---- K1: mark -----------------------------------------------------------------
 // (undo, lost_flags: where the plans and the flags of kPlanBit go -- null: none are made)
+// (lazy_free: Tuning::lazy_alt; bit 8: chains have been running late -- the walks ahead do not flag, prewalk_register)
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap,
@@ -173,7 +174,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			const Bkt kP = load_bucket(table, P);
 			plo = kP.s0;
 			phi = kP.s1;
-			lazy = fresh && lazy_free != 0u && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= lazy_free;
+			lazy = fresh && (lazy_free & 0xffu) != 0u && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= (lazy_free & 0xffu);
 			// what the request would do in P as the table stands (kPlanBit)
 			Undo u;
 			if (fresh && undo && plan_primary(P, kP, rq.sig, &u)) {
@@ -195,7 +196,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 			register_dedup(owner, second, A, key, live && A != P && !lazy, lost);
 		}
 		if (OP == OP_CUCKOO && live && table && !lazy)
-			prewalk_register(table, g, rq, P, A, owner, key, plo, phi, &ctl->hint_stamp, (uint32_t)stamp);
+			prewalk_register(table, g, rq, P, A, owner, key, plo, phi, &ctl->hint_stamp, lost, (lazy_free & 0x100u) == 0u && lost.flag);
 	}
 }
 

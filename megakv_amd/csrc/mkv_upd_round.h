@@ -233,28 +233,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 						u = pre_plan;
 					else
 						u = undo[idx];
-#if defined(MKV_EXP_R1) && (MKV_EXP_R1 & 16)
-					if (u.word1 == kNoWord) {       // experiment: write-through stores
-						__hip_atomic_store(&table[u.word0], r.loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					} else {
-						__hip_atomic_store(&table[u.word0], r.sig, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-						__hip_atomic_store(&table[u.word1], r.loc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-					}
-#elif defined(MKV_EXP_R1) && (MKV_EXP_R1 & 32)
-					if (u.word1 == kNoWord) {       // experiment: non-temporal stores
-						__builtin_nontemporal_store(r.loc, &table[u.word0]);
-					} else {
-						__builtin_nontemporal_store(r.sig, &table[u.word0]);
-						__builtin_nontemporal_store(r.loc, &table[u.word1]);
-					}
-#else
 					if (u.word1 == kNoWord) {
 						table[u.word0] = r.loc;
 					} else {
 						table[u.word0] = r.sig;
 						table[u.word1] = r.loc;
 					}
-#endif
 					state[idx] = ST_ROUND1;
 					ndone++;
 					planned = true;

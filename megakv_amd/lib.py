@@ -77,8 +77,16 @@ def _load(LIB_PATH, diagnostics):
     L = ctypes.CDLL(LIB_PATH)
     P, I64, U32, INT = ctypes.c_void_p, ctypes.c_int64, ctypes.c_uint32, ctypes.c_int
     G = ctypes.POINTER(MkvGeom)
+    # (MKV_LIB_OLD_BUILD=1, tools/ab_lines.sh only: an earlier round's build of the library stands in the product's
+    # place for an A/B -- entry points it does not have yet are simply not there)
+    old_build = bool(os.environ.get("MKV_LIB_OLD_BUILD"))
     for name in ABI_SYMBOLS + (DIAG_SYMBOLS if diagnostics else []):
         if not hasattr(L, name):
+            if old_build:
+                class _Absent:
+                    restype = argtypes = None
+                setattr(L, name, _Absent())
+                continue
             raise LibraryMissing(f"{LIB_PATH} does not export {name}")
     L.gpu_hash_search.restype = None
     L.gpu_hash_search.argtypes = [P, P, P, INT, INT, INT, P]
