@@ -78,27 +78,20 @@ __device__ __forceinline__ uint32_t preferred_slot(uint32_t empties, uint32_t or
 	return (uint32_t)(__ffs((int)ballot) - 1) & 7u;
 }
 
-// Process-wide tuning knobs (defaults = measured best on MI355X).
-// Initialised from MKV_SEARCH_U / MKV_SEARCH_NT / MKV_TAIL_ROUNDS /
-// MKV_REQ_CAP on first use, changeable through mkv_set_tuning().
+// Process-wide tuning knobs (defaults = measured best on MI355X).  Initialised from the environment
+// (MKV_<NAME>) on first use, changeable through mkv_set_tuning().  Sixteen of them; what only tests and probes
+// ever set -- how the tail takes an order violation back, layouts kept for the record, sizes whose sweeps are
+// flat -- exists in the diagnostics build only (DiagTuning below) and is a constant in the product.
 struct Tuning {
-	int search_u;        // requests in flight per 4-lane group: 1, 2, 4 or 8
-	int search_nt;       // non-temporal table loads in search
-	int search_wide;     // 8 lanes per request, one 64-byte access per bucket (search_body_wide)
-	int search_lds;      // signature rows staged in LDS, ballot/ffs probe, dependent location load (search_body_lds)
-	int tail_rounds;     // reservation rounds inside the tail work-group (0..48)
-	long long req_cap;   // default request capacity of an update workspace
+	int search_u;           // requests in flight per 4-lane group: 1, 2, 4 or 8
+	int search_nt;          // non-temporal table loads in search
+	int tail_rounds;        // reservation rounds inside the tail work-group (0..48)
+	long long req_cap;      // default request capacity of an update workspace
 	long long insert_chunk; // requests per canonical-index chunk when the caller hints the batch size
 	int mark_blocks;        // work-groups of the insert mark pass inside the fused search launch
-	int pack_three_pass;    // sharded pack: the three-kernel stable path instead of the one-launch pack
 	int pack_threads;       // one-launch pack: lanes per work-group (256, 512 or 1024)
-	int barrier_sticky;     // calls for which a call that met a barrier counts as "barriers lately"
-	int barrier_split;      // barriers lately: cut a hinted single-chunk batch into this many chunks (1: off)
-	int grid_min;           // a final tail list longer than this runs its rounds on all work-groups of the launch
-	int grid_progress;      // grid-wide tail rounds go on while they resolve at least this many requests (else: in-order replay)
-	int calm_factor;        // chunk size multiplier while no region barrier was met lately
-	int round_blocks;       // work-groups of the round-1 / round-2 launches of an insert or delete
-	int mark_alone_blocks;  // work-groups of the stand-alone mark launch
+	int barrier_sticky;     // calls for which a call whose chains ran late counts as "chains lately"
+	int round_blocks;       // work-groups of the round-1 / round-2 launches of an insert or delete (at most)
 	int tail_groups;        // work-groups of the tail launch (all share its tag scans; group 0 does the rest)
 	int dup_groups;         // duplicates of a key inside one pass are settled as a group in round 2 (kFollowBit); 0: off
 	int lazy_alt;           // a request whose primary bucket shows at least this many free slots at mark time does
@@ -107,14 +100,33 @@ struct Tuning {
 	                        // what that one will do there (self-help, mkv_update.hip); 0: it waits for round 2
 	int plans;              // the mark pass plans what a request does in its primary bucket and flags who is not a bucket's lowest
 	                        // registrant; round 1 carries the plans out without reading bucket or reservation (kPlanBit); 0: as before
-	int merge_round2;       // round 2 runs as the first phase of the tail launch (0: a launch of its own, as before)
+	int merge_round2;       // round 2 runs as the first phase of the tail launch (0: a launch of its own; 1: unless round 1 has
+	                        // been leaving it a lot; 2: always)
 	long long merge_max;    // ... for passes announced with at most this many requests
-	long long debug_first_stamp; // tests only: first round stamp of a new workspace (exercises the stamp wrap guard)
-	int debug_skip;      // tests only (results unchanged): how the tail deals with an order violation --
-	                     // 0 as designed, 1 always the general way (resolve_violations), 2 always the
-	                     // region-suffix fall-back; +4: rounds 1 and 2 leave every eviction chain to the tail
 };
 Tuning &tuning();
+
+// Diagnostics build only (make DIAG=1): knobs of tests and probes.  The product uses the defaults.
+struct DiagTuning {
+	int search_wide = 0;        // 8 lanes per request, one 64-byte access per bucket (search_body_wide)
+	int search_lds = 0;         // signature rows staged in LDS, ballot/ffs probe, dependent location load (search_body_lds)
+	int pack_three_pass = 0;    // sharded pack: the three-kernel stable path instead of the one-launch pack
+	int grid_min = 2048;        // a final tail list longer than this runs its rounds on all work-groups of the launch
+	int grid_progress = 96;     // grid-wide tail rounds go on while they resolve at least this many requests (else: in-order replay)
+	int calm_factor = 1;        // chunk size multiplier while no chain ran late lately
+	int mark_alone_blocks = 1024;   // work-groups of the stand-alone mark launch
+	long long debug_first_stamp = 0; // first round stamp of a new workspace (exercises the stamp wrap guard)
+	int debug_skip = 0;         // (results unchanged) how the tail deals with an order violation -- 0 as designed, 1 always the
+	                            // general way (resolve_violations), 2 always the region-suffix fall-back; +4: rounds 1 and 2
+	                            // leave every eviction chain to the tail
+};
+#ifdef MKV_DIAGNOSTICS
+DiagTuning &diag_tuning();
+#define MKV_DIAG(field) (::mkv::diag_tuning().field)
+#else
+#define MKV_DIAG(field) (::mkv::DiagTuning().field)
+#endif
+
 
 // A launch whose start and end time are delivered into HIP events when given (the dispatch's
 // own timestamps, hipExtLaunchKernelGGL); a plain launch otherwise.

@@ -741,7 +741,7 @@ extern "C" int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_b
 	const int64_t set_tiles = ((n_set > 0 ? n_set : 0) + set_tile - 1) / set_tile;
 	const int64_t set_tiles_max = (dev >= 0 && dev < 64 && resident_cap[dev][v] > 0) ?
 			(resident_cap[dev][v] < 1024 ? resident_cap[dev][v] : 1024) : 128;
-	return nshards >= 1 && nshards <= mkv::kPackBins && set_tiles <= set_tiles_max && !mkv::tuning().pack_three_pass &&
+	return nshards >= 1 && nshards <= mkv::kPackBins && set_tiles <= set_tiles_max && !MKV_DIAG(pack_three_pass) &&
 			scratch_bytes >= (mkv::kPackCtlWords + set_tiles * mkv::kPackBins) * 4;
 }
 

@@ -69,7 +69,7 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 	dim3 grid((unsigned)blocks), block(256);
 	const bool zero = (flags & MKV_SEARCH_ZERO_MISS) != 0;
 #ifdef MKV_DIAGNOSTICS
-	if (tuning().search_lds) {
+	if (MKV_DIAG(search_lds)) {
 		// 64 requests per block of 4 waves
 		const int64_t lblocks = (n + 63) / 64;
 		if (lblocks > 0x7fffffffLL)
@@ -80,7 +80,7 @@ static int launch_search(const uint2 *in, uint32_t *out, const uint4 *table, int
 			MKV_LAUNCH_TIMED((k_search_lds<false>), dim3((unsigned)lblocks), block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
 		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 	}
-	if (tuning().search_wide) {
+	if (MKV_DIAG(search_wide)) {
 		// (same requests per block: 4 waves x 8 x 2U)
 		if (zero)
 			MKV_LAUNCH_TIMED((k_search_wide<U, true, false>), grid, block, stream, e0, e1, in, out, table, n, hash_mask, blk_mask);
@@ -107,74 +107,43 @@ Tuning &tuning()
 {
 	static Tuning t = [] {
 		Tuning v;
-		const char *s = getenv("MKV_SEARCH_U");
-		v.search_u = s ? atoi(s) : 4;
+		auto env = [](const char *name, long long dflt, long long lo, long long hi) {
+			const char *s = getenv(name);
+			const long long x = s ? atoll(s) : dflt;
+			return x < lo || x > hi ? dflt : x;
+		};
+		v.search_u = (int)env("MKV_SEARCH_U", 4, 1, 8);
 		if (v.search_u != 1 && v.search_u != 2 && v.search_u != 4 && v.search_u != 8)
 			v.search_u = 4;
-		s = getenv("MKV_SEARCH_NT");
-		v.search_nt = s ? atoi(s) != 0 : 0;
-		v.search_wide = v.search_lds = 0;      // (diagnostics builds: mkv_set_tuning)
-		s = getenv("MKV_TAIL_ROUNDS");
-		v.tail_rounds = s ? atoi(s) : 48;
-		if (v.tail_rounds < 0) v.tail_rounds = 0;
-		if (v.tail_rounds > 48) v.tail_rounds = 48;
-		s = getenv("MKV_REQ_CAP");
-		v.req_cap = s ? atoll(s) : (1ll << 22);
-		if (v.req_cap < 1024) v.req_cap = 1024;
-		v.debug_skip = 0;
-		v.debug_first_stamp = 0;
-		s = getenv("MKV_ROUND_BLOCKS");
-		v.round_blocks = s ? atoi(s) : 512;
-		if (v.round_blocks < 1 || v.round_blocks > 65536) v.round_blocks = 512;
-		v.grid_progress = 96;
-		v.mark_alone_blocks = 1024;
-		s = getenv("MKV_MARK_BLOCKS");
-		v.mark_blocks = s ? atoi(s) : 208;
-		if (v.mark_blocks < 1) v.mark_blocks = 1;
-		if (v.mark_blocks > 1024) v.mark_blocks = 1024;
-		v.pack_three_pass = 0;                 // (diagnostics builds: mkv_set_tuning forces the fall-back)
-		s = getenv("MKV_PACK_THREADS");
-		v.pack_threads = s ? atoi(s) : 1024;
-		if (v.pack_threads != 256 && v.pack_threads != 512) v.pack_threads = 1024;
-		s = getenv("MKV_BARRIER_STICKY");
-		v.barrier_sticky = s ? atoi(s) : 16;
-		if (v.barrier_sticky < 0) v.barrier_sticky = 0;
-		s = getenv("MKV_BARRIER_SPLIT");
-		v.barrier_split = s ? atoi(s) : 1;
-		if (v.barrier_split < 1) v.barrier_split = 1;
-		if (v.barrier_split > 64) v.barrier_split = 64;
-		s = getenv("MKV_GRID_MIN");
-		v.grid_min = s ? atoi(s) : 2048;
-		if (v.grid_min < 0) v.grid_min = 0;
-		s = getenv("MKV_CALM_FACTOR");
-		v.calm_factor = s ? atoi(s) : 1;
-		if (v.calm_factor < 1) v.calm_factor = 1;
-		if (v.calm_factor > 64) v.calm_factor = 64;
-		s = getenv("MKV_TAIL_GROUPS");
-		v.tail_groups = s ? atoi(s) : 32;
-		if (v.tail_groups < 1) v.tail_groups = 1;
-		if (v.tail_groups > 64) v.tail_groups = 64;
-		s = getenv("MKV_DUP_GROUPS");
-		v.dup_groups = s ? atoi(s) != 0 : 1;
-		s = getenv("MKV_LAZY_ALT");
-		v.lazy_alt = s ? atoi(s) : 2;
-		if (v.lazy_alt < 0 || v.lazy_alt > 8) v.lazy_alt = 2;
-		s = getenv("MKV_SELF_HELP");
-		v.self_help = s ? atoi(s) != 0 : 1;
-		s = getenv("MKV_PLANS");
-		v.plans = s ? atoi(s) != 0 : 1;
-		s = getenv("MKV_MERGE_ROUND2");
-		v.merge_round2 = s ? atoi(s) : 1;      // (2: even when round 1 has been leaving round 2 a lot)
-		s = getenv("MKV_MERGE_MAX");
-		v.merge_max = s ? atoll(s) : 131072;
-		s = getenv("MKV_INSERT_CHUNK");
-		v.insert_chunk = s ? atoll(s) : 524288;
-		if (v.insert_chunk < 1024) v.insert_chunk = 1024;
-		v.insert_chunk &= ~15ll;
+		v.search_nt = (int)env("MKV_SEARCH_NT", 0, 0, 1);
+		v.tail_rounds = (int)env("MKV_TAIL_ROUNDS", 48, 0, 48);
+		v.req_cap = env("MKV_REQ_CAP", 1ll << 22, 1024, 1ll << 40);
+		v.insert_chunk = env("MKV_INSERT_CHUNK", 524288, 1024, 1ll << 40) & ~15ll;
+		v.mark_blocks = (int)env("MKV_MARK_BLOCKS", 208, 1, 1024);
+		v.pack_threads = (int)env("MKV_PACK_THREADS", 1024, 256, 1024);
+		if (v.pack_threads != 256 && v.pack_threads != 512)
+			v.pack_threads = 1024;
+		v.barrier_sticky = (int)env("MKV_BARRIER_STICKY", 16, 0, 1000000);
+		v.round_blocks = (int)env("MKV_ROUND_BLOCKS", 512, 1, 65536);
+		v.tail_groups = (int)env("MKV_TAIL_GROUPS", 32, 1, 64);
+		v.dup_groups = (int)env("MKV_DUP_GROUPS", 1, 0, 1);
+		v.lazy_alt = (int)env("MKV_LAZY_ALT", 2, 0, 8);
+		v.self_help = (int)env("MKV_SELF_HELP", 1, 0, 1);
+		v.plans = (int)env("MKV_PLANS", 1, 0, 1);
+		v.merge_round2 = (int)env("MKV_MERGE_ROUND2", 1, 0, 2);      // (2: even when round 1 has been leaving round 2 a lot)
+		v.merge_max = env("MKV_MERGE_MAX", 131072, 0, 1ll << 40);
 		return v;
 	}();
 	return t;
 }
+
+#ifdef MKV_DIAGNOSTICS
+DiagTuning &diag_tuning()
+{
+	static DiagTuning d;
+	return d;
+}
+#endif
 
 }  // namespace mkv
 
@@ -217,111 +186,62 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 	if (!name)
 		return MKV_EINVAL;
 	mkv::Tuning &t = mkv::tuning();
+	struct Knob { const char *name; int *i; long long *ll; long long lo, hi; };
+	const Knob knobs[] = {
+		{"search_nt", &t.search_nt, nullptr, 0, 1}, {"tail_rounds", &t.tail_rounds, nullptr, 0, 48},
+		{"req_cap", nullptr, &t.req_cap, 1024, 1ll << 40}, {"mark_blocks", &t.mark_blocks, nullptr, 1, 1024},
+		{"barrier_sticky", &t.barrier_sticky, nullptr, 0, 1000000}, {"round_blocks", &t.round_blocks, nullptr, 1, 65536},
+		{"tail_groups", &t.tail_groups, nullptr, 1, 64}, {"dup_groups", &t.dup_groups, nullptr, 0, 1},
+		{"lazy_alt", &t.lazy_alt, nullptr, 0, 8}, {"self_help", &t.self_help, nullptr, 0, 1}, {"plans", &t.plans, nullptr, 0, 1},
+		{"merge_round2", &t.merge_round2, nullptr, 0, 2}, {"merge_max", nullptr, &t.merge_max, 0, 1ll << 40},
+#ifdef MKV_DIAGNOSTICS
+		{"search_wide", &mkv::diag_tuning().search_wide, nullptr, 0, 1}, {"search_lds", &mkv::diag_tuning().search_lds, nullptr, 0, 1},
+		{"pack_three_pass", &mkv::diag_tuning().pack_three_pass, nullptr, 0, 1},
+		{"grid_min", &mkv::diag_tuning().grid_min, nullptr, 0, 1ll << 30},
+		{"grid_progress", &mkv::diag_tuning().grid_progress, nullptr, 0, 1ll << 30},
+		{"calm_factor", &mkv::diag_tuning().calm_factor, nullptr, 1, 64},
+		{"mark_alone_blocks", &mkv::diag_tuning().mark_alone_blocks, nullptr, 1, 65536},
+		{"debug_first_stamp", nullptr, &mkv::diag_tuning().debug_first_stamp, 0, 1ll << 40},
+		{"debug_skip", &mkv::diag_tuning().debug_skip, nullptr, 0, 7},
+#endif
+	};
 	if (!strcmp(name, "search_u")) {
 		if (value != 1 && value != 2 && value != 4 && value != 8)
 			return MKV_EINVAL;
 		t.search_u = (int)value;
-	} else if (!strcmp(name, "search_nt")) {
-		t.search_nt = value != 0;
-#ifdef MKV_DIAGNOSTICS
-	} else if (!strcmp(name, "search_wide")) {
-		t.search_wide = value != 0;
-	} else if (!strcmp(name, "search_lds")) {
-		t.search_lds = value != 0;
-#endif
-	} else if (!strcmp(name, "tail_rounds")) {
-		if (value < 0 || value > 48)
-			return MKV_EINVAL;
-		t.tail_rounds = (int)value;
-	} else if (!strcmp(name, "insert_chunk")) {
+		return MKV_OK;
+	}
+	if (!strcmp(name, "insert_chunk")) {
 		if (value < 1024)
 			return MKV_EINVAL;
 		t.insert_chunk = value & ~15ll;
-	} else if (!strcmp(name, "mark_blocks")) {
-		if (value < 1 || value > 1024)
-			return MKV_EINVAL;
-		t.mark_blocks = (int)value;
-#ifdef MKV_DIAGNOSTICS
-	} else if (!strcmp(name, "pack_three_pass")) {
-		t.pack_three_pass = value != 0;
-#endif
-	} else if (!strcmp(name, "pack_threads")) {
+		return MKV_OK;
+	}
+	if (!strcmp(name, "pack_threads")) {
 		if (value != 256 && value != 512 && value != 1024)
 			return MKV_EINVAL;
 		t.pack_threads = (int)value;
-	} else if (!strcmp(name, "barrier_sticky")) {
-		if (value < 0 || value > 1000000)
-			return MKV_EINVAL;
-		t.barrier_sticky = (int)value;
-	} else if (!strcmp(name, "barrier_split")) {
-		if (value < 1 || value > 64)
-			return MKV_EINVAL;
-		t.barrier_split = (int)value;
-	} else if (!strcmp(name, "grid_min")) {
-		if (value < 0 || value > (1ll << 30))
-			return MKV_EINVAL;
-		t.grid_min = (int)value;
-	} else if (!strcmp(name, "grid_progress")) {
-		if (value < 0 || value > (1ll << 30))
-			return MKV_EINVAL;
-		t.grid_progress = (int)value;
-	} else if (!strcmp(name, "calm_factor")) {
-		if (value < 1 || value > 64)
-			return MKV_EINVAL;
-		t.calm_factor = (int)value;
-	} else if (!strcmp(name, "tail_groups")) {
-		if (value < 1 || value > 64)
-			return MKV_EINVAL;
-		t.tail_groups = (int)value;
-	} else if (!strcmp(name, "round_blocks")) {
-		if (value < 1 || value > 65536)
-			return MKV_EINVAL;
-		t.round_blocks = (int)value;
-	} else if (!strcmp(name, "mark_alone_blocks")) {
-		if (value < 1 || value > 65536)
-			return MKV_EINVAL;
-		t.mark_alone_blocks = (int)value;
-#ifdef MKV_DIAGNOSTICS
-	} else if (!strcmp(name, "debug_first_stamp")) {
-		t.debug_first_stamp = value;
-#endif
-	} else if (!strcmp(name, "dup_groups")) {
-		t.dup_groups = value != 0;
-	} else if (!strcmp(name, "lazy_alt")) {
-		if (value < 0 || value > 8)
-			return MKV_EINVAL;
-		t.lazy_alt = (int)value;
-	} else if (!strcmp(name, "self_help")) {
-		t.self_help = value != 0;
-	} else if (!strcmp(name, "plans")) {
-		t.plans = value != 0;
-	} else if (!strcmp(name, "merge_round2")) {
-		if (value < 0 || value > 2)
-			return MKV_EINVAL;
-		t.merge_round2 = (int)value;
-	} else if (!strcmp(name, "merge_max")) {
-		if (value < 0)
-			return MKV_EINVAL;
-		t.merge_max = value;
-#ifdef MKV_DIAGNOSTICS
-	} else if (!strcmp(name, "debug_skip")) {
-		t.debug_skip = (int)value;
-#endif
-	} else if (!strcmp(name, "req_cap")) {
-		if (value < 1024)
-			return MKV_EINVAL;
-		t.req_cap = value;
-	} else {
-		return MKV_EINVAL;
+		return MKV_OK;
 	}
-	return MKV_OK;
+	for (const Knob &k : knobs) {
+		if (strcmp(name, k.name))
+			continue;
+		if (value < k.lo || value > k.hi)
+			return MKV_EINVAL;
+		if (k.i)
+			*k.i = (int)value;
+		else
+			*k.ll = value;
+		return MKV_OK;
+	}
+	return MKV_EINVAL;      // (unknown here: a diagnostics-only knob in the product library, say)
 }
 
 // the fused search+mark kernel of mkv_cycle is built for the default search tuning
 extern "C" int mkv_tuning_is_default_search(void)
 {
 	const mkv::Tuning &t = mkv::tuning();
-	return t.search_u == 4 && t.search_nt == 0 && t.search_wide == 0 && t.search_lds == 0;
+	return t.search_u == 4 && t.search_nt == 0 && MKV_DIAG(search_wide) == 0 && MKV_DIAG(search_lds) == 0;
 }
 
 #ifdef MKV_DIAGNOSTICS

@@ -258,7 +258,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = ok && hipMemsetAsync(w->lost, 0, (size_t)rc * 4, stream) == hipSuccess;
 		if (ok)
 			hipLaunchKernelGGL(k_init_ctl, dim3(1), dim3(64), 0, stream, w->ctl,
-					(unsigned long long)(tuning().debug_first_stamp > 0 ? tuning().debug_first_stamp : 1), w->host_flag_dev);
+					(unsigned long long)(MKV_DIAG(debug_first_stamp) > 0 ? MKV_DIAG(debug_first_stamp) : 1), w->host_flag_dev);
 		// the buffers are shared by all streams: they are ready before any other stream uses them
 		ok = ok && hipStreamSynchronize(stream) == hipSuccess;
 	}
@@ -402,7 +402,7 @@ template <Op OP>
 static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream,
 		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
-	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)tuning().mark_alone_blocks), dim3(256), 0, stream, w->ctl, src, g,
+	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)MKV_DIAG(mark_alone_blocks)), dim3(256), 0, stream, w->ctl, src, g,
 			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt | (w->barrier_score > 0 ? 0x100 : 0),
 			tuning().plans ? w->undo : nullptr, w->lost);
 }
@@ -459,8 +459,8 @@ static Chunking pick_chunking(Workspace *w, long long hint, bool cuckoo)
 	if (!cuckoo || hint <= 0)
 		return k;
 	long long c = tuning().insert_chunk;
-	if (!lately && tuning().calm_factor > 1)
-		c *= tuning().calm_factor;
+	if (!lately && MKV_DIAG(calm_factor) > 1)
+		c *= MKV_DIAG(calm_factor);
 	if (hint <= c)
 		return k;
 	const long long n = (hint + c - 1) / c;
@@ -580,7 +580,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	// what the rounds are told about the tuning: bit 2 -- every eviction chain left to the tail (tests);
 	// bit 3 -- no groups of duplicates; bit 5 -- no self-help of a bucket's second registrant
 	// bit 6 -- round 1 carries out the mark pass's plans (kPlanBit)
-	const int rhint = (tuning().debug_skip & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32) |
+	const int rhint = (MKV_DIAG(debug_skip) & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32) |
 			(plans_ok && tuning().plans ? 64 : 0);
 #if defined(MKV_EXP_ROUND1) && MKV_EXP_ROUND1 == 1
 	if (0)      // launch-floor experiment (timing only): no round 1
@@ -622,7 +622,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
 			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min, (uint32_t)tuning().grid_progress, tuning().debug_skip & 3,
+			last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min), (uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3,
 			merged ? rhint : -1, (uint32_t)w->req_cap);
 #ifdef MKV_EXP_EXTRA_LAUNCH
 	// launch-floor experiment (timing only; tools/probes/README): one more launch behind the tail --
@@ -631,8 +631,8 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (MKV_EXP_EXTRA_LAUNCH == 1)
 		hipLaunchKernelGGL(k_exp_trivial_tail, dim3(tail_groups_for<OP>()), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[2],
 				w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
-				tail_rounds, lo, hi, first_chunk, last_chunk, w->host_flag_dev, (uint32_t)tuning().grid_min,
-				(uint32_t)tuning().grid_progress, tuning().debug_skip & 3, merged ? rhint : -1, (uint32_t)w->req_cap);
+				tail_rounds, lo, hi, first_chunk, last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min),
+				(uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3, merged ? rhint : -1, (uint32_t)w->req_cap);
 	else if (MKV_EXP_EXTRA_LAUNCH == 2)
 		hipLaunchKernelGGL(k_exp_trivial, dim3(1), dim3(64), 0, stream, w->ctl);
 	else

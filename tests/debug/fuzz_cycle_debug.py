@@ -26,7 +26,7 @@ og = ogeom(g)
 L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 3, 48])))
 L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 8192, 65536])))
 L.mkv_set_tuning(b"tail_groups", int(rng.choice([1, 5, 32])))
-L.mkv_set_tuning(b"grid_min", int(rng.choice([0, 64, 2048])))
+L.mkv_set_tuning(b"grid_min", int(rng.choice([0, 64, 2048])))      # (diagnostics build only)
 for k, v in over.items():
     L.mkv_set_tuning(k.encode(), int(v))
 sig_space = int(rng.choice([40, 5000, 1 << 20]))

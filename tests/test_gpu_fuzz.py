@@ -26,9 +26,9 @@ def _defaults():
         L.mkv_set_tuning(b"tail_rounds", 48)
         L.mkv_set_tuning(b"insert_chunk", 65536)
         L.mkv_set_tuning(b"tail_groups", 32)
-        L.mkv_set_tuning(b"grid_min", 2048)
-        L.mkv_set_tuning(b"calm_factor", 4)
         if diag:
+            L.mkv_set_tuning(b"grid_min", 2048)
+            L.mkv_set_tuning(b"calm_factor", 1)
             L.mkv_set_tuning(b"debug_skip", 0)
         L.mkv_set_tuning(b"round_blocks", 512)
         L.mkv_set_tuning(b"self_help", 1)
@@ -73,7 +73,6 @@ def test_order_violations_of_late_chains(path, chunk):
     if path:
         assert L.mkv_set_tuning(b"debug_skip", path) == 0
     L.mkv_set_tuning(b"insert_chunk", chunk)
-    L.mkv_set_tuning(b"calm_factor", 1)
     g = Geometry(mem_p=20)
     og = ogeom(g)
     rng = np.random.default_rng(31 + path)
@@ -121,6 +120,9 @@ def test_rounds_on_more_work_groups_than_list_places(blocks):
     assert listed > 0                                    # the tail did have work
 
 
+DIAG_ONLY = (b"grid_min", b"grid_progress", b"calm_factor", b"mark_alone_blocks", b"debug_skip", b"debug_first_stamp")
+
+
 def _run(seed, forced):
     rng = np.random.default_rng(1000 + seed)
     env = __import__("os").environ
@@ -131,7 +133,12 @@ def _run(seed, forced):
     rng3 = np.random.default_rng(11000 + seed)
     skip = int(rng3.choice([0, 0, 1, 2])) + int(rng3.choice([0, 0, 0, 4]))
     skip = int(env.get("MKV_FUZZ_DEBUG_SKIP", forced.get(b"debug_skip", skip)))
-    L = load_library(diagnostics=skip != 0)
+    # The knobs of tests and probes (DIAG_ONLY) exist in the diagnostics build only -- the same sources; the
+    # product library has their defaults as constants.  A case that forces one of them, and every other seed,
+    # runs on the diagnostics build with all knobs drawn; the rest on the product library with its own sixteen.
+    diag = skip != 0 or seed % 2 == 1 or any(k in DIAG_ONLY for k in forced) or \
+        any(("MKV_FUZZ_" + k.decode().upper()) in env for k in DIAG_ONLY)
+    L = load_library(diagnostics=diag)
     big = int(env.get("MKV_FUZZ_BIG", "0"))          # 1: tables up to 2 MiB, batches up to 300 K requests
     mem_p = int(rng.integers(10, 19)) + (int(rng.integers(0, 4)) if big else 0)
     iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
@@ -143,8 +150,9 @@ def _run(seed, forced):
     L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 2048, 8192, 65536])))
     rng2 = np.random.default_rng(5000 + seed)        # tail shape: work-groups, grid-wide rounds, calm-mode chunks
     L.mkv_set_tuning(b"tail_groups", int(rng2.choice([1, 2, 5, 32])))
-    L.mkv_set_tuning(b"grid_min", int(rng2.choice([0, 0, 64, 2048])))
-    L.mkv_set_tuning(b"calm_factor", int(rng2.choice([1, 4])))
+    gm, cf = int(rng2.choice([0, 0, 64, 2048])), int(rng2.choice([1, 4]))
+    if diag:
+        assert L.mkv_set_tuning(b"grid_min", gm) == 0 and L.mkv_set_tuning(b"calm_factor", cf) == 0
     if skip:
         assert L.mkv_set_tuning(b"debug_skip", skip) == 0
     # work-groups of rounds 1 and 2: few make a work-group's queue of held-back requests run over
@@ -161,10 +169,10 @@ def _run(seed, forced):
                  b"self_help", b"merge_round2", b"plans"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
-            L.mkv_set_tuning(name, int(v))
+            assert L.mkv_set_tuning(name, int(v)) == 0, name
     for name, v in forced.items():
         if name != b"debug_skip":
-            L.mkv_set_tuning(name, int(v))
+            assert L.mkv_set_tuning(name, int(v)) == 0, name
     fill = float(rng.choice([0.0, 0.3, 0.6, 0.85, 0.97]))
     sig_space = int(rng.choice([40, 5000, 1 << 20, 1 << 31]))
     exp = random_table(g, rng, fill, sig_space)
@@ -223,17 +231,20 @@ def test_fuzz_cycles(seed):
 def test_fuzz_cycles_without_deletes(seed):
     """The same without deletes, always fused, one pass -- the shape of bench.py's step -- on 1, 3, 40
     or 128 mark work-groups."""
-    L = load_library()
-    L.mkv_set_tuning(b"mark_blocks", int(np.random.default_rng(13000 + seed).choice([1, 3, 40, 128])))
+    mb = int(np.random.default_rng(13000 + seed).choice([1, 3, 40, 128]))
+    for d in (False, True):
+        load_library(d).mkv_set_tuning(b"mark_blocks", mb)
     try:
         _run_cycles(seed, deletes=False)
     finally:
-        L.mkv_set_tuning(b"mark_blocks", 208)
+        for d in (False, True):
+            load_library(d).mkv_set_tuning(b"mark_blocks", 208)
 
 
 def _run_cycles(seed, deletes):
     rng = np.random.default_rng(9000 + seed)
-    L = load_library()
+    diag = seed % 2 == 1                             # (every other seed on the diagnostics build, whose tail has all its knobs)
+    L = load_library(diagnostics=diag)
     mem_p = int(rng.integers(10, 19))
     iblock_p = int(rng.integers(0, min(5, mem_p - 7) + 1))
     scheme = int(rng.integers(0, 2))
@@ -242,7 +253,9 @@ def _run_cycles(seed, deletes):
     L.mkv_set_tuning(b"tail_rounds", int(rng.choice([0, 3, 48])))
     L.mkv_set_tuning(b"insert_chunk", int(rng.choice([1024, 8192, 65536])))
     L.mkv_set_tuning(b"tail_groups", int(rng.choice([1, 5, 32])))
-    L.mkv_set_tuning(b"grid_min", int(rng.choice([0, 64, 2048])))
+    gm = int(rng.choice([0, 64, 2048]))
+    if diag:
+        assert L.mkv_set_tuning(b"grid_min", gm) == 0
     rng4 = np.random.default_rng(17000 + seed)
     L.mkv_set_tuning(b"self_help", int(rng4.choice([1, 1, 0])))
     L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
@@ -251,7 +264,7 @@ def _run_cycles(seed, deletes):
         L.mkv_set_tuning(b"insert_chunk", 65536)     # (one pass)
     sig_space = int(rng.choice([40, 5000, 1 << 20]))
     exp = random_table(g, rng, float(rng.choice([0.0, 0.3, 0.7, 0.9])), sig_space)
-    idx = HashIndex(g)
+    idx = HashIndex(g, lib=L)
     idx.load_table(exp)
     nslots = g.nbuckets * 8
     memset = bool(rng.integers(0, 2))

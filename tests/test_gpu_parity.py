@@ -37,9 +37,11 @@ def test_product_library_has_no_diagnostics():
     L, D = load_library(), load_library(diagnostics=True)
     for name in ("mkv_debug_request", "mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read"):
         assert not hasattr(L, name) and hasattr(D, name)
-    for name in (b"debug_skip", b"debug_first_stamp", b"search_wide", b"search_lds", b"pack_three_pass"):
-        assert L.mkv_set_tuning(name, 0) != 0
-        assert D.mkv_set_tuning(name, 0) == 0
+    for name, dflt in ((b"debug_skip", 0), (b"debug_first_stamp", 0), (b"search_wide", 0), (b"search_lds", 0),
+                       (b"pack_three_pass", 0), (b"grid_min", 2048), (b"grid_progress", 96), (b"calm_factor", 1),
+                       (b"mark_alone_blocks", 1024)):
+        assert L.mkv_set_tuning(name, dflt) != 0
+        assert D.mkv_set_tuning(name, dflt) == 0
 
 
 # ---------------------------------------------------------------- search ----
