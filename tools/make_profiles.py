@@ -35,6 +35,16 @@ def short(n):
     return s
 
 
+def library_id(raw):
+    """the library build the passes ran with: the `library` word of the line the stats run printed
+    (bench.py: roofline.library = the last word of mkv_version(), a digest of the library's sources)"""
+    try:
+        line = [ln for ln in open(os.path.join(raw, "stats.json")).read().splitlines() if ln.startswith("{")][-1]
+        return (json.loads(line).get("roofline") or {}).get("library")
+    except Exception:
+        return None
+
+
 def steps_of(rows, key="k_search_mark"):
     """indices of the rows that start a step (the dominant kernel's dispatches)"""
     return [i for i, r in enumerate(rows) if key in r["Kernel_Name"]]
@@ -61,7 +71,7 @@ def main():
     trows = sorted(csv.DictReader(open(tr)), key=lambda r: int(r["Start_Timestamp"]))
     marks = steps_of(trows, dom)
     marks_set = set(marks)
-    summary = {"round": rnd, "tag": tag, "head": head, "warmup": W, "steps": K,
+    summary = {"round": rnd, "tag": tag, "head": head, "library": library_id(raw), "warmup": W, "steps": K,
                "command": open(os.path.join(raw, "stats.err")).read()[:0] or "python3 bench.py " + " ".join(sys.argv[8:]), "repeats": R}
 
     cycle = ("k_search_mark", "k_search<", "k_round", "k_tail", "k_mark", "k_search_slots")
@@ -135,7 +145,8 @@ def main():
             "note": "FETCH_SIZE + WRITE_SIZE (KB x 1024) per launch, separate --pmc passes, the timed region's "
                     "dispatches only; calibrated on uniform GETs: random 64-B bucket reads are tallied exactly, "
                     "the coalesced request stream at one half (gfx950 FETCH_SIZE rule) -- DESIGN.md 'measurement'",
-            "l2": {c: pmc[k][c] for c in pmc[k] if c.startswith("TCC_")}, "source": name, "head": head}
+            "l2": {c: pmc[k][c] for c in pmc[k] if c.startswith("TCC_")}, "source": name, "head": head,
+            "library": library_id(raw)}
         json.dump(d, open(tp, "w"), indent=1)
     print(json.dumps(summary, indent=1)[:2500])
 
