@@ -1,11 +1,6 @@
 #!/bin/bash
 cd "$GRAFT_REPO_ROOT"
-bash tools/collect_profiles.sh driver --steps 20 --warmup 5 2>&1 | tail -6
-bash tools/collect_profiles.sh default 2>&1 | tail -6
-PMC=1 bash tools/collect_profiles.sh get100 --workload get100 --no-pcie 2>&1 | tail -6
-PMC=1 bash tools/collect_profiles.sh zipf50 --workload zipf50 --steps 20 --warmup 5 --no-cpu --no-pcie 2>&1 | tail -6
-du -sh gpurun_out/profiles_raw
-# keep what make_profiles.py needs, drop the rest (the merge back is limited to 64 MiB)
-find gpurun_out/profiles_raw -name "*agent_info*" -delete
-find gpurun_out/profiles_raw -name "*domain_stats*" -delete
-du -sh gpurun_out/profiles_raw
+export MKV_FUZZ_CYCLE_CASES=400 MKV_FUZZ_NODEL_CASES=400
+bash tools/fuzz_campaign.sh 6000 2>&1 | tee gpurun_out/fuzz_r05.txt
+echo "== big tables"; MKV_FUZZ_BIG=1 MKV_FUZZ_CASES=600 MKV_FUZZ_CYCLE_CASES=24 MKV_FUZZ_NODEL_CASES=24 timeout 3000 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | grep -E "passed|failed" | tail -1 | tee -a gpurun_out/fuzz_r05.txt
+echo "== cycles"; MKV_FUZZ_CASES=8 MKV_FUZZ_CYCLE_CASES=3000 MKV_FUZZ_NODEL_CASES=3000 timeout 3000 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | grep -E "passed|failed" | tail -1 | tee -a gpurun_out/fuzz_r05.txt
