@@ -185,7 +185,8 @@ def launch_ranks(n):
     return subprocess.call(cmd, env=env)
 
 
-PREFLIGHT_S = 60.0
+PREFLIGHT_S = 60.0              # per phase of the transport check
+PREFLIGHT_STARTUP_S = 300.0     # ... and for its child process to come up (a first `import torch` on a fresh box)
 
 
 def preflight_child(args):
@@ -253,20 +254,37 @@ def preflight_check(args):
     env.pop("TORCHELASTIC_USE_AGENT_STORE", None)      # (rank 0's child serves the children's store itself)
     cmd = [sys.executable, os.path.abspath(__file__), "--preflight", "--scheme", args.scheme]
     child = subprocess.Popen(cmd, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
-    try:
-        _, err = child.communicate(timeout=PREFLIGHT_S)
-        timed_out = False
-    except subprocess.TimeoutExpired:
-        child.kill()                                 # (this very process: the PID we started)
-        _, err = child.communicate()
-        timed_out = True
-    phases = [ln.split(":", 1)[1].strip() for ln in err.splitlines() if ln.startswith("preflight phase:")]
+    # The deadline runs per PHASE, from the line that announces it: importing torch in a fresh container can take a
+    # minute or two by itself (the image pages in) and is no sign of a transport that hangs.
+    import threading
+    seen = {"phases": [], "t": time.time(), "tail": []}
+
+    def reader():
+        for ln in child.stderr:
+            ln = ln.rstrip()
+            if ln.startswith("preflight phase:"):
+                seen["phases"].append(ln.split(":", 1)[1].strip())
+                seen["t"] = time.time()
+            elif ln:
+                seen["tail"] = (seen["tail"] + [ln])[-6:]
+    th = threading.Thread(target=reader, daemon=True)
+    th.start()
+    timed_out = False
+    while child.poll() is None:
+        limit = PREFLIGHT_S if seen["phases"] else PREFLIGHT_STARTUP_S
+        if time.time() - seen["t"] > limit:
+            child.kill()                             # (this very process: the PID we started)
+            timed_out = True
+            break
+        time.sleep(0.2)
+    child.wait()
+    th.join(timeout=5)
     if child.returncode == 0 and not timed_out:
         return None
-    last = phases[-1] if phases else "start-up (importing torch)"
-    tail = " | ".join(ln for ln in err.splitlines()[-6:] if not ln.startswith("preflight phase:"))
-    return (f"{'no answer within %.0f s in' % PREFLIGHT_S if timed_out else 'failed in'} phase \"{last}\""
-            + (f": {tail}" if tail else ""))
+    last = seen["phases"][-1] if seen["phases"] else "start-up (importing torch)"
+    tail = " | ".join(seen["tail"])
+    return (f"{'no answer within %.0f s in' % (PREFLIGHT_S if seen['phases'] else PREFLIGHT_STARTUP_S) if timed_out else 'failed in'} "
+            f"phase \"{last}\"" + (f": {tail}" if tail else ""))
 
 
 def main():

@@ -167,6 +167,7 @@ struct Ctl {
 	uint32_t tail_rounds_used;       // stamps the tail consumed beyond rounds 1 and 2
 	uint32_t hf_last[2];             // what the host-mapped flag words hold (they are written only when they change)
 	uint32_t hf_losers;              // ... and word 3: round 1 left many requests to round 2 in the last pass
+	uint32_t hf_walk;                // ... and word 4: one request in sixteen (or more) ran an eviction chain in the last pass
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
@@ -970,8 +971,9 @@ __device__ __forceinline__ void prewalk_register(const uint32_t *table, const De
 	const uint32_t v = r.sig & 7u;              // victim slot: ORIGINAL signature (ref :360)
 	// (flagging: the walk's registrations are returning atomics too and flag whom they displace, like all the
 	// others -- the plans of the pass stand, kPlanBit; else they are not, and the pass says so: round 1 then reads
-	// every reservation.  The host asks for the second form while chains have been running late -- a well-filled
-	// table, thousands of walks per pass: the returning atomic per step made the fused launch a third longer there.)
+	// every reservation.  The host asks for the second form while one request in sixteen or more has been walking a
+	// chain (the tail launch's epilogue says so through its host-mapped word 4) -- a well-filled table, thousands of
+	// walks per pass: the returning atomic per step made the fused launch a third longer there.)
 	if (g.max_cuckoo != 0u && !flagging)
 		*hint_stamp = lost.s32;
 	for (uint32_t k = 0; k < g.max_cuckoo; k++) {

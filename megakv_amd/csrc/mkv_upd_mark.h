@@ -10,7 +10,7 @@ namespace mkv {
 
 // ---- K1: mark -----------------------------------------------------------------
 // (undo, lost_flags: where the plans and the flags of kPlanBit go -- null: none are made)
-// (lazy_free: Tuning::lazy_alt; bit 8: chains have been running late -- the walks ahead do not flag, prewalk_register)
+// (lazy_free: Tuning::lazy_alt; bit 8: the last passes walked many eviction chains -- the walks ahead do not flag, prewalk_register)
 template <Op OP>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap,
@@ -78,7 +78,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		// The tail launch of this pass leaves at once if the rounds leave it nothing -- unless its epilogue has
 		// something to tell the host (a dropped batch to count, a flag word that may have to change back, round
 		// stamps running low)
-		ctl->force_tail = (over || ctl->hf_last[0] != 0u || ctl->hf_last[1] != 0u || ctl->hf_losers != 0u ||
+		ctl->force_tail = (over || ctl->hf_last[0] != 0u || ctl->hf_last[1] != 0u || ctl->hf_losers != 0u || ctl->hf_walk != 0u ||
 				stamp > kStampMax - kStampReserve) ? 1u : 0u;
 		if (ep_pending) {
 			// ... in which case what the epilogue would have reset is reset here

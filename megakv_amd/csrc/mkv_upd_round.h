@@ -496,8 +496,10 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 						else
 							ctl->loose = ctl->any_tail = 1u;    // (work for the tail even if nothing else is)
 					}
-					if (chained)
+					if (chained) {
 						atomicAdd(&ctl->chain_ok, 1u);
+						ctl->force_tail = 1u;           // (the epilogue reports the pass's share of chains to the host)
+					}
 					ndone++;
 					done = true;
 				}

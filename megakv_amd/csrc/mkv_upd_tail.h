@@ -1773,6 +1773,13 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 			}
 			if (ctl->overflow)
 				host_flag[2] = host_flag[2] + 1u;
+			// word 4: the pass walked many eviction chains (a well-filled table) -- the host then has the next mark
+			// passes' walks ahead register without returning atomics (prewalk_register)
+			const uint32_t f4 = ctl->chain_n * 16u > total_all ? 1u : 0u;
+			if (f4 != ctl->hf_walk) {
+				host_flag[4] = f4;
+				ctl->hf_walk = f4;
+			}
 		}
 		ctl->hard_tail = 0;
 		ctl->chain_n = 0;
@@ -1864,30 +1871,30 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// tags by 32 work-groups, no meeting behind it; the others read the same records, decide alike and leave.
 	__shared__ uint32_t s_few_n, s_few_bad, s_few[kFewLosers], s_rec[3];
 	bool few = false;
-	if (t == 0) {
-		s_few_n = 0u;
-		s_few_bad = 0u;
-		s_rec[0] = s_rec[1] = s_rec[2] = 0u;
-	}
-	__syncthreads();
-	{
-		// the records' sums (lanes beyond the records hold zeros)
-		uint32_t a = rec_stat.y, b = rec_stat.z, c = rec_stat.w;
-		if (__ballot(a | b | c)) {
-			for (int off = 32; off > 0; off >>= 1) {
-				a += __shfl_down(a, off);
-				b += __shfl_down(b, off);
-				c += __shfl_down(c, off);
-			}
-			if ((t & 63u) == 0u) {
-				if (a) atomicAdd(&s_rec[0], a);
-				if (b) atomicAdd(&s_rec[1], b);
-				if (c) atomicAdd(&s_rec[2], c);
-			}
-		}
-	}
+	// the records' sums (lanes beyond the records hold zeros): added up where the launch has a barrier anyway
+#define MKV_SUM_RECS()                                                                  \
+	do {                                                                                \
+		uint32_t a_ = rec_stat.y, b_ = rec_stat.z, c_ = rec_stat.w;                     \
+		if (__ballot(a_ | b_ | c_)) {                                                   \
+			for (int off = 32; off > 0; off >>= 1) {                                    \
+				a_ += __shfl_down(a_, off);                                             \
+				b_ += __shfl_down(b_, off);                                             \
+				c_ += __shfl_down(c_, off);                                             \
+			}                                                                           \
+			if ((t & 63u) == 0u) {                                                      \
+				if (a_) atomicAdd(&s_rec[0], a_);                                       \
+				if (b_) atomicAdd(&s_rec[1], b_);                                       \
+				if (c_) atomicAdd(&s_rec[2], c_);                                       \
+			}                                                                           \
+		}                                                                               \
+	} while (0)
 	const bool try_few = round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u && first_chunk && last_chunk;
 	if (try_few) {
+		if (t == 0) {
+			s_few_n = 0u;
+			s_few_bad = 0u;
+		}
+		__syncthreads();
 		if (t < kTlGroups) {
 			const uint32_t nl = rec_stat.w;
 			if (nl > kLlPer) {
@@ -1904,8 +1911,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 				}
 			}
 		}
+		__syncthreads();
 	}
-	__syncthreads();
 	few = try_few && s_few_bad == 0u && s_few_n != 0u;      // (none listed: round 1 ran on more work-groups than it has records for)
 	if (few) {
 		if (wg != 0)
@@ -1934,8 +1941,14 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// next pass.
 	const uint32_t p_any_tail = ld_agent32(&ctl->any_tail);
 	if (p_any_tail == 0u) {
-		if (wg == 0)
+		if (wg == 0) {
+			if (t == 0)
+				s_rec[0] = s_rec[1] = s_rec[2] = 0u;
+			__syncthreads();
+			MKV_SUM_RECS();
+			__syncthreads();
 			tail_epilogue<true>(ctl, nullptr, 0u, total_all, 0u, 0u, 0u, 0u, first_chunk, last_chunk, host_flag, s_rec);
+		}
 		return;
 	}
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
@@ -1947,8 +1960,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	if (t == 0) {
 		s_tl_total = 0u;
 		s_tl_over = 0u;
+		s_rec[0] = s_rec[1] = s_rec[2] = 0u;
 	}
 	__syncthreads();
+	MKV_SUM_RECS();          // (read behind the next barrier: s_done12 below, the epilogue at the end)
 	const bool list_ok = first_chunk && last_chunk && carry_in >= lo_idx && ctl->loose == 0u && p_any_tail != 0u;
 	const uint32_t tl_g1 = list_ok ? ctl->tl_groups[0] : 0u;
 	const uint32_t tl_g2 = list_ok && ctl->any_loser != 0u ? ctl->tl_groups[1] : 0u;    // (round 2 leaves at once without losers)
@@ -2275,7 +2290,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 	const uint32_t t = threadIdx.x;
 	if (t == 0) {
 		if (host_flag)
-			host_flag[0] = host_flag[1] = host_flag[3] = 0;     // (in step with hf_last / hf_losers below)
+			host_flag[0] = host_flag[1] = host_flag[3] = host_flag[4] = 0;     // (in step with hf_last / hf_losers / hf_walk below)
 		ctl->stamp_base = ctl->stamp_cur = first_stamp;
 		ctl->ep_pending = 0;
 		ctl->total = 0;
@@ -2298,6 +2313,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->hard_tail = 0;
 		ctl->hf_last[0] = ctl->hf_last[1] = 0;
 		ctl->hf_losers = 0;
+		ctl->hf_walk = 0;
 		for (int k = 0; k < 8; k++)
 			ctl->dbg[k] = 0;
 	}

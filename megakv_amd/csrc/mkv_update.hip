@@ -242,7 +242,7 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 		ok = hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess;
 		if (ok) {
 			w->host_flag = reinterpret_cast<volatile uint32_t *>(hf);
-			w->host_flag[0] = w->host_flag[1] = 0;
+			w->host_flag[0] = w->host_flag[1] = w->host_flag[3] = w->host_flag[4] = 0;
 			w->host_flag[2] = dropped_seen;          // (the count goes on over a regrown workspace)
 			w->dropped_seen = dropped_seen;
 			void *dp = nullptr;
@@ -403,7 +403,7 @@ static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipSt
 		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
 	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)MKV_DIAG(mark_alone_blocks)), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt | (w->barrier_score > 0 ? 0x100 : 0),
+			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0),
 			tuning().plans ? w->undo : nullptr, w->lost);
 }
 
@@ -764,11 +764,11 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
-				mkv::tuning().lazy_alt | (w->barrier_score > 0 ? 0x100 : 0), mkv::tuning().plans ? w->undo : nullptr, w->lost);
+				mkv::tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0), mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
-				mkv::tuning().lazy_alt | (w->barrier_score > 0 ? 0x100 : 0), mkv::tuning().plans ? w->undo : nullptr, w->lost);
+				mkv::tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0), mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -897,12 +897,12 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 	if (cuckoo)
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_CUCKOO>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt | (w->barrier_score > 0 ? 0x100 : 0),
+				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0),
 				mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	else
 		MKV_LAUNCH_TIMED((mkv::k_search_slots_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, recvbuf, slot_words,
 				(uint32_t)cap_get, out_slots, t4, chunks ? chunks : 1u, search_blocks, w->ctl, src, d,
-				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt | (w->barrier_score > 0 ? 0x100 : 0),
+				w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi, self_u, self_out, mkv::tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0),
 				mkv::tuning().plans ? w->undo : nullptr, w->lost);
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	for (int c = 0; c < nchunks; c++) {
