@@ -29,10 +29,11 @@ __device__ __forceinline__ void tail_list_add(uint32_t *s_tl, uint32_t *s_tln, u
 }
 
 // ... and round 1 what it leaves to round 2: the first kLlPer per work-group (the count is in its record, Ctl::wg_rec)
-__device__ __forceinline__ void loser_list_add(uint32_t *s_ll, uint32_t *s_lln, uint32_t idx, bool add)
+__device__ __forceinline__ void loser_list_add(uint32_t *s_ll, volatile uint32_t *s_lln, uint32_t idx, bool add)
 {
-	if (add) {
-		const uint32_t at = atomicAdd(s_lln, 1u);
+	// (once the list is full nobody queues on its counter: a pass of duplicates leaves a work-group a hundred losers)
+	if (add && *s_lln < kLlPer) {
+		const uint32_t at = atomicAdd(const_cast<uint32_t *>(s_lln), 1u);
 		if (at < kLlPer)
 			s_ll[at] = idx;
 	}
@@ -573,7 +574,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		const uint32_t n = s_tln;
 		if (threadIdx.x < kTlPer && threadIdx.x < n)
 			ctl->tl[0][block][threadIdx.x] = s_tl[threadIdx.x];
-		if (threadIdx.x < kLlPer && threadIdx.x < s_lln)
+		if (threadIdx.x < kLlPer && threadIdx.x < s_lln)          // (s_lln may run a little past kLlPer; the count is in the record)
 			ctl->wg_rec[block].ll[threadIdx.x] = s_ll[threadIdx.x];
 		if (threadIdx.x == 0) {
 			ctl->wg_rec[block].stat = make_uint4(n, s_words[4], s_words[5], s_words[6]);
