@@ -271,6 +271,74 @@ __device__ __forceinline__ Bkt load_bucket(const uint32_t *table, uint32_t b)
 	return k;
 }
 
+// ---- a bucket per QUAD of lanes and instruction ---------------------------------------------------------------
+// load_bucket above is four 16-byte loads of one lane: four requests to the memory system for one 64-byte line.  Here
+// the four lanes of a quad fetch the four pieces of ONE bucket with one instruction -- adjacent 16-byte pieces of a
+// line, one request, as in the search kernel -- bucket after bucket of the quad's four, and hand the pieces round
+// afterwards (a 4 x 4 transpose among the quad's lanes, two exchanges over DPP).  Every lane of the wave must be
+// active; b = kNone: no bucket.  (The mark pass of a 2^19-request batch: 47.7 -> 46.7 us of the fused launch; a pass
+// of that size is bound by what the memory side does per request -- atomics, sector writes -- not by their number on
+// the way there: profiles/r05_launch_floor.txt, 10.)
+template <int J>
+__device__ __forceinline__ uint32_t quad_bcast(uint32_t v)
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, J * 0x55, 0xF, 0xF, true);
+}
+
+template <int BIT>
+__device__ __forceinline__ uint32_t quad_swap(uint32_t v)      // BIT 1: lanes 0 <-> 1, 2 <-> 3; BIT 2: lanes 0 <-> 2, 1 <-> 3
+{
+	return (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, BIT == 1 ? 0xB1 : 0x4E, 0xF, 0xF, true);
+}
+
+template <int BIT>
+__device__ __forceinline__ void quad_exchange(uint32_t &lo, uint32_t &hi, bool up)
+{
+	// the lane whose bit BIT is clear gives its `hi` for the partner's `lo`, and the other way round
+	const uint32_t y = quad_swap<BIT>(up ? lo : hi);
+	lo = up ? y : lo;
+	hi = up ? hi : y;
+}
+
+template <int BIT>
+__device__ __forceinline__ void quad_exchange(uint4 &lo, uint4 &hi, bool up)
+{
+	quad_exchange<BIT>(lo.x, hi.x, up);
+	quad_exchange<BIT>(lo.y, hi.y, up);
+	quad_exchange<BIT>(lo.z, hi.z, up);
+	quad_exchange<BIT>(lo.w, hi.w, up);
+}
+
+// lane q's a[j] <-> lane j's a[q], within each quad
+__device__ __forceinline__ void quad_transpose(uint4 &a0, uint4 &a1, uint4 &a2, uint4 &a3)
+{
+	const uint32_t q = threadIdx.x & 3u;
+	quad_exchange<1>(a0, a1, (q & 1u) != 0u);
+	quad_exchange<1>(a2, a3, (q & 1u) != 0u);
+	quad_exchange<2>(a0, a2, (q & 2u) != 0u);
+	quad_exchange<2>(a1, a3, (q & 2u) != 0u);
+}
+
+__device__ __forceinline__ Bkt load_bucket_quad(const uint32_t *table, uint32_t b)
+{
+	const uint32_t q = threadIdx.x & 3u;
+	const uint4 z = make_uint4(0u, 0u, 0u, 0u);
+	const uint32_t b0 = quad_bcast<0>(b), b1 = quad_bcast<1>(b), b2 = quad_bcast<2>(b), b3 = quad_bcast<3>(b);
+	const uint4 *t4 = reinterpret_cast<const uint4 *>(table) + q;
+	uint4 a0 = z, a1 = z, a2 = z, a3 = z;
+	if (b0 != kNone) a0 = t4[(uint64_t)b0 << 2];
+	if (b1 != kNone) a1 = t4[(uint64_t)b1 << 2];
+	if (b2 != kNone) a2 = t4[(uint64_t)b2 << 2];
+	if (b3 != kNone) a3 = t4[(uint64_t)b3 << 2];
+	quad_transpose(a0, a1, a2, a3);
+	Bkt k;
+	k.s0 = a0;
+	k.s1 = a1;
+	k.l0 = a2;
+	k.l1 = a3;
+	return k;
+}
+
 __device__ __forceinline__ uint32_t loc_at(const Bkt &k, uint32_t slot)
 {
 	const uint4 v = (slot & 4u) ? k.l1 : k.l0;

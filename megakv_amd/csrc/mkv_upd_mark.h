@@ -169,9 +169,10 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		// may still be running): room enough there -> no registration on the alternate bucket
 		uint4 plo = make_uint4(1u, 1u, 1u, 1u), phi = plo;
 		bool lazy = false, planned = false;
-		if (OP != OP_DELETE && live && table && (fresh || OP == OP_CUCKOO)) {
-			// (the whole bucket: the same 64-byte request as its signature row)
-			const Bkt kP = load_bucket(table, P);
+		// (the whole bucket: the same 64-byte request as its signature row -- one request, the quad's four lanes a piece each)
+		const bool look = OP != OP_DELETE && live && table && (fresh || OP == OP_CUCKOO);
+		const Bkt kP = OP != OP_DELETE && table ? load_bucket_quad(table, look ? P : kNone) : Bkt();
+		if (look) {
 			plo = kP.s0;
 			phi = kP.s1;
 			lazy = fresh && (lazy_free & 0xffu) != 0u && A != P && (uint32_t)__popc(eq_mask(plo, phi, 0u)) >= (lazy_free & 0xffu);
