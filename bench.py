@@ -105,6 +105,9 @@ def parse(argv=None):
                     help="untimed read-only searches before the warm-up steps, so that a short run (the driver's "
                          "--steps 20 --warmup 5 is 1.5 ms of GPU work) does not measure the clocks ramping up")
     ap.add_argument("--no-events", action="store_true", help="skip per-kernel HIP events (roofline = null)")
+    ap.add_argument("--no-live-traffic", action="store_true",
+                    help="roofline.traffic from the committed counter passes (profiles/search_traffic.json) instead of two "
+                         "child passes of this command's workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; ~15 s each)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
     ap.add_argument("--cpu-batches", type=int, default=400,
@@ -639,6 +642,14 @@ def main():
         achieved = algo_bytes / med_s / 1e9
         fused = not sharded and args.overlap == "fused" and not args.memset and stream_gen.n_set > 0
         traffic, traffic_src, traffic_lib = load_traffic(args, fused, sharded)
+        committed = {"bytes": traffic, "source": traffic_src, "library": traffic_lib}
+        live_why = None
+        if rank == 0 and world == 1 and not sharded and not args.no_live_traffic:
+            # (measured by this run itself, in two child passes under the profiler; the committed passes stay beside it)
+            live, live_why = live_traffic(args, fused)
+            if live is not None:
+                traffic, traffic_src, traffic_lib = live, live_why, library_id(engine)
+                live_why = None
         roofline = {"bound": "hbm",
                     "kernel": "mkv::k_search_mark (search work-groups + the insert's mark work-groups)" if fused
                     else ("mkv::k_search_slots_mark" if sharded else "mkv::k_search"),
@@ -647,6 +658,7 @@ def main():
                     # (the library build the counter passes were taken with -- the last word of its mkv_version() -- beside
                     # this run's: a profile older than the kernels shows as two different words)
                     "traffic_head": traffic_lib, "library": library_id(engine),
+                    "traffic_committed": committed, "traffic_not_live_because": live_why,
                     "algorithmic_bytes_per_launch": algo_bytes,
                     "launch_us": round(med_s * 1e6, 2),
                     "launch_us_is": "median over launches_timed launches of the kernel's own duration: HIP events that "
@@ -1103,6 +1115,74 @@ def library_id(engine):
         return engine.idx.lib.mkv_version().decode().split()[-1]
     except Exception:
         return None
+
+
+def profiler_present():
+    """is this process itself running under a profiler (rocprofv3's tool library in the environment)?"""
+    keys = ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH")
+    return any(os.environ.get(k) for k in keys) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
+
+
+def live_traffic(args, fused):
+    """HBM bytes per launch of the dominant kernel, measured by THIS run: two child processes of this script (the same
+    workload flags, 5 warm-up + 20 steps once, no side legs) under `rocprofv3 --kernel-trace --pmc <counter>`, FETCH_SIZE
+    and WRITE_SIZE each in a pass of its own and with no other trace domain, as MI355X_MICROARCH.md's HBM / rocprofv3
+    section prescribes; the counters are in KB, averaged over the kernel's dispatches behind the warm-up.  Returns
+    (bytes per launch, note) or (None, why not).  The children are started with subprocess -- nothing is exec'ed from
+    this process, which holds the GPU -- and each has 150 s."""
+    import csv
+    import glob
+    import shutil
+    import subprocess
+    import tempfile
+    exe = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if not exe:
+        return None, "no rocprofv3 on this machine"
+    if profiler_present():
+        return None, "this run is itself under a profiler"
+    kern = "k_search_mark" if fused else "k_search<"
+    warm, steps = 5, 20
+    child = ["python3", os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm), "--repeats", "1",
+             "--workload", args.workload, "--keying", args.keying, "--sets", args.sets, "--scheme", args.scheme,
+             "--lf", str(args.lf), "--batch-log2", str(args.batch_log2), "--mem-p", str(args.mem_p), "--overlap", args.overlap,
+             "--no-cpu", "--no-pcie", "--no-abi", "--no-events", "--no-live-traffic", "--prewarm-ms", "0"]
+    if args.memset:
+        child.append("--memset")
+    if args.sorted_gets:
+        child.append("--sorted-gets")
+    env = dict(os.environ, TMPDIR="/tmp")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    got, launches = {}, 0
+    top = tempfile.mkdtemp(prefix="mkv_pmc_", dir="/tmp")
+    try:
+        for counter in ("FETCH_SIZE", "WRITE_SIZE"):
+            out = os.path.join(top, counter)
+            cmd = [exe, "--kernel-trace", "--pmc", counter, "--output-format", "csv", "-d", out, "--"] + child
+            try:
+                r = subprocess.run(cmd, cwd=ROOT, env=env, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, timeout=150)
+            except subprocess.TimeoutExpired:
+                return None, f"the {counter} pass did not finish in 150 s"
+            files = glob.glob(os.path.join(out, "**", "*counter_collection.csv"), recursive=True)
+            if r.returncode != 0 or not files:
+                tail = (r.stderr or b"").decode(errors="replace").strip().splitlines()[-1:]
+                return None, f"the {counter} pass failed (exit {r.returncode}{': ' + tail[0][:120] if tail else ''})"
+            per = {}
+            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
+                if kern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+                    d = int(row["Dispatch_Id"])
+                    per[d] = per.get(d, 0.0) + float(row["Counter_Value"])
+            ids = sorted(per)[warm:warm + steps]       # (the timed steps: behind them the child checks its results with searches)
+            if len(ids) < steps // 2:
+                return None, f"the {counter} pass shows {len(per)} dispatches of {kern}"
+            got[counter] = sum(per[d] for d in ids) / len(ids)
+            launches = len(ids)
+    finally:
+        shutil.rmtree(top, ignore_errors=True)
+    total = int((got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)
+    return total, (f"live: rocprofv3 --kernel-trace --pmc FETCH_SIZE / WRITE_SIZE, a child pass each of this run's workload "
+                   f"({launches} launches of {kern.rstrip('<')} behind {warm} warm-up steps averaged; "
+                   f"FETCH {got['FETCH_SIZE']:.0f} KB + WRITE {got['WRITE_SIZE']:.0f} KB)")
 
 
 def load_traffic(args, fused, sharded):

@@ -44,6 +44,20 @@ def test_single_gpu_line():
     check_common(d, 1, 6, 3)
     assert "k_search_mark" in d["roofline"]["kernel"]
     assert d["step_algorithmic"]["bytes_per_step"] > 0
+    # roofline.traffic is this run's own (two child passes under rocprofv3 --pmc) -- or the line says why it is not
+    r = d["roofline"]
+    if r["traffic_not_live_because"] is None:
+        assert r["traffic_source"].startswith("live: rocprofv3") and r["traffic"] > 0 and r["traffic_head"] == r["library"], r
+    else:
+        assert isinstance(r["traffic_not_live_because"], str) and r["traffic_not_live_because"], r
+
+
+def test_single_gpu_line_with_committed_traffic():
+    """--no-live-traffic: the counter passes committed under profiles/ (none for this small geometry's workload key
+    is an error neither: the field is null or labelled with its source)."""
+    d = run_bench("--steps", "4", "--warmup", "2", "--no-live-traffic", *SMALL)
+    r = d["roofline"]
+    assert r["traffic_not_live_because"] is None and (r["traffic"] is None or "profiles/" in r["traffic_source"]), r
 
 
 def test_gpus_2_starts_its_own_ranks():
