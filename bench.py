@@ -1123,6 +1123,24 @@ def profiler_present():
     return any(os.environ.get(k) for k in keys) or "rocprofiler" in os.environ.get("LD_PRELOAD", "")
 
 
+def counter_per_launch(path, kern, counter, warm, steps):
+    """rocprofv3's counter_collection.csv -> (mean value of `counter` per dispatch of the kernel whose name contains
+    `kern`, dispatches averaged, dispatches seen): a dispatch's rows (one per instance the counter is kept in) are
+    summed; the dispatches are taken in order, the first `warm` (the warm-up steps) dropped and the next `steps` (the
+    timed steps; behind them the run checks its results with further searches) averaged.  (None, 0, seen) when fewer
+    than half of `steps` are there."""
+    import csv
+    per = {}
+    for row in csv.DictReader(open(path)):
+        if kern in row["Kernel_Name"] and row["Counter_Name"] == counter:
+            d = int(row["Dispatch_Id"])
+            per[d] = per.get(d, 0.0) + float(row["Counter_Value"])
+    ids = sorted(per)[warm:warm + steps]
+    if len(ids) < max(1, steps // 2):
+        return None, 0, len(per)
+    return sum(per[d] for d in ids) / len(ids), len(ids), len(per)
+
+
 def live_traffic(args, fused):
     """HBM bytes per launch of the dominant kernel, measured by THIS run: two child processes of this script (the same
     workload flags, 5 warm-up + 20 steps once, no side legs) under `rocprofv3 --kernel-trace --pmc <counter>`, FETCH_SIZE
@@ -1130,7 +1148,6 @@ def live_traffic(args, fused):
     section prescribes; the counters are in KB, averaged over the kernel's dispatches behind the warm-up.  Returns
     (bytes per launch, note) or (None, why not).  The children are started with subprocess -- nothing is exec'ed from
     this process, which holds the GPU -- and each has 150 s."""
-    import csv
     import glob
     import shutil
     import subprocess
@@ -1167,16 +1184,10 @@ def live_traffic(args, fused):
             if r.returncode != 0 or not files:
                 tail = (r.stderr or b"").decode(errors="replace").strip().splitlines()[-1:]
                 return None, f"the {counter} pass failed (exit {r.returncode}{': ' + tail[0][:120] if tail else ''})"
-            per = {}
-            for row in csv.DictReader(open(max(files, key=os.path.getmtime))):
-                if kern in row["Kernel_Name"] and row["Counter_Name"] == counter:
-                    d = int(row["Dispatch_Id"])
-                    per[d] = per.get(d, 0.0) + float(row["Counter_Value"])
-            ids = sorted(per)[warm:warm + steps]       # (the timed steps: behind them the child checks its results with searches)
-            if len(ids) < steps // 2:
-                return None, f"the {counter} pass shows {len(per)} dispatches of {kern}"
-            got[counter] = sum(per[d] for d in ids) / len(ids)
-            launches = len(ids)
+            mean, launches, seen = counter_per_launch(max(files, key=os.path.getmtime), kern, counter, warm, steps)
+            if mean is None:
+                return None, f"the {counter} pass shows {seen} dispatches of {kern}"
+            got[counter] = mean
     finally:
         shutil.rmtree(top, ignore_errors=True)
     total = int((got["FETCH_SIZE"] + got["WRITE_SIZE"]) * 1024)

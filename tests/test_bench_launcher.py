@@ -49,3 +49,45 @@ def test_launcher_process_never_loads_torch_or_the_library():
     import json
     seen = json.loads(p.stdout.strip().splitlines()[-1])
     assert seen == {"torch": False, "mkv": False, "n": ["--nproc-per-node=2"]}
+
+
+def test_counter_passes_are_read_per_dispatch_of_the_timed_steps(tmp_path):
+    """roofline.traffic of a run comes from rocprofv3's counter_collection.csv of a child pass (bench.live_traffic):
+    the rows of a dispatch are summed (a counter is kept per instance), the warm-up dispatches dropped, the timed
+    steps averaged, the searches the child checks itself with behind them left out, other kernels ignored."""
+    import bench
+    rows = ["Correlation_Id,Dispatch_Id,Agent_Id,Queue_Id,Process_Id,Thread_Id,Grid_Size,Kernel_Id,Kernel_Name,"
+            "Workgroup_Size,LDS_Block_Size,Scratch_Size,VGPR_Count,SGPR_Count,Counter_Name,Counter_Value"]
+
+    def add(d, kern, counter, values):
+        for v in values:
+            rows.append(f"{d},{d},1,1,1,1,1024,7,\"{kern}\",256,0,0,52,68,{counter},{v}")
+
+    d = 1
+    for _ in range(3):                                      # pre-load: another kernel
+        add(d, "void mkv::k_mark<(mkv::Op)1>(mkv::Ctl*)", "FETCH_SIZE", [5.0, 5.0])
+        d += 1
+    for step in range(2 + 4 + 3):                           # 2 warm-up, 4 timed, 3 checks behind them
+        val = 1000.0 if step < 2 else (100.0 + step if step < 6 else 9000.0)
+        add(d, "void mkv::k_search_mark<(mkv::Op)1>(uint2 const*, unsigned int*)", "FETCH_SIZE", [val / 2, val / 2])
+        add(d, "void mkv::k_search_mark<(mkv::Op)1>(uint2 const*, unsigned int*)", "WRITE_SIZE", [1.0])
+        d += 1
+        add(d, "void mkv::k_round<(mkv::Op)1, 1>(mkv::Ctl*)", "FETCH_SIZE", [77.0])
+        d += 1
+    p = tmp_path / "1_counter_collection.csv"
+    p.write_text("\n".join(rows) + "\n")
+    mean, n, seen = bench.counter_per_launch(str(p), "k_search_mark", "FETCH_SIZE", 2, 4)
+    assert (n, seen) == (4, 9) and mean == (102.0 + 103.0 + 104.0 + 105.0) / 4
+    mean, n, seen = bench.counter_per_launch(str(p), "k_search_mark", "WRITE_SIZE", 2, 4)
+    assert (mean, n) == (1.0, 4)
+    assert bench.counter_per_launch(str(p), "k_search<", "FETCH_SIZE", 2, 4) == (None, 0, 0)
+    assert bench.counter_per_launch(str(p), "k_search_mark", "FETCH_SIZE", 8, 4)[0] is None     # (too few behind the warm-up)
+
+
+def test_a_run_under_a_profiler_is_recognised(monkeypatch):
+    import bench
+    for k in ("ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB", "ROCPROFILER_REGISTER_FORCE_LOAD", "ROCPROF_OUTPUT_PATH", "LD_PRELOAD"):
+        monkeypatch.delenv(k, raising=False)
+    assert not bench.profiler_present()
+    monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
+    assert bench.profiler_present()
