@@ -646,7 +646,10 @@ def main():
         live_why = None
         if rank == 0 and world == 1 and not sharded and not args.no_live_traffic:
             # (measured by this run itself, in two child passes under the profiler; the committed passes stay beside it)
-            live, live_why = live_traffic(args, fused)
+            try:
+                live, live_why = live_traffic(args, fused)
+            except Exception as ex:                               # noqa: BLE001  (whatever the profiler does, the line is printed)
+                live, live_why = None, f"{type(ex).__name__}: {ex}"
             if live is not None:
                 traffic, traffic_src, traffic_lib = live, live_why, library_id(engine)
                 live_why = None

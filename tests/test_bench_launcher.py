@@ -91,3 +91,16 @@ def test_a_run_under_a_profiler_is_recognised(monkeypatch):
     assert not bench.profiler_present()
     monkeypatch.setenv("ROCP_TOOL_LIBRARIES", "/opt/rocm/lib/rocprofiler-sdk/librocprofiler-sdk-tool.so")
     assert bench.profiler_present()
+
+
+def test_counter_csv_of_an_unknown_shape_is_an_error_the_caller_survives(tmp_path):
+    """(bench.py wraps live_traffic in try / except: a profiler that writes another CSV costs the run its live
+    traffic figure, not its line)"""
+    import bench
+    import pytest
+    p = tmp_path / "x_counter_collection.csv"
+    p.write_text("Dispatch_Id,Kernel_Name,FETCH_SIZE\n1,k_search_mark,5\n")
+    with pytest.raises(KeyError):
+        bench.counter_per_launch(str(p), "k_search_mark", "FETCH_SIZE", 0, 1)
+    src = open(bench.__file__).read()
+    assert "live, live_why = live_traffic(args, fused)" in src and "except Exception as ex:" in src.split("live, live_why = live_traffic(args, fused)")[1][:200]
