@@ -140,7 +140,8 @@ struct Ctl {
 	uint32_t hint_stamp;             // low word of the round-1 stamp of the last pass whose mark pass walked ahead for a
 	                                 // chain (prewalk_register): round 1 then reads every request's reservation
 	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
-	uint32_t pad_head[2];
+	uint32_t r1_wide;                // a BIG pass's round 1 runs on a lane per request (Ctl::unplanned below)
+	uint32_t pad_head[1];
 	uint32_t first_hard;
 	uint32_t chain_n;                // chain-log entries handed out this call
 	uint32_t chain_ok;               // chains committed optimistically
@@ -181,6 +182,15 @@ struct Ctl {
 	// kLlPer of the latter by index (k_tail: a short list is run by one work-group -- no scan of the pass's tags, no
 	// meeting) -- instead of a count here and atomics on the commit counters below (cleared by the mark pass, like those)
 	struct alignas(32) WgRec { uint4 stat; uint32_t ll[kLlPer]; } wg_rec[kTlGroups];
+	// Requests of the passes so far that got NO plan from their mark pass (primary bucket full as the table stood):
+	// counted where they are found, one atomic per wave that has any, never cleared.  The first work-group of a BIG
+	// pass's round 1 (bit 8 of its hint) takes what has been added since the last such round (unplanned_base) and
+	// leaves its verdict for the NEXT pass in r1_wide_next -- mostly plan-carrying: a lane per request pays, k_round --
+	// which that pass's mark pass moves to r1_wide: no kernel reads a word another work-group of it writes, and a
+	// table's load factor moves a fraction of a per cent per pass.
+	struct { uint32_t n; uint32_t pad[15]; } unplanned[kShards];
+	uint32_t unplanned_base;
+	uint32_t r1_wide_next;
 	uint32_t tl_groups[2];               // work-groups of round 1 / round 2 of this pass
 	uint32_t tl_cnt[2][kTlGroups];       // entries a work-group left (may exceed kTlPer: not all listed)
 	uint32_t tl[2][kTlGroups][kTlPer];

@@ -72,6 +72,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	const bool over = s_total == kNone;
 	const uint32_t total = over ? 0u : s_total;
 	if (block == 0 && t == 0) {
+		ctl->r1_wide = ctl->r1_wide_next;      // (the verdict of the last big pass's round 1, for this pass's: Ctl::unplanned)
 		ctl->stamp_cur = stamp;
 		ctl->total = total;
 		ctl->overflow = over ? 1u : 0u;
@@ -112,6 +113,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	// whole waves iterate together: the reservation de-duplication is a wave operation
 	const uint32_t span = nblocks * blockDim.x;
 	const uint32_t first = start + block * blockDim.x;          // this block's first index
+	uint32_t nun = 0u;      // this lane's requests without a plan
 	for (uint32_t base = first; base < end && base >= start; base += span) {
 		const uint32_t idx = base + t;
 		bool live = idx < end && idx >= start;
@@ -182,6 +184,7 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 				undo[idx] = u;
 				planned = true;
 			}
+			nun += fresh && undo && !planned ? 1u : 0u;
 		}
 		if (fresh)
 			reqc[idx] = make_uint4(rq.sig, rq.hash, rq.loc, (lazy ? kLazyBit : 0u) | (planned ? kPlanBit : 0u));
@@ -199,6 +202,8 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		if (OP == OP_CUCKOO && live && table && !lazy)
 			prewalk_register(table, g, rq, P, A, owner, key, plo, phi, &ctl->hint_stamp, lost, (lazy_free & 0x100u) == 0u && lost.flag);
 	}
+	if (OP != OP_DELETE && undo)
+		count_add(&ctl->unplanned[0].n, nun);       // (an atomic per wave that has any: next to none below load factor 0.3)
 }
 
 // Optimistic eviction chain of a hard request that owns P and A (grid-wide rounds).

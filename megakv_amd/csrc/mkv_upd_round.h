@@ -87,7 +87,7 @@ struct RoundLds {
 // (block of nblocks: the work-group's place among those that share the round -- the launch's own for
 // rounds launched by themselves)
 template <Op OP, int ROUND, int QCAP>
-__device__ __forceinline__ void round_body(const uint32_t block, const uint32_t nblocks, unsigned char *lds, Ctl *ctl,
+__device__ __forceinline__ void round_body(const uint32_t block, const uint32_t nblocks_launched, unsigned char *lds, Ctl *ctl,
 		const DevGeom &g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
@@ -139,6 +139,33 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	// (... unless a chain walked ahead in this pass's mark pass: it registers without flagging, prewalk_register)
 	const bool plans_on = plans && ctl->hint_stamp != (uint32_t)stamp1;
 	const uint32_t s32 = (uint32_t)stamp1;
+	// A BIG pass is launched on a lane per request (bit 8 of the hint, launch_rounds): a turn that only carries out plans
+	// is one round trip whatever it holds, and 2^19 requests on kTlGroups work-groups are four of them (zipf50 at load
+	// factor 0.2: round 1 29.3 -> 25.0 us).  Four times the work-groups walking to alternate buckets and along chains at
+	// once are SLOWER (load factor 0.38: 33.5 -> 49.6 us; profiles/r05_launch_floor.txt 12): unless the last such pass
+	// was mostly plan-carrying (Ctl::r1_wide, moved here by this pass's mark pass) and this one's plans stand, the round
+	// keeps to kTlGroups work-groups and the others leave.  Every work-group reads the same words and decides alike.
+	uint32_t nblocks = nblocks_launched;
+	if (ROUND == 1 && (record_hint & 256) != 0) {
+		if (block == 0 && threadIdx.x < (uint32_t)kShards) {
+			// (the verdict for the NEXT big pass: more than one request in 128 of this one without a plan -- its primary
+			// bucket was full -- and a lane per request does not pay)
+			static_assert(kShards == 64, "a shard a lane of a wave");
+			uint32_t un = ctl->unplanned[threadIdx.x].n;
+			for (int off = 32; off > 0; off >>= 1)
+				un += __shfl_xor(un, off);
+			if (threadIdx.x == 0) {
+				const uint32_t added = un - ctl->unplanned_base;
+				ctl->unplanned_base = un;
+				ctl->r1_wide_next = plans_on && (unsigned long long)added * 128ull <= ctl->total ? 1u : 0u;
+			}
+		}
+		if (nblocks > kTlGroups && !(ctl->r1_wide != 0u && plans_on)) {
+			nblocks = kTlGroups;
+			if (block >= nblocks)
+				return;
+		}
+	}
 	const uint32_t span = nblocks * blockDim.x;
 	uint32_t ndone = 0, ndone_help = 0, nlosers = 0;
 	// owner table holding the round-1 registrations of every request of this pass (chains claim there)

@@ -2320,6 +2320,10 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 	reset_tail_scratch(ctl);
 	if (t < kMaxRegions)
 		ctl->barrier[t] = kNone;
+	if (t < (uint32_t)kShards)
+		ctl->unplanned[t].n = 0u;
+	if (t == 0)
+		ctl->unplanned_base = ctl->r1_wide = ctl->r1_wide_next = 0u;
 }
 
 }  // namespace mkv

@@ -596,9 +596,17 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	const bool busy = (w->host_flag && w->host_flag[3]) || w->barrier_score > 0;
 	if (hint > 0 && !busy && (hint + 255) / 256 < r1_blocks)
 		r1_blocks = (hint + 255) / 256;
+	// (... and a BIG pass a lane per request, within 2048 work-groups -- the round itself keeps to kTlGroups of them
+	// unless the passes are mostly plan-carrying, bit 8 of its hint: round_body.  Only the default of
+	// Tuning::round_blocks is scaled: a host that set it gets what it set.)
+	bool big_grid = false;
+	if (hint > r1_blocks * 256 && r1_blocks == 512 && OP != OP_DELETE && plans_ok && tuning().plans) {
+		r1_blocks = (hint + 255) / 256 > 2048 ? 2048 : (hint + 255) / 256;
+		big_grid = true;
+	}
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost);
+			rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost);
 	// round 2: inside the tail launch (k_tail's first phase), unless the pass is announced with more
 	// requests than that launch has lanes for in a few turns, or is a delete
 	// (word 3 of the tail kernel's flags, read without synchronising -- a pass late, which only costs time:
