@@ -194,6 +194,9 @@ int mkv_debug_stamp_resets(void *stream, int cycle_insert);
 /* what the workspace holds for request idx after the last pass: out[0] = tag, out[1..4] = the
  * request cache {sig, hash, loc, flags}, out[5..8] = its undo record.  Synchronises the device. */
 int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9]);
+/* what the last big pass's round 1 left for the next one: 1 = mostly plan-carrying (it runs on a lane per request),
+ * 0 = not; negative: no such workspace.  Synchronises the device. */
+int mkv_debug_wide_round(int cycle_insert);
 #endif
 
 /* ---- request preparation on the device ------------------

@@ -1308,6 +1308,27 @@ extern "C" int mkv_debug_request(int cycle_insert, uint32_t idx, uint32_t out[9]
 	return MKV_OK;
 }
 
+// diagnostics (tests/test_gpu_parity.py): what the last BIG pass's round 1 left for the next one -- 1: mostly plan-carrying, a
+// lane per request pays (Ctl::r1_wide_next); 0: not; < 0: no such workspace
+extern "C" int mkv_debug_wide_round(int cycle_insert)
+{
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess || hipDeviceSynchronize() != hipSuccess)
+		return -2;
+	mkv::Workspace *w = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+		auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
+		if (it == mkv::g_ws.end() || !it->second->ctl)
+			return -1;
+		w = it->second;
+	}
+	uint32_t v = 0;
+	if (hipMemcpy(&v, &w->ctl->r1_wide_next, sizeof(v), hipMemcpyDeviceToHost) != hipSuccess)
+		return -2;
+	return (int)v;
+}
+
 // diagnostics (tools/loser_probe.py): the tags and cache entries of requests 0 .. n-1 after the last pass
 extern "C" int mkv_debug_dump(int cycle_insert, uint8_t *state_out, uint32_t *reqc_out, uint32_t n)
 {

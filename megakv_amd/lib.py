@@ -50,7 +50,8 @@ ABI_SYMBOLS = [
     "cudaGetLastError", "cudaGetErrorString", "cudaMemGetInfo",
 ]
 
-DIAG_SYMBOLS = ["mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_debug_request"]
+DIAG_SYMBOLS = ["mkv_debug_tail_phases", "mkv_debug_stamp_resets", "mkv_debug_random_read", "mkv_debug_request",
+                "mkv_debug_wide_round"]
 
 _lib = None
 _diag_lib = None
@@ -132,6 +133,8 @@ def _load(LIB_PATH, diagnostics):
     if diagnostics:
         L.mkv_debug_random_read.restype = ctypes.c_longlong
         L.mkv_debug_random_read.argtypes = [P, ctypes.c_longlong, INT, ctypes.c_longlong, ctypes.c_longlong, P, P]
+        L.mkv_debug_wide_round.restype = INT
+        L.mkv_debug_wide_round.argtypes = [INT]
         L.mkv_debug_stamp_resets.restype = INT
         L.mkv_debug_stamp_resets.argtypes = [P, INT]
         L.mkv_debug_tail_phases.restype = INT

@@ -84,3 +84,43 @@ def test_hundreds_of_cycles_on_one_table(scheme, diag, mem_p, scale, steps):
     assert len(modes) >= 2, modes
     if scheme == 0:
         assert any(m[1] or m[2] for m in modes), modes
+
+
+@pytest.mark.parametrize("scheme", [0, 1])
+def test_big_passes_wide_round_1_and_its_fall_back(scheme):
+    """Passes announced with more than 131 072 requests: round 1 runs on a lane per request (2 048 work-groups, counts and
+    lists through shared places) once the pass before was mostly plan-carrying, and keeps to 512 work-groups when it
+    was not (primary buckets full: more than one request in 128 without a plan) -- the verdict is left one pass
+    ahead (diagnostics build: mkv_debug_wide_round).  A table filled from empty to past load factor 0.6 in passes of
+    150 000 new keys, then thinned out by deletes and filled again: the verdict goes 1 -> 0 -> 1, every table exact."""
+    L = load_library(diagnostics=True)
+    g = Geometry(mem_p=25, scheme=scheme, iblock_p=3, max_cuckoo=5)      # 2^19 buckets, 4 M slots
+    og = ogeom(g)
+    rng = np.random.default_rng(99 + scheme)
+    exp = np.zeros((g.nbuckets, 16), np.uint32)
+    idx = HashIndex(g, lib=L)
+    idx.load_table(exp)
+    nslots = g.nbuckets * 8
+    verdicts = []
+
+    def insert_pass(n):
+        e = random_requests(g, rng, n, 1 << 31)
+        blocks = split_blocks(e, g, rng, "region")
+        O.insert(og, exp, blocks)
+        idx.insert([dev(b) for b in blocks])              # (hint = the batch's size)
+        got = idx.table_numpy()
+        assert np.array_equal(got, exp), (scheme, len(verdicts), first_diff(got, exp), idx.last_update_info())
+        verdicts.append((round(np.count_nonzero(exp[:, :8]) / nslots, 2), L.mkv_debug_wide_round(0)))
+
+    for _ in range(18):                                    # 18 x 150 000 keys: load factor 0 -> ~0.6
+        insert_pass(150000)
+    occ = np.argwhere(exp[:, :8] != 0)
+    pick = occ[rng.permutation(len(occ))[: int(len(occ) * 0.8)]]
+    d = np.stack([exp[pick[:, 0], pick[:, 1]], pick[:, 0].astype(np.uint32), exp[pick[:, 0], 8 + pick[:, 1]]], axis=1).astype(np.uint32)
+    O.delete(og, exp, d)
+    idx.delete(dev(d))
+    assert np.array_equal(idx.table_numpy(), exp)
+    for _ in range(4):
+        insert_pass(150000)
+    v = [w for _, w in verdicts]
+    assert v[1] == 1 and 0 in v[4:18] and v[-1] == 1, verdicts      # calm at first, crowded later, calm again once thinned out
