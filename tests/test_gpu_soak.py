@@ -94,6 +94,16 @@ def test_big_passes_wide_round_1_and_its_fall_back(scheme):
     ahead (diagnostics build: mkv_debug_wide_round).  A table filled from empty to past load factor 0.6 in passes of
     150 000 new keys, then thinned out by deletes and filled again: the verdict goes 1 -> 0 -> 1, every table exact."""
     L = load_library(diagnostics=True)
+    # (the product's defaults, whatever the tests before left: one pass per call, 512 work-groups for the rounds, plans on)
+    for name, v in ((b"insert_chunk", 524288), (b"round_blocks", 512), (b"plans", 1), (b"tail_rounds", 48), (b"tail_groups", 32)):
+        assert L.mkv_set_tuning(name, v) == 0
+    try:
+        _big_passes(L, scheme)
+    finally:
+        L.mkv_set_tuning(b"insert_chunk", 65536)          # (what the other suites' fixtures leave)
+
+
+def _big_passes(L, scheme):
     g = Geometry(mem_p=25, scheme=scheme, iblock_p=3, max_cuckoo=5)      # 2^19 buckets, 4 M slots
     og = ogeom(g)
     rng = np.random.default_rng(99 + scheme)
