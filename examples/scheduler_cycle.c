@@ -11,7 +11,10 @@
  * It is the build's own counterpart of the caller (the reference's .c files
  * are not copied) and doubles as the link test of lib/libgpuhash.a:
  *   gcc -Iinclude examples/scheduler_cycle.c -Llib -lgpuhash -lamdhip64 -lstdc++
- * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0] [one call, default 0] [digest, default 0]
+ * usage: scheduler_cycle [cycles] [worker streams, default 4] [mapped, default 0] [one call, default 0] [digest, default 0] [per-stream wait, default 0]
+ *   per-stream wait = 1: instead of the reference's one cudaDeviceSynchronize per cycle the host waits for
+ *   every worker's stream by itself, the LAST worker's first (cudaStreamSynchronize) -- each stream must then
+ *   have that worker's results behind it on its own (the library's deferred mode issues a cycle on one stream).
  *   digest = 1: a checksum of the whole table is printed at the end (runs with and without MKV_DEFER=1 --
  *   the library's deferred mode, megakv_hip.h -- must print the same).
  *   mapped = 1: no staging copies; the library gets the pinned host buffers themselves
@@ -81,6 +84,7 @@ int main(int argc, char **argv)
 	int MAPPED = argc > 3 ? atoi(argv[3]) : 0;
 	int ONECALL = argc > 4 ? atoi(argv[4]) : 0;
 	int DIGEST = argc > 5 ? atoi(argv[5]) : 0;
+	int STREAMWAIT = argc > 6 ? atoi(argv[6]) : 0;
 	mkv_geom_t geom = {MEM_P, IBLOCK_P,
 #if defined(HASH_2CHOICE)
 		MKV_SCHEME_2CHOICE, 0
@@ -253,7 +257,11 @@ int main(int argc, char **argv)
 						cudaMemcpyHostToDevice, k->stream));
 			gpu_hash_insert((bucket_t *)table, k->insert_ptrarray_d, k->insert_job_num_d, INSERT_BLOCK, k->stream);
 		}
-		CUDA_SAFE_CALL(cudaDeviceSynchronize());
+		if (STREAMWAIT)
+			for (id = WORKERS - 1; id >= 0; id--)
+				CUDA_SAFE_CALL(cudaStreamSynchronize(w[id].stream));
+		else
+			CUDA_SAFE_CALL(cudaDeviceSynchronize());
 
 		/* --- senders: consume results (src/mega_send.c:408-414) --- */
 		for (id = 0; id < WORKERS; id++) {

@@ -57,6 +57,7 @@ struct DeferredCopy {
 	void *dst;
 	const void *src;
 	size_t n;
+	hipStream_t stream;         // the stream the host issued it on (the flush makes that stream wait for it)
 };
 
 struct DeferredWorker {
@@ -102,8 +103,20 @@ bool defer_on_locked()
 
 // the entry of `stream` that has no call of this kind yet (a second search on a stream before the
 // cycle is issued starts a new entry: a later worker)
+int defer_flush_locked();
+
 DeferredWorker *defer_slot(hipStream_t stream, bucket_t *table, int kind)
 {
+	// A search recorded behind a delete or insert of its OWN stream must see that update (stream order): a flush
+	// runs every search of the cycle ahead of every update, so what is recorded goes out first.  (Two searches in a
+	// row on one stream see the same table either way and share a cycle.)
+	if (kind == 0) {
+		for (const DeferredWorker &d : g_defer)
+			if (d.stream == stream && (d.has_delete || d.has_insert)) {
+				die_on(defer_flush_locked(), "gpu_hash_search/flush of the stream's earlier cycle");
+				break;
+			}
+	}
 	for (auto it = g_defer.rbegin(); it != g_defer.rend(); ++it) {
 		if (it->stream != stream)
 			continue;
@@ -139,12 +152,46 @@ void issue_deferred_copies(hipStream_t s)
 	g_defer_copies.clear();
 }
 
+// A flush issues the whole cycle and the queued result copies on ONE stream, s0 (the first worker's).  The
+// host, though, issued them on a stream per worker and may wait for any of those alone (cudaStreamSynchronize,
+// a later copy or kernel of its own on that stream): every OTHER stream that has recorded work or a queued
+// copy is made to wait for an event behind the flush, so that stream order holds on each of them as if the
+// work had been issued there.
+hipEvent_t g_flush_ev = nullptr;
+
+int join_streams_locked(hipStream_t s0, const std::vector<hipStream_t> &others)
+{
+	if (others.empty())
+		return MKV_OK;
+	if (!g_flush_ev && hipEventCreateWithFlags(&g_flush_ev, hipEventDisableTiming) != hipSuccess)
+		return MKV_EHIP;
+	if (hipEventRecord(g_flush_ev, s0) != hipSuccess)
+		return MKV_EHIP;
+	for (hipStream_t o : others)
+		if (hipStreamWaitEvent(o, g_flush_ev, 0) != hipSuccess)
+			return MKV_EHIP;
+	return MKV_OK;
+}
+
 int defer_flush_locked()
 {
 	int rc = release_memset_locked();
 	if (g_defer.empty() && g_defer_copies.empty())
 		return rc;
-	hipStream_t s0 = g_defer.empty() ? nullptr : g_defer[0].stream;
+	hipStream_t s0 = g_defer.empty() ? g_defer_copies[0].stream : g_defer[0].stream;
+	std::vector<hipStream_t> others;
+	auto note_stream = [&](hipStream_t o) {
+		if (o == s0)
+			return;
+		for (hipStream_t k : others)
+			if (k == o)
+				return;
+		others.push_back(o);
+	};
+	for (const DeferredWorker &d : g_defer)
+		note_stream(d.stream);
+	for (const DeferredCopy &c : g_defer_copies)
+		note_stream(c.stream);
 	size_t i = 0;
 	if (g_defer.size() > 1) {
 		// What the host queued on the workers' own streams (request copies, memsets) is done first: ONE wait for
@@ -187,6 +234,8 @@ int defer_flush_locked()
 	issue_deferred_copies(s0);
 	if (rc == MKV_OK)
 		rc = t_copy_rc;
+	if (rc == MKV_OK)
+		rc = join_streams_locked(s0, others);
 	g_defer.clear();
 	g_defer_copies.clear();
 	return rc;
@@ -244,8 +293,8 @@ extern "C" int mkv_defer_copy(void *dst, const void *src, size_t n, void *stream
 	die_on(release_memset_locked(), "held memset");
 	if (g_defer.empty())
 		return 0;
-	(void)stream;           // (any stream: the recorded cycle may write what the copy reads whatever stream it names)
-	g_defer_copies.push_back(DeferredCopy{dst, src, n});
+	// (any stream: the recorded cycle may write what the copy reads whatever stream it names)
+	g_defer_copies.push_back(DeferredCopy{dst, src, n, (hipStream_t)stream});
 	return 1;
 }
 
@@ -274,6 +323,7 @@ extern "C" void gpu_hash_search(selem_t *in, loc_t *out, bucket_t *hash_table, i
 			d->has_search = true;
 			return;
 		}
+		die_on(defer_flush_locked(), "gpu_hash_search/flush");     // (eager: behind whatever is still recorded)
 	}
 	die_on(mkv_search(&kGeom, in, out, hash_table, num_elem, MKV_SEARCH_KEEP_MISS, (void *)stream),
 			"gpu_hash_search");
@@ -294,6 +344,9 @@ extern "C" void gpu_hash_insert(bucket_t *hash_table, ielem_t **blk_input, int *
 			d->has_insert = true;
 			return;
 		}
+		// (eager -- the mode is off, or the call has more blocks than a recorded cycle takes: behind whatever is
+		// recorded, in the order the host issued the calls)
+		die_on(defer_flush_locked(), "gpu_hash_insert/flush");
 	}
 	die_on(mkv_insert(&kGeom, hash_table, blk_input, blk_elem_num, num_blks, (void *)stream),
 			"gpu_hash_insert");
@@ -318,6 +371,7 @@ extern "C" void gpu_hash_delete(delem_t *in, bucket_t *hash_table, int num_elem,
 			d->has_delete = true;
 			return;
 		}
+		die_on(defer_flush_locked(), "gpu_hash_delete/flush");
 	}
 	die_on(mkv_delete(&kGeom, in, hash_table, num_elem, (void *)stream), "gpu_hash_delete");
 }
@@ -462,5 +516,5 @@ extern "C" const char *mkv_version(void)
 #ifndef MKV_BUILD_ID
 #define MKV_BUILD_ID "unknown"
 #endif
-	return "megakv_amd libgpuhash gfx950 r5 " MKV_BUILD_ID;       // (the last word: a digest of the library's sources, csrc/Makefile)
+	return "megakv_amd libgpuhash gfx950 r6 " MKV_BUILD_ID;       // (the last word: a digest of the library's sources, csrc/Makefile)
 }

@@ -80,7 +80,7 @@ struct mkv_shard {
 	int host_paced = 1;             // the host, not the stream, waits for a local phase's requests (MKV_SHARD_PACED=0)
 	int nsvc = 1;                   // service streams (MKV_SHARD_SVC = 1..3; default 1 rank: 1, else 3)
 	hipStream_t svc[3] = {nullptr, nullptr, nullptr};
-	int delay_unpack_us = 0;        // tests (MKV_SHARD_DELAY_UNPACK_US): every un-pack starts that much later
+	int delay_unpack_us = 0;        // tests, diagnostics build (MKV_SHARD_DELAY_UNPACK_US): every un-pack starts that much later
 	const char *phase = "idle";     // what the engine was doing when a call failed (mkv_shard_error)
 	Rccl api;
 	ncclComm_t comm = nullptr;
@@ -125,6 +125,9 @@ struct Span {
 };
 }  // namespace
 
+// ---- diagnostics build only (make DIAG=1): the stand-ins a one-GPU box measures and tests W-rank schedules with ----
+// (the product library has neither: tests/test_gpu_sharded.py and tools/loopback_trace.py load libmegakv_hip_diag.so)
+#ifdef MKV_DIAGNOSTICS
 // MKV_SHARD_FAKE_XFER_US=n (diagnostics): every exchange is followed by a one-wave kernel that
 // waits n microseconds on the lane's stream -- a stand-in for the time the exchange takes over
 // xGMI when only one GPU is there to measure schedules on
@@ -283,6 +286,9 @@ Rccl loopback_api()
 	return a;
 }
 }  // namespace
+#else
+static inline void fake_xfer(hipStream_t) {}
+#endif
 
 static int fail(mkv_shard *e, int code, const char *what, const char *detail)
 {
@@ -409,10 +415,14 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 		e->self_direct = e->self_direct && atoi(v) != 0;
 
 	if (rccl_path && !strcmp(rccl_path, "loopback")) {
+#ifdef MKV_DIAGNOSTICS
 		// test shape (tests/test_gpu_sharded.py): every peer is this process -- see loopback_api()
 		e->api = loopback_api();
 		g_loop_world = world;
 		e->loopback = 1;
+#else
+		return fail(e, MKV_EINVAL, "create", "rccl_path \"loopback\" (every peer looped back) exists in the diagnostics build only");
+#endif
 	} else {
 	e->api.lib = dlopen(rccl_path && *rccl_path ? rccl_path : "librccl.so", RTLD_NOW | RTLD_GLOBAL);
 	if (!e->api.lib)
@@ -783,8 +793,10 @@ static int run_batches(mkv_shard *e, int nbatches, const selem_t *const *gets, c
 		}
 		if (more)
 			SH_HIP(e, hipEventRecord(l.ev_recv[k2], S));
+#ifdef MKV_DIAGNOSTICS
 		if (e->delay_unpack_us > 0)
 			hipLaunchKernelGGL(k_wait_us, dim3(1), dim3(64), 0, S, (unsigned)e->delay_unpack_us);
+#endif
 		{
 			Span sp("unpack", b, i, S, tr);
 			rc = mkv_unpack_results(l.back_slots[k], l.perm2[k], n_get[i], outs[i], S);

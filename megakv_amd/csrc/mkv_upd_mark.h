@@ -328,10 +328,6 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 {
 	// mark blocks first: they are few and latency-bound, let them start early
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
-#ifdef MKV_EXP_NOMARK
-	if (blockIdx.x < mark_blocks)       // launch-floor experiment (timing only): the mark work-groups leave at once
-		return;
-#endif
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
 				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost);

@@ -543,26 +543,6 @@ static unsigned tail_groups_for()
 	return (unsigned)(g < 1 ? 1 : g);
 }
 
-#if defined(MKV_EXP_EXTRA_LAUNCH) || defined(MKV_EXP_TAIL) || defined(MKV_EXP_ROUND1)
-__global__ __launch_bounds__(kTailThreads) void k_exp_trivial_tail(Ctl *ctl, DevGeom g, uint32_t *table,
-		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, const unsigned long long *owner1,
-		const unsigned long long *owner2, const unsigned long long *second, const uint4 *reqc, uint8_t *state, const Undo *undo,
-		const ChainLog *chain_logs, uint32_t *glist, int max_rounds, uint32_t lo_idx, uint32_t hi_idx, int first_chunk,
-		int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress, int dbg_path, int round2_hint,
-		uint32_t req_cap)
-{
-	__shared__ uint32_t big[43u * 256u];
-	if (ld_agent32(&ctl->any_tail) == 0x12345u)     // (never)
-		big[threadIdx.x] = g.hash_mask + lo_idx, glist[threadIdx.x] = big[(threadIdx.x * 7u) & 1023u];
-}
-
-__global__ void k_exp_trivial(Ctl *ctl)
-{
-	if (ld_agent32(&ctl->any_tail) == 0x12345u)
-		ctl->dbg[0] = 1u;
-}
-#endif
-
 // K2..K4
 // done_ev: an event that completes with the LAST kernel of the pass (the tail launch delivers its
 // end into it, hipExtLaunchKernelGGL): what a hipEventRecord behind the launch would give, without
@@ -582,12 +562,6 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	// bit 6 -- round 1 carries out the mark pass's plans (kPlanBit)
 	const int rhint = (MKV_DIAG(debug_skip) & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32) |
 			(plans_ok && tuning().plans ? 64 : 0);
-#if defined(MKV_EXP_ROUND1) && MKV_EXP_ROUND1 == 1
-	if (0)      // launch-floor experiment (timing only): no round 1
-#elif defined(MKV_EXP_ROUND1) && MKV_EXP_ROUND1 == 2
-	hipLaunchKernelGGL(k_exp_trivial, dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl);
-	if (0)      // ... a launch of its grid with nothing to do in its place
-#endif
 	// (a pass announced with fewer requests than round 1's grid has lanes: as many work-groups as it takes --
 	// 208 instead of 512 are 0.5 us of a 52 K-request pass)
 	// (not while round 1 has been leaving round 2 a lot, or chains have been running late: what a work-group
@@ -621,31 +595,11 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
 				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr);
-#if defined(MKV_EXP_TAIL) && MKV_EXP_TAIL == 1
-	if (0)      // launch-floor experiment (timing only): no tail launch at all
-#elif defined(MKV_EXP_TAIL) && MKV_EXP_TAIL == 2
-	hipLaunchKernelGGL(k_exp_trivial, dim3(1), dim3(64), 0, stream, w->ctl);
-	if (0)      // ... a one-wave launch in its place
-#endif
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
 			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min), (uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3,
 			merged ? rhint : -1, (uint32_t)w->req_cap);
-#ifdef MKV_EXP_EXTRA_LAUNCH
-	// launch-floor experiment (timing only; tools/probes/README): one more launch behind the tail --
-	// 1: the tail's grid, LDS and argument list, nothing done; 2: one wave, no arguments to speak of;
-	// 3: round 1's grid
-	if (MKV_EXP_EXTRA_LAUNCH == 1)
-		hipLaunchKernelGGL(k_exp_trivial_tail, dim3(tail_groups_for<OP>()), dim3(kTailThreads), 0, stream, w->ctl, g, table, w->owner[2],
-				w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
-				tail_rounds, lo, hi, first_chunk, last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min),
-				(uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3, merged ? rhint : -1, (uint32_t)w->req_cap);
-	else if (MKV_EXP_EXTRA_LAUNCH == 2)
-		hipLaunchKernelGGL(k_exp_trivial, dim3(1), dim3(64), 0, stream, w->ctl);
-	else
-		hipLaunchKernelGGL(k_exp_trivial, dim3((unsigned)tuning().round_blocks), dim3(256), 0, stream, w->ctl);
-#endif
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

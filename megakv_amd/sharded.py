@@ -123,7 +123,8 @@ class NativeEngine:
 
     def __init__(self, sh, dist, loopback=False):
         """loopback: every peer is this process (the exchanges are device copies) -- the W-rank
-        schedule on one GPU, for tests (mkv_shard.hip, loopback_api)."""
+        schedule on one GPU, for tests (mkv_shard.hip, loopback_api; the diagnostics build only:
+        ShardedIndex(..., lib=load_library(diagnostics=True)))."""
         import os
         self.sh, self.lib = sh, sh.idx.lib
         self.h = ctypes.c_void_p(0)
@@ -241,7 +242,9 @@ class _Lane:
 
 class ShardedIndex:
     def __init__(self, mem_p_local, world, rank, scheme, device, n_get, n_set, comm, ops=None,
-                 cap_factor=None, index=None):
+                 cap_factor=None, index=None, lib=None):
+        # (lib: another build of the library than the product's -- the looped-back peers of the tests and
+        # probes exist in the diagnostics build only, load_library(diagnostics=True))
         self.world, self.rank = world, rank
         self.native = None
         self.device = torch.device(device)
@@ -252,7 +255,7 @@ class ShardedIndex:
         self.shift = mem_p_local - 6
         self.comm = comm
         if ops is None:
-            index = index or HashIndex(self.geom, device=device)
+            index = index or HashIndex(self.geom, device=device, lib=lib)
             ops = HipOps(index)
         self.idx = index
         self.ops = ops

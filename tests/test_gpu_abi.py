@@ -127,6 +127,28 @@ def test_deferred_launch_mode_gives_an_unchanged_host_the_fused_cycle(workers, m
     print(f"workers {workers} mapped {mapped}: eager {rates[0]} Mops, deferred {rates[1]} Mops")
 
 
+@pytest.mark.parametrize("workers", ["4", "16"])
+def test_deferred_launch_mode_with_a_wait_per_worker_stream(workers):
+    """The deferred mode issues a whole cycle -- every worker's search, the updates, the result copies -- on the
+    FIRST worker's stream.  A host that waits for its streams one by one (cudaStreamSynchronize, last worker
+    first) must still find each worker's results behind that worker's own stream: the flush makes every other
+    recorded stream wait for an event behind the cycle (mkv_abi.hip, join_streams_locked).  Same plain-C host,
+    staged copies, 0 errors against its own model and the same table digest as the eager run."""
+    import os
+    import re
+    import subprocess
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "megakv_amd", "_lib", "scheduler_cycle")
+    assert os.path.exists(exe), "run __graft_entry__.build() first"
+    digests = []
+    for defer in ("0", "1"):
+        env = dict(os.environ, MKV_DEFER=defer)
+        r = subprocess.run([exe, "12", workers, "0", "0", "1", "1"], capture_output=True, text=True, timeout=600, env=env)
+        assert r.returncode == 0 and "errors 0" in r.stdout, r.stdout + r.stderr
+        digests.append(re.search(r"table digest ([0-9a-f]+)", r.stdout).group(1))
+    assert digests[0] == digests[1], digests
+
+
 def test_cycle_captured_into_a_hipgraph_through_the_c_api():
     """examples/graph_cycle.c (gcc, HIP's C header): one mkv_cycle captured with
     hipStreamBeginCapture, replayed, against the same cycles issued eagerly from the same start:
@@ -504,3 +526,43 @@ def test_update_under_capture_behind_another_streams_update_is_refused():
     torch.cuda.synchronize()
     O.insert(og, exp, [e2])
     assert np.array_equal(idx.table_numpy(), exp)
+
+
+def test_deferred_mode_keeps_stream_order_for_a_search_behind_its_own_insert():
+    """Deferred mode: insert A, search A, insert B, search A+B on ONE stream with no wait in between.  A flush runs
+    every recorded search ahead of every recorded update, so a search recorded behind an update of its own stream
+    first issues what is recorded (mkv_abi.hip, defer_slot): each search sees the inserts issued before it, as
+    the eager calls (and the reference's, stream order) do."""
+    from megakv_amd.lib import load_library
+    L = load_library()
+    g = M.Geometry(mem_p=30)
+    table = torch.zeros(g.ht_size // 4, dtype=torch.int32, device="cuda")
+    stream = torch.cuda.Stream()
+    rng = np.random.default_rng(77)
+    keys = rng.permutation(np.arange(1, 1 << 22, dtype=np.uint32))[:16384]
+    keep, outs, qs = [], [], []
+    L.mkv_set_defer(1)
+    try:
+        with torch.cuda.stream(stream):
+            for step in range(2):
+                e = W.make_ielem(keys[step * 8192:(step + 1) * 8192], None, W.KEYING_MIX)
+                blocks = [dev(b) for b in W.bin_inserts(e, 30, 3, W.BIN_APP)]
+                ptrs = torch.tensor([b.data_ptr() for b in blocks], dtype=torch.int64).cuda()
+                cnts = torch.tensor([b.shape[0] for b in blocks], dtype=torch.int32).cuda()
+                q = W.make_selem(keys[:(step + 1) * 8192], W.KEYING_MIX)
+                dq = dev(q)
+                out = torch.zeros((q.shape[0], 2), dtype=torch.int32, device="cuda")
+                keep += [blocks, ptrs, cnts, dq]
+                torch.cuda.synchronize()                 # (the staging above is torch's; nothing of the library waits)
+                M.gpu_hash_insert(table, ptrs, cnts, 8, stream)
+                M.gpu_hash_search(dq, out, table, q.shape[0], 24576, 256, stream)
+                outs.append(out)
+                qs.append(keys[:(step + 1) * 8192])
+        assert L.mkv_flush() == 0
+        torch.cuda.synchronize()
+    finally:
+        L.mkv_set_defer(0)
+    for out, k in zip(outs, qs):
+        o = host(out)
+        loc = np.where(o[:, 0] != 0, o[:, 0], o[:, 1])
+        assert np.array_equal(loc, k), "a search recorded behind an insert of its own stream did not see it"

@@ -173,6 +173,7 @@ def test_native_engine_schedule_with_several_slots(world, scheme, lanes, selfd, 
     import numpy as np
     import torch
     from bench import late_imports, sharded_engine as ShardedIndex
+    from megakv_amd.lib import load_library
     from oracle import oracle as O
     late_imports()
     monkeypatch.setenv("MKV_SHARD_SVC", str(svc))              # service streams
@@ -184,7 +185,9 @@ def test_native_engine_schedule_with_several_slots(world, scheme, lanes, selfd, 
     k = world.bit_length() - 1
     rng = np.random.default_rng(500 + world + 2 * lanes)
     n_get, n_set = 60000, 6000
-    sh = ShardedIndex(mem_p, world, 0, scheme, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6)
+    # (looped-back peers: a stand-in of the diagnostics build -- the product library refuses the path)
+    sh = ShardedIndex(mem_p, world, 0, scheme, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6,
+                      lib=load_library(diagnostics=True))
     sh.enable_native(None, loopback=True)
     try:
         og = O.geom(mem_p=mem_p, scheme=scheme, iblock_p=3 - k)
@@ -218,3 +221,17 @@ def test_native_engine_schedule_with_several_slots(world, scheme, lanes, selfd, 
             assert np.array_equal(sh.idx.table_numpy(), table)
     finally:
         sh.native.close()
+
+
+def test_product_library_has_no_looped_back_peers():
+    """The looped-back stand-in for the wire (and the wait kernel behind MKV_SHARD_FAKE_XFER_US) are test
+    scaffolding: the diagnostics build has them, the product library refuses the path by name."""
+    import subprocess
+    from bench import late_imports, sharded_engine as ShardedIndex
+    from megakv_amd.lib import LIB_PATH
+    late_imports()
+    sh = ShardedIndex(16, 2, 0, 0, "cuda:0", 1024, 64, comm=None, cap_factor=2.0)
+    with pytest.raises(RuntimeError, match="diagnostics build only"):
+        sh.enable_native(None, loopback=True)
+    names = subprocess.run(["nm", "-D", "--defined-only", LIB_PATH], capture_output=True, text=True, check=True).stdout
+    assert "k_wait_us" not in names and "k_loop_group" not in names

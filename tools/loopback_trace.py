@@ -37,7 +37,9 @@ def main():
         gen = bench.Stream(a, 0, world, mem_p + world.bit_length() - 1)
         n_get, n_set = gen.n_get, gen.n_set
     # (a hot key sends all its GETs to one shard: slots sized like bench.py sizes them)
-    sh = ShardedIndex(mem_p, world, 0, 0, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6 if zipf and world > 2 else 1.3)
+    from megakv_amd.lib import load_library
+    sh = ShardedIndex(mem_p, world, 0, 0, "cuda:0", n_get, n_set, comm=None, cap_factor=1.6 if zipf and world > 2 else 1.3,
+                      lib=load_library(diagnostics=True))     # (the looped-back peers live in the diagnostics build)
     sh.enable_native(None, loopback=True)
     rng = np.random.default_rng(7)
     try:
