@@ -142,6 +142,16 @@ long long mkv_workspace_bytes(void);
  * insert/delete call, and counted here.  Nothing aborts. */
 unsigned long long mkv_dropped_batches(void);
 
+/* Big insert passes -- a pass announced (mkv_insert_hinted, mkv_cycle's insert_hint) with at least
+ * MKV_SORTED_MIN requests (tuning "sorted_min", default 131072; 0: never) is split into bins by bucket
+ * range and applied per bucket with one line read and one whole-line write, no reservation atomics;
+ * what is not settled in its primary bucket goes through round 2 and the tail as ever.  Statistics of
+ * the current device's workspace (cycle_insert: the one mkv_cycle's inserts use): out[0] = passes that
+ * ran that way so far, out[1] = passes that fell back to the reservation rounds because a bin
+ * overflowed (many duplicates of one key), out[2] = requests the last such pass left over, out[3] = 0.
+ * Waits for `stream`. */
+int mkv_sorted_stats(void *stream, int cycle_insert, uint32_t out[4]);
+
 /* Updates issued on different streams are put in issue order (while updates have been changing
  * streams lately every update call records an event of the library's own behind its last kernel
  * and an update on another stream waits for it; a change of stream after a long run on one

@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t preferred_slot(uint32_t empties, uint32_t or
 }
 
 // Process-wide tuning knobs (defaults = measured best on MI355X).  Initialised from the environment
-// (MKV_<NAME>) on first use, changeable through mkv_set_tuning().  Sixteen of them; what only tests and probes
+// (MKV_<NAME>) on first use, changeable through mkv_set_tuning().  Seventeen of them; what only tests and probes
 // ever set -- how the tail takes an order violation back, layouts kept for the record, sizes whose sweeps are
 // flat -- exists in the diagnostics build only (DiagTuning below) and is a constant in the product.
 struct Tuning {
@@ -103,6 +103,9 @@ struct Tuning {
 	int merge_round2;       // round 2 runs as the first phase of the tail launch (0: a launch of its own; 1: unless round 1 has
 	                        // been leaving it a lot; 2: always)
 	long long merge_max;    // ... for passes announced with at most this many requests
+	long long sorted_min;   // an insert pass announced with at least this many requests (one pass, not a chunk of several) is
+	                        // partitioned into bins and applied per bucket, whole-bucket write-back, no reservation atomics
+	                        // (mkv_upd_apply.h); 0: never
 };
 Tuning &tuning();
 

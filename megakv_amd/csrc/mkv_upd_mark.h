@@ -4,6 +4,7 @@
 // are compiled together).  The design is described at the top of mkv_update.hip and in DESIGN.md 5.2.
 #pragma once
 #include "mkv_upd_common.h"
+#include "mkv_upd_sorted.h"
 #include "mkv_search_body.h"
 
 namespace mkv {
@@ -42,6 +43,10 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	const unsigned long long stamp_prev = ctl->stamp_base;
 	const uint32_t ep_pending = ctl->ep_pending;
 	const unsigned long long stamp = stamp_prev + (ep_pending ? 3ull : 0ull);
+	// (bit 9 of the hint: this launch is the fall-back behind a big pass's partition, k_search_part -- it runs only
+	// if that gave up; every lane reads the same word: only the kernel before this one writes it)
+	if ((lazy_free & 0x200u) != 0u && ctl->sorted_fail != (uint32_t)stamp)
+		return;
 	Lost lost;
 	lost.flag = OP != OP_DELETE && undo ? lost_flags : nullptr;
 	lost.s32 = (uint32_t)stamp;
@@ -386,6 +391,8 @@ __device__ __forceinline__ bool round_commit_used_pre(uint32_t st, const uint4 &
 	const uint32_t P = sh.y & g.hash_mask;
 	if (b == P)
 		return true;
+	if (sorted_commit(st, sh.w))
+		return false;                       // (a commit of k_apply, big passes: settled in its primary bucket; its record is in its bin)
 	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
 	const uint32_t w0 = undo[c].word0;
 	if (b == alt_bucket(sh.y, sh.x, g.hash_mask, g.blk_mask))

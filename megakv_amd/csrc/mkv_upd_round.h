@@ -4,6 +4,7 @@
 // are compiled together).  The design is described at the top of mkv_update.hip and in DESIGN.md 5.2.
 #pragma once
 #include "mkv_upd_common.h"
+#include "mkv_upd_sorted.h"
 
 namespace mkv {
 
@@ -91,9 +92,26 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		const DevGeom &g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, const uint32_t *list = nullptr,
-		uint32_t list_n = 0u)
+		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, const Sorted S, const uint32_t *list_arg = nullptr,
+		uint32_t list_n_arg = 0u)
 {
+	// A BIG pass (bits 9 / 10 of the hint: the host enqueued the partition-and-apply path, mkv_upd_apply.h; whether it
+	// ran is the device's to say -- a bin that overflowed makes the pass run the old way, Ctl::sorted_fail): round 1 is
+	// then only the fall-back's and leaves at once; round 2 runs over the LIST of what k_apply left over, on as many
+	// work-groups as it takes, with every eviction chain left to the tail (nobody of the pass has registered in the
+	// round-1 table, which try_chain reads everybody's rights from) and no groups of duplicates.
+	if (ROUND == 1 && (record_hint & 1024) != 0 && ctl->sorted_fail != (uint32_t)ctl->stamp_cur)
+		return;
+	const uint32_t *list = list_arg;
+	uint32_t list_n = list_n_arg;
+	bool sorted = false;
+	if (ROUND == 2 && (record_hint & 512) != 0 && list == nullptr) {
+		sorted = ctl->sorted_fail != (uint32_t)ctl->stamp_base;
+		if (sorted) {
+			list = S.losers;
+			list_n = ctl->sorted_nlosers;
+		}
+	}
 	// (list: the round's requests by index, at most a lane each -- one turn over them instead of the scan of the
 	// pass's tags: round 2 run by the tail launch's first work-group over the few losers round 1 listed)
 	// (lost: the mark pass's flags of the requests that are not the lowest registrant of their buckets, kPlanBit)
@@ -117,8 +135,8 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		pre_plan = undo[pre_idx];
 	else
 		pre_plan.word0 = pre_plan.old0 = pre_plan.word1 = pre_plan.old1 = kNoWord;
-	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
-	const bool groups_on = (record_hint & 8) == 0;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
+	const bool chains_here = (record_hint & 4) == 0 && !sorted;      // tests: every hard request left to the tail
+	const bool groups_on = (record_hint & 8) == 0 && !sorted;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
 	const bool help_on = (record_hint & 32) == 0;         // Tuning::self_help = 0: the second registrant waits for round 2, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
 		return;
@@ -227,14 +245,15 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	uint32_t dg_qmax = 0;
 #endif
 	uint32_t base = start + block * blockDim.x;
+	uint32_t lpos = block * blockDim.x;             // (list mode: this turn's first entry of the list)
 	uint32_t pf_a = 0u, pf_b = 0u;
 	// (Fetching a turn's requests and tags a turn ahead was built and measured: no difference -- the turns of a
 	// long pass are bound by the memory system's rate of random accesses, not by their round trips.)
-	for (bool more = list ? list_n != 0u : (base < count && base >= start); ; ) {
+	for (bool more = list ? lpos < list_n : (base < count && base >= start); ; ) {
 		asm volatile("" ::"v"(pf_a), "v"(pf_b));       // (last turn's touches have long arrived)
 		if (more) {
-			const bool listed = list != nullptr && threadIdx.x < list_n;
-			const uint32_t idx = list ? (listed ? list[threadIdx.x] : 0u) : base + threadIdx.x;
+			const bool listed = list != nullptr && lpos + threadIdx.x < list_n;
+			const uint32_t idx = list ? (listed ? list[lpos + threadIdx.x] : 0u) : base + threadIdx.x;
 			const bool in_range = list ? listed : idx < count;
 			// first round trip: request and its state -- independent loads
 			const bool pre = base == pre_base && pre_ok;
@@ -444,7 +463,8 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			else
 				loser_list_add(s_ll, &s_lln, idx, lose);
 			base += span;
-			more = list == nullptr && base < count && base >= start;
+			lpos += span;
+			more = list ? lpos < list_n : (base < count && base >= start);
 		}
 		__syncthreads();
 		if (ROUND == 1 && s_fused) {
@@ -493,6 +513,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 				const uint32_t c3 = (v3 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v3 & ((1ull << kIdxBits) - 1ull)) : kNone;
 				if (!late && c3 != kNone && c3 != c1 && c3 > idx)
 					late = round_commit_used(state, reqc, undo, chain_logs, g, c3, A, &e1) && e1 > idx;
+				// ... or by k_apply (a big pass): whatever it committed there of later requests -- found in the bin
+				if (!late && sorted)
+					sorted_for_each_on(S, g.hash_mask, A, [&](const uint4 &rs, uint32_t) {
+						late = rs.w > idx && state[rs.w] == ST_ROUND1;
+						return late;
+					});
 			}
 			if (live && !late && (A == P || owner[A] == key)) {
 				Undo u;
@@ -625,11 +651,11 @@ template <Op OP, int ROUND>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost)
+		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, Sorted S)
 {
 	__shared__ __align__(16) unsigned char lds[RoundLds<ROUND, kDeferCap>::bytes];
 	round_body<OP, ROUND, kDeferCap>(blockIdx.x, gridDim.x, lds, ctl, g, table, owner, owner_next, reqc, state, undo,
-			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax, second, lost);
+			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax, second, lost, S);
 }
 
 }  // namespace mkv

@@ -35,7 +35,27 @@ struct Tv {
 	const ChainLog *chain_logs;          // (behind the kChainLogCap logs of the rounds: one log per lane of the tail launch)
 	Ctl *ctl;                            // violations are noted there: viol[] per region (lowest violating index), tflags
 	                                     // (bit 0: one was recorded), vlist_n / vlist (this turn's: {index, bucket}); dbg[]
+	Sorted sorted;                       // a BIG pass's bins (mkv_upd_sorted.h): k_apply's commits are found there, a fourth
+	bool sorted_on;                      // source beside the three reservation words -- any number of commits per bucket
 };
+
+// a commit of k_apply later than idx on bucket b (its index; kNone: none) -- `sig_only`: only one that carries that signature
+__device__ __forceinline__ uint32_t sorted_later_commit(const Tv &tv, const DevGeom &g, uint32_t b, uint32_t idx, bool any,
+		uint32_t sig)
+{
+	uint32_t found = kNone;
+	if (tv.sorted_on)
+		sorted_for_each_on(tv.sorted, g.hash_mask, b, [&](const uint4 &r, uint32_t) {
+			// (tag ST_ROUND1 exactly: pending again, selected for take-back or committed by round 2 -- then the
+			// reservation words name it -- it is not k_apply's commit any more)
+			if (r.w > idx && (any || r.x == sig) && tv.state[r.w] == ST_ROUND1) {
+				found = r.w;
+				return true;
+			}
+			return false;
+		});
+	return found;
+}
 constexpr uint32_t kTvViolation = 1u;
 
 // (debug builds, make EXTRA=-DMKV_TRACE: what the tail did, in the order it did it -- tests/debug/fuzz_debug.py prints it)
@@ -114,7 +134,7 @@ __device__ __forceinline__ uint32_t later_commit_from(const Tv &tv, const DevGeo
 		return c2;
 	if (c3 != kNone && commit_used_pre(tv, g, k.st3, k.sh3, c3, b, &e) && e > idx)
 		return c3;
-	return kNone;
+	return sorted_later_commit(tv, g, b, idx, true, 0u);
 }
 
 __device__ __forceinline__ uint32_t later_commit_on(const Tv &tv, const DevGeom &g, uint32_t b, uint32_t idx)
@@ -142,7 +162,9 @@ __device__ __forceinline__ bool conflict_on(const Tv &tv, const DevGeom &g, uint
 		return true;
 	if (c2 != kNone && commit_used_pre(tv, g, k.st2, k.sh2, c2, b, &e) && e > idx && (any || k.sh2.x == sig))
 		return true;
-	return c3 != kNone && commit_used_pre(tv, g, k.st3, k.sh3, c3, b, &e) && e > idx && (any || k.sh3.x == sig);
+	if (c3 != kNone && commit_used_pre(tv, g, k.st3, k.sh3, c3, b, &e) && e > idx && (any || k.sh3.x == sig))
+		return true;
+	return sorted_later_commit(tv, g, b, idx, any, sig) != kNone;
 }
 
 // The check a pending request makes ONCE (kCheckedBit), before anything later than it in its region
@@ -1475,6 +1497,32 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 				last = b;
 			}
 		}
+		// ... and k_apply's commits on the bucket (a big pass: any number of them, all with this bucket as their primary
+		// one, found in the bin): every one later than the asking index goes -- which covers (b) for this bucket, so
+		// only its alternate bucket, which it may need when it runs again, is followed
+		if (tv.sorted_on) {
+			sorted_for_each_on(tv.sorted, g.hash_mask, e.x, [&](const uint4 &r, uint32_t) {
+				const uint32_t u = r.w;
+				if (u <= e.y || state[u] != ST_ROUND1)
+					return false;
+				const uint32_t sh = (u & 3u) * 8u;
+				if ((atomicOr(reinterpret_cast<uint32_t *>(state) + (u >> 2), (uint32_t)ST_SELECT << sh) >> sh) & ST_SELECT)
+					return false;
+				const uint32_t at = atomicAdd(nsel, 1u);
+				if (at < kSelCap)
+					sel[at] = u;
+				else
+					ok = false;
+				const uint32_t A = alt_bucket(r.y, r.x, g.hash_mask, g.blk_mask);
+				if (A != e.x) {
+					if (sp + 1u > kLaneStack)
+						ok = false;
+					else
+						stack[sp++] = make_uint2(A, u);
+				}
+				return false;
+			});
+		}
 	}
 	return ok;
 }
@@ -1482,9 +1530,10 @@ __device__ __forceinline__ bool select_from(const DevGeom &g, uint8_t *state, co
 // takes the selected commit u (tag already checked) back: its words restored, its tag ST_DEFER
 // (pending, sitting out one round -- and no longer a commit to anybody who asks commit_used)
 __device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
-		const Undo *undo, const ChainLog *chain_logs, uint32_t u, bool chain)
+		const Undo *undo, const ChainLog *chain_logs, uint32_t u, bool chain, const Tv &tv, uint32_t st)
 {
-	const Undo ur = undo[u];
+	// (a commit of k_apply -- a big pass -- has its record in its bin)
+	const Undo ur = undo_record(undo, tv.sorted, tv.sorted_on && !chain, g.hash_mask, u, reqc[u], st);
 	if (chain) {
 		const ChainLog *L = &chain_logs[ur.word0];
 		const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
@@ -1507,7 +1556,7 @@ __device__ __forceinline__ void take_back(const DevGeom &g, uint32_t *table, uin
 // Returns the number this thread rolled back.
 __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *table, uint8_t *state, const uint4 *reqc,
 		const Undo *undo, const ChainLog *chain_logs, const uint32_t *thr, uint32_t lo_idx, uint32_t total,
-		uint32_t wg, uint32_t nwg, uint32_t *sync_counter, uint2 *trunc, uint32_t *ntrunc)
+		uint32_t wg, uint32_t nwg, uint32_t *sync_counter, uint2 *trunc, uint32_t *ntrunc, const Tv &tv)
 {
 	// (a group's commit by a request below its region's threshold that reaches to or beyond it is cut
 	// there, like select_from cuts it: trunc[], the caller runs truncate_groups)
@@ -1537,7 +1586,7 @@ __device__ __forceinline__ uint32_t roll_back_from(const DevGeom &g, uint32_t *t
 					continue;
 				}
 			}
-			const Undo u = undo[idx];
+			const Undo u = undo_record(undo, tv.sorted, tv.sorted_on, g.hash_mask, idx, reqc[idx], st);
 			if ((st & 0x7fu) == ctag) {
 				const ChainLog *L = &chain_logs[u.word0];
 				const uint32_t n = L->n < (uint32_t)kChainLogWords ? L->n : (uint32_t)kChainLogWords;
@@ -1810,8 +1859,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		const ChainLog *chain_logs,
 		uint32_t *glist, int max_rounds,
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
-		int dbg_path, int round2_hint, uint32_t req_cap)
+		int dbg_path, int round2_hint, uint32_t req_cap, Sorted S, int sorted_hint)
 {
+	// (S, sorted_hint: the pass was enqueued as a BIG one -- partition, then apply per bucket, mkv_upd_apply.h; if it ran
+	// that way, Ctl::sorted_fail, the commits of k_apply are looked for in its bins: Tv::sorted)
 	// (round2_hint >= 0: ROUND 2 runs here, as the launch's first phase, with that record_hint -- a launch that
 	// finds nothing to do costs 4.6 - 5 us in this chain, and since a bucket's second registrant helps itself
 	// in round 1 the usual batch leaves round 2 nothing: what is left of its losers takes the lanes of this
@@ -1920,7 +1971,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		nwg = 1u;
 		round_body<OP, 2, kTailThreads>(0u, 1u, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
 				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
-				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, s_few, s_few_n);
+				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, S, s_few, s_few_n);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (every lane's stores have left before anybody reads on)
 		wg_sync();
 		// ... and that was it, as a rule: the pass's epilogue stays pending then, as on the way out above
@@ -1932,7 +1983,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		static_assert(RoundLds<2, kTailThreads>::bytes <= sizeof(lkeys), "round 2's LDS in the work list's");
 		round_body<OP, 2, kTailThreads>(wg, nwg, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
 				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
-				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr);
+				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, S);
 		grid_sync(&ctl->sync_r2, nwg);
 	}
 	// Round 2 left nothing (or the epilogue is wanted for its own sake): no lists, no scans, no meetings --
@@ -2055,6 +2106,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	tv.undo = undo;
 	tv.chain_logs = chain_logs;
 	tv.ctl = ctl;
+	tv.sorted = S;
+	tv.sorted_on = sorted_hint != 0 && ctl->sorted_fail != (uint32_t)stamp1;
 	uint32_t rounds_total = 0;
 	while (work_left) {
 		const uint32_t m = s_n;
@@ -2212,7 +2265,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 						const uint32_t st = state[k];
 						if (st != tag && st != ctag)
 							continue;
-						take_back(g, table, state, reqc, undo, chain_logs, k, st == ctag);
+						take_back(g, table, state, reqc, undo, chain_logs, k, st == ctag, tv, st);
 						if (reqc[k].w & kLeadBit) {         // its shadows are requests of their own again
 							const uint32_t at = atomicAdd(&s_ntrunc, 1u);
 							if (at < kTruncCap)
@@ -2238,7 +2291,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 					s_ntrunc = 0u;                      // (what select_from noted is found again by index)
 				__syncthreads();
 				u = roll_back_from(g, table, state, reqc, undo, chain_logs, s_thr, lo_idx, total, 0u, 1u, nullptr, s_trunc,
-						&s_ntrunc);
+						&s_ntrunc, tv);
 			}
 			// groups of duplicates that begin below a violation's index and reach beyond it: cut there
 			__syncthreads();
@@ -2298,6 +2351,9 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->any_loser = ctl->any_tail = 0;
 		ctl->force_tail = 0;
 		ctl->hint_stamp = 0;
+		ctl->sorted_fail = 0;
+		ctl->sorted_nlosers = 0;
+		ctl->sorted_passes = ctl->sorted_fallbacks = 0;
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k].n = ctl->committed[1][k].n = ctl->committed[2][k].n = ctl->committed[3][k].n = 0;
 		for (uint32_t k = 0; k < kTlGroups; k++)

@@ -83,6 +83,7 @@
 #include "mkv_upd_mark.h"
 #include "mkv_upd_round.h"
 #include "mkv_upd_tail.h"
+#include "mkv_upd_apply.h"
 
 // ---- host side: chunking, workspaces, ordering across streams, launches, the C entry points ----
 namespace mkv {
@@ -111,6 +112,8 @@ struct Workspace {
 	uint32_t *glist = nullptr;
 	ChainLog *chain_logs = nullptr;        // kChainLogCap logs of the grid-wide rounds' chains, then one per lane
 	                                       // of the tail launch (kTailLanes)
+	Sorted sorted = {};                    // big passes (mkv_upd_apply.h): the bins, their hash tables and logs, the list for round 2
+	bool cycle_sorted = false;             // the first half of an mkv_cycle insert enqueued the partition, not the mark pass
 	Ctl *ctl = nullptr;
 	// mkv_cycle only: side stream on which the table-independent mark pass of the
 	// insert overlaps the search kernel, and the fork/join events
@@ -152,6 +155,12 @@ static void free_ws(Workspace *w)
 	if (w->lost) (void)hipFree(w->lost);
 	if (w->glist) (void)hipFree(w->glist);
 	if (w->chain_logs) (void)hipFree(w->chain_logs);
+	if (w->sorted.rec) (void)hipFree(w->sorted.rec);
+	if (w->sorted.cursor) (void)hipFree(w->sorted.cursor);
+	if (w->sorted.heads) (void)hipFree(w->sorted.heads);
+	if (w->sorted.next) (void)hipFree(w->sorted.next);
+	if (w->sorted.undo) (void)hipFree(w->sorted.undo);
+	if (w->sorted.losers) (void)hipFree(w->sorted.losers);
 	if (w->ctl) (void)hipFree(w->ctl);
 	if (w->host_flag) (void)hipHostFree((void *)w->host_flag);
 	if (w->aux) (void)hipStreamDestroy(w->aux);
@@ -237,6 +246,18 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	ok = ok && hipMalloc(&w->lost, (size_t)rc * 4) == hipSuccess;
 	ok = ok && hipMalloc(&w->chain_logs, ((size_t)kChainLogCap + kTailLanes) * sizeof(ChainLog)) == hipSuccess;
 	ok = ok && hipMalloc(&w->ctl, sizeof(Ctl)) == hipSuccess;
+	// big passes: at most 2^kSortBinsLog2 bins of kSortBinCap records whatever the table (30 MiB), a list entry per request
+	constexpr size_t kBinsMax = (size_t)1 << kSortBinsLog2;
+	ok = ok && hipMalloc(&w->sorted.rec, kBinsMax * kSortBinCap * sizeof(uint4)) == hipSuccess;
+	ok = ok && hipMalloc(&w->sorted.cursor, 2 * kBinsMax * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMalloc(&w->sorted.heads, kBinsMax * kSortHeads * sizeof(uint16_t)) == hipSuccess;
+	ok = ok && hipMalloc(&w->sorted.next, kBinsMax * kSortBinCap * sizeof(uint16_t)) == hipSuccess;
+	ok = ok && hipMalloc(&w->sorted.undo, kBinsMax * kSortBinCap * sizeof(uint2)) == hipSuccess;
+	ok = ok && hipMalloc(&w->sorted.losers, (size_t)rc * 4) == hipSuccess;
+	if (ok) {
+		w->sorted.count = w->sorted.cursor + kBinsMax;
+		ok = hipMemsetAsync(w->sorted.cursor, 0, 2 * kBinsMax * sizeof(uint32_t), stream) == hipSuccess;
+	}
 	if (ok) {
 		void *hf = nullptr;
 		ok = hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess;
@@ -400,17 +421,49 @@ static int64_t ws_need(const ReqSrc &src, long long hint = 0)
 // K1 alone: touches the requests and the workspace, never the table.
 template <Op OP>
 static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream,
-		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
+		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone, bool fallback = false)
 {
+	// (fallback: behind a big pass's partition -- the launch leaves at once unless that gave up, mark_body)
 	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)MKV_DIAG(mark_alone_blocks)), dim3(256), 0, stream, w->ctl, src, g,
-			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table, tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0),
+			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table,
+			tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0) | (fallback ? 0x200 : 0),
 			tuning().plans ? w->undo : nullptr, w->lost);
+}
+
+// ---- big passes: partition, then apply per bucket (mkv_upd_apply.h) ----------------------------------------------
+static Sorted sorted_of(Workspace *w, const DevGeom &g)
+{
+	Sorted S = w->sorted;
+	uint32_t bucket_bits = 0;
+	while (((uint64_t)1 << bucket_bits) <= g.hash_mask)
+		bucket_bits++;
+	S.bin_shift = bucket_bits > kSortBinsLog2 ? bucket_bits - kSortBinsLog2 : 0u;
+	S.nbins = (uint32_t)(((uint64_t)g.hash_mask + 1u) >> S.bin_shift);
+	return S;
+}
+
+// A pass goes that way when it is announced big enough to pay for the extra launches (Tuning::sorted_min), is the
+// call's only pass, and an even spread over the bins would fill them to two thirds at most (a skewed one overflows
+// a bin, which the device finds out: Ctl::sorted_fail, and the pass runs the old way behind the partition).
+static bool sorted_wanted(Workspace *w, const DevGeom &g, long long hint, bool is_delete, int nchunks)
+{
+	const long long smin = tuning().sorted_min;
+	if (is_delete || smin <= 0 || hint < smin || nchunks != 1 || !w->sorted.rec)
+		return false;
+	const Sorted S = sorted_of(w, g);
+	return hint <= (long long)S.nbins * (long long)(kSortBinCap * 2u / 3u);
+}
+
+static uint32_t part_blocks_for(long long hint)
+{
+	const long long b = (hint + kPartTile - 1) / kPartTile;
+	return (uint32_t)(b < 1 ? 1 : (b > 1024 ? 1024 : b));
 }
 
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
 		uint32_t lo = 0, uint32_t hi = kNone, int first_chunk = 1, int last_chunk = 1, hipEvent_t done_ev = nullptr,
-		long long hint = 0, bool plans_ok = true);
+		long long hint = 0, bool plans_ok = true, bool sorted = false);
 
 // Canonical-index passes of one call.  With a size hint from the caller a large batch runs
 // pass after pass (stream order = canonical order), Tuning::insert_chunk requests each; no
@@ -508,11 +561,18 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 		hint = src.single_n;               // delete: the count is a host value
 	const Chunking ck = pick_chunking(w, hint, OP == OP_CUCKOO);
 	const int nchunks = ck.passes;
+	const bool sorted = sorted_wanted(w, g, hint, OP == OP_DELETE, nchunks);
 	for (int c = 0; c < nchunks; c++) {
 		uint32_t lo, hi;
 		chunk_range(c, ck, &lo, &hi);
-		launch_mark<OP>(w, g, src, stream, table, lo, hi);
-		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : hint);
+		if constexpr (OP != OP_DELETE) {
+			if (sorted)
+				hipLaunchKernelGGL((k_part<OP>), dim3(part_blocks_for(hint)), dim3(kPartThreads), 0, stream, w->ctl, src, g,
+						sorted_of(w, g), w->reqc, w->state, (uint32_t)w->req_cap, hi);
+		}
+		launch_mark<OP>(w, g, src, stream, table, lo, hi, sorted);
+		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : hint,
+				true, sorted);
 		if (rc != MKV_OK)
 			return rc;
 	}
@@ -549,8 +609,18 @@ static unsigned tail_groups_for()
 // the marker packet of its own (3 us between two kernels of a stream, tools/probes/event_probe.hip)
 template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
-		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev, long long hint, bool plans_ok)
+		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev, long long hint, bool plans_ok, bool sorted)
 {
+	// (sorted: the pass's requests went through the partition, k_part / k_search_part, and a fall-back mark pass is
+	// enqueued behind that: k_apply comes first here, and the rounds and the tail are told -- bits 9 / 10 of the
+	// hint -- to ask the device which way the pass went, Ctl::sorted_fail)
+	Sorted S = {};
+	if constexpr (OP != OP_DELETE) {
+		if (sorted) {
+			S = sorted_of(w, g);
+			hipLaunchKernelGGL((k_apply<OP>), dim3(S.nbins), dim3(kApplyThreads), 0, stream, w->ctl, g, table, S, w->state, w->owner[1]);
+		}
+	}
 	// (hint: the caller's upper bound on the pass's requests, 0 = unknown)
 	// (plans_ok: nothing has written the table since this pass's mark pass read it -- false for the insert of a
 	// cycle whose mark pass rode in the search launch ahead of the cycle's deletes)
@@ -561,7 +631,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	// bit 3 -- no groups of duplicates; bit 5 -- no self-help of a bucket's second registrant
 	// bit 6 -- round 1 carries out the mark pass's plans (kPlanBit)
 	const int rhint = (MKV_DIAG(debug_skip) & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32) |
-			(plans_ok && tuning().plans ? 64 : 0);
+			(plans_ok && tuning().plans ? 64 : 0) | (sorted ? 512 | 1024 : 0);
 	// (a pass announced with fewer requests than round 1's grid has lanes: as many work-groups as it takes --
 	// 208 instead of 512 are 0.5 us of a 52 K-request pass)
 	// (not while round 1 has been leaving round 2 a lot, or chains have been running late: what a work-group
@@ -580,12 +650,12 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	}
 	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
 			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost);
+			rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost, S);
 	// round 2: inside the tail launch (k_tail's first phase), unless the pass is announced with more
 	// requests than that launch has lanes for in a few turns, or is a delete
 	// (word 3 of the tail kernel's flags, read without synchronising -- a pass late, which only costs time:
 	// round 1 has been leaving round 2 a lot: duplicates of hot keys, say)
-	const bool merged = OP != OP_DELETE && tuning().merge_round2 != 0 && hint <= (long long)tuning().merge_max &&
+	const bool merged = OP != OP_DELETE && tuning().merge_round2 != 0 && hint <= (long long)tuning().merge_max && !sorted &&
 			!(w->host_flag && w->host_flag[3] && tuning().merge_round2 == 1);
 	// (round 2 looks at every request's tag to find its few: a lane per announced request, within 2048
 	// work-groups -- 524 K tags on the 512 work-groups of round 1 took 15 us, on 2048 they take 6.5)
@@ -594,12 +664,12 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (!merged)
 		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr);
+				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr, S);
 	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
 			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
 			tail_rounds, lo, hi, first_chunk,
 			last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min), (uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3,
-			merged ? rhint : -1, (uint32_t)w->req_cap);
+			merged ? rhint : -1, (uint32_t)w->req_cap, S, sorted ? 1 : 0);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 
@@ -670,6 +740,7 @@ extern "C" int mkv_cycle_insert_begin(const mkv_geom_t *geom, const bucket_t *ta
 		return MKV_EHIP;
 	uint32_t lo, hi;
 	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
+	w->cycle_sorted = false;
 	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, w->aux, nullptr, lo, hi);
@@ -715,7 +786,9 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	uint32_t lo, hi;
 	w->cycle_ck = mkv::pick_chunking(w, size_hint, d.scheme == MKV_SCHEME_CUCKOO);
 	mkv::chunk_range(0, w->cycle_ck, &lo, &hi);
-	const uint32_t mark_blocks = mkv::mark_blocks_for(size_hint, w->barrier_score > 0);
+	// a big pass: the partition rides in the search launch in the mark pass's place (mkv_upd_apply.h)
+	w->cycle_sorted = mkv::sorted_wanted(w, d, size_hint, false, w->cycle_ck.passes);
+	const uint32_t mark_blocks = w->cycle_sorted ? mkv::part_blocks_for(size_hint) : mkv::mark_blocks_for(size_hint, w->barrier_score > 0);
 	if (search_blocks + mark_blocks > 0x7fffffffLL)
 		return MKV_ETOOBIG;
 	const dim3 grid((unsigned)(search_blocks + mark_blocks)), block(256);
@@ -723,6 +796,16 @@ extern "C" int mkv_cycle_search_mark(const mkv_geom_t *geom, const selem_t *in, 
 	// hipExtLaunchKernelGGL -- i.e. the kernel's duration as a profiler sees it, without the
 	// launch latency a pair of hipEventRecord calls around the launch includes)
 	hipEvent_t e0 = (hipEvent_t)ev_start, e1 = (hipEvent_t)ev_stop;
+	if (w->cycle_sorted) {
+		const mkv::Sorted S = mkv::sorted_of(w, d);
+		if (d.scheme == MKV_SCHEME_2CHOICE)
+			MKV_LAUNCH_TIMED((mkv::k_search_part<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
+					(uint32_t)search_blocks, w->ctl, src, d, S, w->reqc, w->state, (uint32_t)w->req_cap, hi);
+		else
+			MKV_LAUNCH_TIMED((mkv::k_search_part<mkv::OP_CUCKOO>), grid, block, s, e0, e1, in2, out, t4, num_search,
+					(uint32_t)search_blocks, w->ctl, src, d, S, w->reqc, w->state, (uint32_t)w->req_cap, hi);
+		return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+	}
 	if (d.scheme == MKV_SCHEME_2CHOICE)
 		MKV_LAUNCH_TIMED((mkv::k_search_mark<mkv::OP_2CHOICE>), grid, block, s, e0, e1, in2, out, t4, num_search,
 				(uint32_t)search_blocks, w->ctl, src, d, w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, hi,
@@ -764,16 +847,19 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 	for (int c = 0; c < nchunks; c++) {
 		uint32_t lo, hi;
 		mkv::chunk_range(c, ck, &lo, &hi);
+		// (a big pass, partitioned in the search launch: its fall-back's mark pass runs here, behind the cycle's
+		// deletes -- its plans stand; the partition itself never looked at the table)
+		const bool sorted = c == 0 && w->cycle_sorted;
 		if (d.scheme == MKV_SCHEME_2CHOICE) {
-			if (c > 0)
-				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
+			if (c > 0 || sorted)
+				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi, sorted);
 			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint,
-					c > 0 || !stale);
+					c > 0 || !stale || sorted, sorted);
 		} else {
-			if (c > 0)
-				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
+			if (c > 0 || sorted)
+				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi, sorted);
 			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint,
-					c > 0 || !stale);
+					c > 0 || !stale || sorted, sorted);
 		}
 		if (rc != MKV_OK)
 			return rc;
@@ -1233,6 +1319,38 @@ extern "C" int mkv_last_update_info_ex(void *stream, int cycle_insert, mkv_updat
 	info->tail_rounds = h.last.tail_rounds;
 	info->helped = h.last.helped;
 	info->losers = h.last.losers;
+	return MKV_OK;
+}
+
+// Big insert passes (partition, then apply per bucket: mkv_upd_apply.h) on the device's workspace so far:
+// out[0] = passes that ran that way, out[1] = passes whose partition gave up (a bin overflowed: they ran the
+// reservation rounds), out[2] = requests the last such pass left over for round 2 and the tail, out[3] = 0.
+// Waits for `stream`.
+extern "C" int mkv_sorted_stats(void *stream, int cycle_insert, uint32_t out[4])
+{
+	if (!out)
+		return MKV_EINVAL;
+	int dev = 0;
+	if (hipGetDevice(&dev) != hipSuccess)
+		return MKV_EHIP;
+	mkv::Workspace *w = nullptr;
+	{
+		std::lock_guard<std::mutex> lock(mkv::g_ws_mutex);
+		auto it = mkv::g_ws.find(((uint64_t)dev << 1) | (cycle_insert ? 1ull : 0ull));
+		if (it == mkv::g_ws.end() || !it->second->ctl)
+			return MKV_EINVAL;
+		w = it->second;
+	}
+	if (hipStreamSynchronize((hipStream_t)stream) != hipSuccess)
+		return MKV_EHIP;
+	uint32_t h[3];
+	static_assert(offsetof(mkv::Ctl, sorted_fallbacks) == offsetof(mkv::Ctl, sorted_nlosers) + 8, "three words in a row");
+	if (hipMemcpy(h, &w->ctl->sorted_nlosers, sizeof(h), hipMemcpyDeviceToHost) != hipSuccess)
+		return MKV_EHIP;
+	out[0] = h[1];
+	out[1] = h[2];
+	out[2] = h[0];
+	out[3] = 0u;
 	return MKV_OK;
 }
 

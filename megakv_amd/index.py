@@ -214,6 +214,12 @@ class HashIndex:
         _check(self.lib.mkv_reserve(ctypes.byref(self._g), int(max_requests), _stream_ptr(stream)),
                "mkv_reserve")
 
+    def sorted_stats(self, stream=None, cycle_insert=False):
+        """big insert passes of the device's workspace so far: {passes, fallbacks, left_over (last pass)}"""
+        out = (ctypes.c_uint32 * 4)()
+        _check(self.lib.mkv_sorted_stats(_stream_ptr(stream), 1 if cycle_insert else 0, ctypes.byref(out)), "mkv_sorted_stats")
+        return {"passes": int(out[0]), "fallbacks": int(out[1]), "left_over": int(out[2])}
+
     def last_update_info(self, stream=None, cycle_insert=False):
         info = MkvUpdateInfo()
         _check(self.lib.mkv_last_update_info_ex(_stream_ptr(stream), 1 if cycle_insert else 0,

@@ -43,7 +43,7 @@ ABI_SYMBOLS = [
     "mkv_search_slots", "mkv_unpack_results", "mkv_slots_cycle", "mkv_derive_requests", "mkv_resolve_results", "mkv_resolve_verify", "mkv_last_update_info_ex", "mkv_timer_create", "mkv_timer_elapsed_ms", "mkv_timer_destroy",
     "mkv_shard_create", "mkv_shard_unique_id", "mkv_shard_connect", "mkv_shard_run", "mkv_shard_overflowed",
     "mkv_shard_error", "mkv_shard_destroy", "mkv_shard_trace", "mkv_shard_phases", "mkv_parse_scratch_bytes", "mkv_parse_packets",
-    "mkv_set_defer", "mkv_flush", "mkv_forget_stream", "mkv_dropped_batches", "mkv_workspace_bytes", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
+    "mkv_set_defer", "mkv_flush", "mkv_forget_stream", "mkv_dropped_batches", "mkv_sorted_stats", "mkv_workspace_bytes", "mkv_pipe_create", "mkv_pipe_run", "mkv_pipe_error", "mkv_pipe_destroy", "mkv_host_alloc", "mkv_host_free",
     "cudaMalloc", "cudaFree", "cudaHostAlloc", "cudaFreeHost", "cudaMemset",
     "cudaMemsetAsync", "cudaMemcpy", "cudaMemcpyAsync", "cudaStreamCreate",
     "cudaStreamDestroy", "cudaStreamSynchronize", "cudaDeviceSynchronize",
@@ -115,6 +115,8 @@ def _load(LIB_PATH, diagnostics):
     L.mkv_flush.argtypes = []
     L.mkv_dropped_batches.restype = ctypes.c_ulonglong
     L.mkv_dropped_batches.argtypes = []
+    L.mkv_sorted_stats.restype = INT
+    L.mkv_sorted_stats.argtypes = [P, INT, ctypes.POINTER(U32 * 4)]
     L.mkv_workspace_bytes.restype = ctypes.c_longlong
     L.mkv_workspace_bytes.argtypes = []
     L.mkv_timer_create.restype = P

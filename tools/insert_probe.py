@@ -52,7 +52,8 @@ def main():
         idx.insert(blocks)
         b.record()
         torch.cuda.synchronize()
-        print(f"batch {i}: {a.elapsed_time(b) * 1e3:9.1f} us  {idx.last_update_info()} tail phases us {idx.tail_phases_us()}", flush=True)
+        print(f"batch {i}: {a.elapsed_time(b) * 1e3:9.1f} us  {idx.last_update_info()} tail phases us {idx.tail_phases_us()} "
+              f"big passes {idx.sorted_stats()}", flush=True)
 
 
 if __name__ == "__main__":
