@@ -143,7 +143,8 @@ long long mkv_workspace_bytes(void);
 unsigned long long mkv_dropped_batches(void);
 
 /* Big insert passes -- a pass announced (mkv_insert_hinted, mkv_cycle's insert_hint) with at least
- * MKV_SORTED_MIN requests (tuning "sorted_min", default 131072; 0: never) is split into bins by bucket
+ * MKV_SORTED_MIN requests (tuning "sorted_min"; default 0: never -- the path is exact but measured no
+ * faster than the reservation rounds on MI355X) is split into bins by bucket
  * range and applied per bucket with one line read and one whole-line write, no reservation atomics;
  * what is not settled in its primary bucket goes through round 2 and the tail as ever.  Statistics of
  * the current device's workspace (cycle_insert: the one mkv_cycle's inserts use): out[0] = passes that

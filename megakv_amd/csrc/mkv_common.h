@@ -79,7 +79,7 @@ __device__ __forceinline__ uint32_t preferred_slot(uint32_t empties, uint32_t or
 }
 
 // Process-wide tuning knobs (defaults = measured best on MI355X).  Initialised from the environment
-// (MKV_<NAME>) on first use, changeable through mkv_set_tuning().  Seventeen of them; what only tests and probes
+// (MKV_<NAME>) on first use, changeable through mkv_set_tuning().  Eighteen of them; what only tests and probes
 // ever set -- how the tail takes an order violation back, layouts kept for the record, sizes whose sweeps are
 // flat -- exists in the diagnostics build only (DiagTuning below) and is a constant in the product.
 struct Tuning {
@@ -106,6 +106,8 @@ struct Tuning {
 	long long sorted_min;   // an insert pass announced with at least this many requests (one pass, not a chunk of several) is
 	                        // partitioned into bins and applied per bucket, whole-bucket write-back, no reservation atomics
 	                        // (mkv_upd_apply.h); 0: never
+	int sorted_cooldown;    // ... and after such a pass that fell back or left over more than one request in 256, this many big
+	                        // passes run the old way before one is tried again (0: never back off -- tests)
 };
 Tuning &tuning();
 

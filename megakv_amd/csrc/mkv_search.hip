@@ -132,7 +132,8 @@ Tuning &tuning()
 		v.plans = (int)env("MKV_PLANS", 1, 0, 1);
 		v.merge_round2 = (int)env("MKV_MERGE_ROUND2", 1, 0, 2);      // (2: even when round 1 has been leaving round 2 a lot)
 		v.merge_max = env("MKV_MERGE_MAX", 131072, 0, 1ll << 40);
-		v.sorted_min = env("MKV_SORTED_MIN", 131072, 0, 1ll << 40);
+		v.sorted_min = env("MKV_SORTED_MIN", 0, 0, 1ll << 40);       // (off by default: DESIGN.md 5.2 item 15 -- exact, not faster)
+		v.sorted_cooldown = (int)env("MKV_SORTED_COOLDOWN", 32, 0, 1000000);
 		return v;
 	}();
 	return t;
@@ -195,7 +196,7 @@ extern "C" int mkv_set_tuning(const char *name, long long value)
 		{"tail_groups", &t.tail_groups, nullptr, 1, 64}, {"dup_groups", &t.dup_groups, nullptr, 0, 1},
 		{"lazy_alt", &t.lazy_alt, nullptr, 0, 8}, {"self_help", &t.self_help, nullptr, 0, 1}, {"plans", &t.plans, nullptr, 0, 1},
 		{"merge_round2", &t.merge_round2, nullptr, 0, 2}, {"merge_max", nullptr, &t.merge_max, 0, 1ll << 40},
-		{"sorted_min", nullptr, &t.sorted_min, 0, 1ll << 40},
+		{"sorted_min", nullptr, &t.sorted_min, 0, 1ll << 40}, {"sorted_cooldown", &t.sorted_cooldown, nullptr, 0, 1000000},
 #ifdef MKV_DIAGNOSTICS
 		{"search_wide", &mkv::diag_tuning().search_wide, nullptr, 0, 1}, {"search_lds", &mkv::diag_tuning().search_lds, nullptr, 0, 1},
 		{"pack_three_pass", &mkv::diag_tuning().pack_three_pass, nullptr, 0, 1},

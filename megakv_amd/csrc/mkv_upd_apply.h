@@ -11,8 +11,8 @@
 //      loc, index} -- per tile of 2 048 requests a histogram in LDS, one returning atomic per (tile, bin) on the bin's
 //      cursor, the records stored where the cursors say.  It also fills the request cache and tags every request
 //      ST_ROUND1 -- in index order, streamed.  A bin that overflows (kSortBinCap: a pass of duplicates of one hot key)
-//      makes the pass run the OLD way: Ctl::sorted_fail, and the fall-back launches enqueued behind it -- a mark pass,
-//      round 1 -- which leave at once otherwise, do their work.
+//      makes k_apply leave EVERY request of the pass to round 2 (Ctl::sorted_fail): exact, slow, and the host is told
+//      (word 5 of its flags) so that it runs the next passes the old way.
 //   2. APPLY (a launch behind the search): a work-group per bin.  The bin goes into LDS and is linked into a chained
 //      hash table over its requests' buckets; the request with the LOWEST index of a bucket loads the bucket (a quad of
 //      lanes a line, load_bucket_quad) and applies the bucket's requests in index order in registers -- a duplicate's
@@ -142,7 +142,7 @@ __device__ __forceinline__ void partition_body(uint32_t block, uint32_t nblocks,
 		__syncthreads();
 		for (uint32_t b = t; b < nbins; b += blockDim.x) {
 			const uint32_t c = s_hist[b];
-			s_base[b] = c ? atomicAdd(&S.cursor[b], c) : 0u;
+			s_base[b] = c ? atomicAdd(&S.cursor[b * kSortCursorStride], c) : 0u;
 		}
 		__syncthreads();
 		// pass 2: the records to their bins, the request cache and the tags in index order
@@ -179,7 +179,7 @@ __device__ __forceinline__ void partition_body(uint32_t block, uint32_t nblocks,
 		__syncthreads();
 	}
 	if (fail || (over && block == 0 && t == 0))
-		ctl->sorted_fail = (uint32_t)stamp;     // (an oversize batch: the fall-back's mark pass drops it the usual way)
+		ctl->sorted_fail = (uint32_t)stamp;     // (an oversize batch: total 0, nothing to do -- the tail's epilogue counts the drop)
 }
 
 template <Op OP>
@@ -217,54 +217,11 @@ __device__ __forceinline__ void store_bucket_quad(uint32_t *table, uint32_t b, c
 	if (b3 != kNone) t4[(uint64_t)b3 << 2] = a3;
 }
 
-__device__ __forceinline__ void put4(uint4 &v, uint32_t s, uint32_t x)
-{
-	v.x = s == 0u ? x : v.x;
-	v.y = s == 1u ? x : v.y;
-	v.z = s == 2u ? x : v.z;
-	v.w = s == 3u ? x : v.w;
-}
-
-// what place_loaded does, on the bucket in registers only: true = settled there.  `written`: the slots requests of this
-// pass have written so far -- a request that would rewrite one of them is not settled here (its commit and the earlier
-// one would share a word: they could not be taken back independently).
-__device__ __forceinline__ bool apply_in_registers(Bkt &k, uint32_t sig, uint32_t loc, uint32_t &written, uint2 *log)
-{
-	if (sig == 0u)
-		return false;                       // (signature 0 "matches" every empty slot, ref :277-287: left to the tail)
-	const uint32_t m = eq_mask(k.s0, k.s1, sig);
-	uint32_t s, code;
-	if (m) {
-		s = (uint32_t)__ffs((int)m) - 1u;
-		if ((written >> s) & 1u)
-			return false;
-		code = s;
-	} else {
-		const uint32_t e = eq_mask(k.s0, k.s1, 0u);
-		if (!e)
-			return false;
-		s = preferred_slot(e, sig);
-		code = s | 8u;
-		if (s & 4u)
-			put4(k.s1, s & 3u, sig);
-		else
-			put4(k.s0, s & 3u, sig);
-	}
-	log->x = code;
-	log->y = loc_at(k, s);
-	if (s & 4u)
-		put4(k.l1, s & 3u, loc);
-	else
-		put4(k.l0, s & 3u, loc);
-	written |= 1u << s;
-	return true;
-}
-
 constexpr uint32_t kApplyThreads = 512;
 
 template <Op OP>
 __global__ __launch_bounds__(kApplyThreads) void k_apply(Ctl *ctl, DevGeom g, uint32_t *table, Sorted S, uint8_t *state,
-		unsigned long long *owner_next)
+		unsigned long long *owner_next, const uint4 *reqc)
 {
 	__shared__ uint4 s_rec[kSortBinCap];                // 32 KB
 	__shared__ uint2 s_log[kSortBinCap];                // 16 KB
@@ -274,18 +231,16 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(Ctl *ctl, DevGeom g, ui
 	const uint32_t t = threadIdx.x, bin = blockIdx.x;
 	const unsigned long long stamp1 = ctl->stamp_cur;
 	const bool failed = ctl->sorted_fail == (uint32_t)stamp1;
-	uint32_t n = S.cursor[bin];
+	uint32_t n = S.cursor[bin * kSortCursorStride];
 	__syncthreads();
 	if (t == 0)
-		S.cursor[bin] = 0u;                             // (for the next pass's partition)
+		S.cursor[bin * kSortCursorStride] = 0u;         // (for the next pass's partition)
 	if (bin == 0 && t == 0) {
 		if (failed)
 			ctl->sorted_fallbacks = ctl->sorted_fallbacks + 1u;
 		else
 			ctl->sorted_passes = ctl->sorted_passes + 1u;
 	}
-	if (failed)
-		return;                                         // the pass runs the old way: mark pass and round 1 behind this launch
 	n = n < kSortBinCap ? n : kSortBinCap;
 	// what the first work-group of round 1 does for the kernels behind it (round_body)
 	if (bin == 0) {
@@ -297,6 +252,35 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(Ctl *ctl, DevGeom g, ui
 		}
 		for (uint32_t q = t; q < kTlGroups; q += blockDim.x)
 			ctl->tl_cnt[1][q] = 0u;
+	}
+	const unsigned long long stamp2 = stamp1 + 1ull;
+	if (failed) {
+		// The partition gave up (a bin overflowed: a pass of duplicates of a few keys): NOTHING is applied here.  Every
+		// request of the pass is left to round 2 -- tagged, registered there on both its buckets (folded per wave: the
+		// duplicates sit next to each other), the list the identity -- and the bins are left empty.  Exact like any
+		// round 2; slow (the host, told through its flag word 5, runs the next passes the old way).
+		for (uint32_t q = t; q < kSortHeads; q += blockDim.x)
+			S.heads[(size_t)bin * kSortHeads + q] = (uint16_t)kSortNone16;
+		if (t == 0)
+			S.count[bin] = 0u;
+		const uint32_t total = ctl->total;
+		const uint4 *reqc4 = reqc;
+		for (uint32_t base = bin * blockDim.x; base < total; base += gridDim.x * blockDim.x) {
+			const uint32_t idx = base + t;
+			const bool live = idx < total && state[idx] == ST_ROUND1;
+			const uint4 r = live ? reqc4[idx] : make_uint4(0u, 0u, 0u, 0u);
+			const uint32_t P = r.y & g.hash_mask, A = alt_bucket(r.y, r.x, g.hash_mask, g.blk_mask);
+			if (idx < total)
+				S.losers[idx] = idx;                    // (a request that is not pending is skipped by its tag)
+			if (live)
+				state[idx] = ST_LOSER;
+			reserve_wave(owner_next, P, A, owner_key(stamp2, idx), live);
+		}
+		if (bin == 0 && t == 0) {
+			ctl->sorted_nlosers = total;
+			ctl->any_loser = 1u;
+		}
+		return;
 	}
 	if (t == 0) {
 		S.count[bin] = n;
@@ -369,7 +353,6 @@ __global__ __launch_bounds__(kApplyThreads) void k_apply(Ctl *ctl, DevGeom g, ui
 	}
 	__syncthreads();
 	// what was not applied: to round 2 -- tagged, registered on both its buckets in that round's table, listed
-	const unsigned long long stamp2 = stamp1 + 1ull;
 	uint32_t mine = 0;
 	for (uint32_t s = t; s < n; s += blockDim.x)
 		mine += s_log[s].x == kNone ? 1u : 0u;

@@ -142,7 +142,7 @@ struct Ctl {
 	uint32_t any_hard;               // a request was left to the tail needing an eviction chain
 	uint32_t r1_wide;                // a BIG pass's round 1 runs on a lane per request (Ctl::unplanned below)
 	uint32_t sorted_fail;            // low word of the round-1 stamp of the last pass whose PARTITION gave up (a bin overflowed,
-	                                 // mkv_upd_apply.h): that pass runs the old way -- mark, rounds -- behind it
+	                                 // mkv_upd_apply.h): k_apply then leaves EVERY request of the pass to round 2
 	uint32_t first_hard;
 	uint32_t chain_n;                // chain-log entries handed out this call
 	uint32_t chain_ok;               // chains committed optimistically
@@ -173,6 +173,7 @@ struct Ctl {
 	uint32_t sorted_nlosers;         // big passes: requests k_apply left to round 2 (listed in Sorted::losers); reset by the partition
 	uint32_t sorted_passes;          // ... passes k_apply has run so far / passes whose partition gave up (mkv_sorted_stats)
 	uint32_t sorted_fallbacks;
+	uint32_t hf_sorted;              // what word 5 of the host-mapped flags holds (round_body, sorted)
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)

@@ -43,10 +43,6 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 	const unsigned long long stamp_prev = ctl->stamp_base;
 	const uint32_t ep_pending = ctl->ep_pending;
 	const unsigned long long stamp = stamp_prev + (ep_pending ? 3ull : 0ull);
-	// (bit 9 of the hint: this launch is the fall-back behind a big pass's partition, k_search_part -- it runs only
-	// if that gave up; every lane reads the same word: only the kernel before this one writes it)
-	if ((lazy_free & 0x200u) != 0u && ctl->sorted_fail != (uint32_t)stamp)
-		return;
 	Lost lost;
 	lost.flag = OP != OP_DELETE && undo ? lost_flags : nullptr;
 	lost.s32 = (uint32_t)stamp;
@@ -222,8 +218,18 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 // roll-back behind a barrier.  Follows ref gpu_hash.cu:357-423.
 __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint32_t A, uint32_t idx,
 		unsigned long long *owner1, unsigned long long stamp1, Ctl *ctl, ChainLog *logs, uint32_t *log_slot,
-		bool own_ok, const unsigned long long *owner2)
+		bool own_ok, const unsigned long long *owner2, const uint4 *s_rec, const uint16_t *s_heads, const uint16_t *s_next,
+		uint32_t s_bin_shift, bool sorted_on, const uint8_t *state)
 {
+	// (the bins by their parts: a reference to the kernel's argument would put it into scratch memory for this call)
+	Sorted S = {};
+	S.rec = const_cast<uint4 *>(s_rec);
+	S.heads = const_cast<uint16_t *>(s_heads);
+	S.next = const_cast<uint16_t *>(s_next);
+	S.bin_shift = s_bin_shift;
+	// (sorted_on: a big pass, mkv_upd_apply.h -- nobody but the requests k_apply left over stands in a reservation
+	// table: they all stand in round 2's, owner2; what k_apply COMMITTED on a bucket the chain goes on to is in its bin,
+	// and a commit of a later request there is an order violation: the chain gives up and is left to the tail)
 	// (owner2: in round 2, that round's own table -- a bucket one of ITS requests is registered on is
 	// not free either: a request that did not register on its alternate bucket in the mark pass, Tuning::lazy_alt,
 	// does so there)
@@ -278,6 +284,17 @@ __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint3
 		if (!mine) {
 			ok = false;
 			break;
+		}
+		if (sorted_on) {
+			bool later = false;
+			sorted_for_each_on(S, g.hash_mask, b, [&](const uint4 &rs, uint32_t) {
+				later = rs.w > idx && state[rs.w] == ST_ROUND1;
+				return later;
+			});
+			if (later) {
+				ok = false;
+				break;
+			}
 		}
 		uint4 lo, hi;
 		load_sig_row<false>(table, b, lo, hi);

@@ -95,21 +95,26 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, const Sorted S, const uint32_t *list_arg = nullptr,
 		uint32_t list_n_arg = 0u)
 {
-	// A BIG pass (bits 9 / 10 of the hint: the host enqueued the partition-and-apply path, mkv_upd_apply.h; whether it
-	// ran is the device's to say -- a bin that overflowed makes the pass run the old way, Ctl::sorted_fail): round 1 is
-	// then only the fall-back's and leaves at once; round 2 runs over the LIST of what k_apply left over, on as many
-	// work-groups as it takes, with every eviction chain left to the tail (nobody of the pass has registered in the
-	// round-1 table, which try_chain reads everybody's rights from) and no groups of duplicates.
-	if (ROUND == 1 && (record_hint & 1024) != 0 && ctl->sorted_fail != (uint32_t)ctl->stamp_cur)
-		return;
+	// A BIG pass (bit 9 of the hint: its requests went through the partition and k_apply, mkv_upd_apply.h; no round 1
+	// ran): round 2 runs over the LIST of what k_apply left over, on as many work-groups as it takes.  Nobody of the
+	// pass but those requests stands in a reservation table (they stand in this round's, on both their buckets); what
+	// k_apply committed on a bucket is in its bin.  No groups of duplicates.
 	const uint32_t *list = list_arg;
 	uint32_t list_n = list_n_arg;
-	bool sorted = false;
-	if (ROUND == 2 && (record_hint & 512) != 0 && list == nullptr) {
-		sorted = ctl->sorted_fail != (uint32_t)ctl->stamp_base;
-		if (sorted) {
-			list = S.losers;
-			list_n = ctl->sorted_nlosers;
+	const bool sorted = ROUND == 2 && (record_hint & 512) != 0 && list == nullptr;
+	if (sorted) {
+		list = S.losers;
+		list_n = ctl->sorted_nlosers;
+		// (word 5 of the host's flags: the pass fell back -- a bin overflowed, everything was left over -- or left
+		// over more than one request in 256: the host then runs the next passes the old way for a while.  Written
+		// when it has something new to say, with the pass's number so that the host tells a new verdict from an old one)
+		if (block == 0 && threadIdx.x == 0 && S.host_flag) {
+			const uint32_t bad = (unsigned long long)list_n * 256ull > ctl->total ? 1u : 0u;
+			if (bad || ctl->hf_sorted != 0u) {
+				const uint32_t word = bad ? (((ctl->sorted_passes + ctl->sorted_fallbacks) << 1) | 1u) : 0u;
+				S.host_flag[5] = word;
+				ctl->hf_sorted = word;
+			}
 		}
 	}
 	// (list: the round's requests by index, at most a lane each -- one turn over them instead of the scan of the
@@ -135,7 +140,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 		pre_plan = undo[pre_idx];
 	else
 		pre_plan.word0 = pre_plan.old0 = pre_plan.word1 = pre_plan.old1 = kNoWord;
-	const bool chains_here = (record_hint & 4) == 0 && !sorted;      // tests: every hard request left to the tail
+	const bool chains_here = (record_hint & 4) == 0;      // tests: every hard request left to the tail
 	const bool groups_on = (record_hint & 8) == 0 && !sorted;        // Tuning::dup_groups = 0: duplicates of a key one per round, as before
 	const bool help_on = (record_hint & 32) == 0;         // Tuning::self_help = 0: the second registrant waits for round 2, as before
 	if (ROUND == 2 && ctl->any_loser == 0u)
@@ -513,14 +518,33 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 				const uint32_t c3 = (v3 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v3 & ((1ull << kIdxBits) - 1ull)) : kNone;
 				if (!late && c3 != kNone && c3 != c1 && c3 > idx)
 					late = round_commit_used(state, reqc, undo, chain_logs, g, c3, A, &e1) && e1 > idx;
-				// ... or by k_apply (a big pass): whatever it committed there of later requests -- found in the bin
-				if (!late && sorted)
-					sorted_for_each_on(S, g.hash_mask, A, [&](const uint4 &rs, uint32_t) {
-						late = rs.w > idx && state[rs.w] == ST_ROUND1;
-						return late;
-					});
 			}
-			if (live && !late && (A == P || owner[A] == key)) {
+			const bool own = live && !late && (A == P || owner[A] == key);
+			// ... or by k_apply (a big pass): whatever it committed there of later requests is in the bin -- taken out,
+			// the request put in its place and they behind it again, in registers (resolve_late_alternate)
+			int res = 0;
+			Undo ur;
+			uint32_t dr0 = kNone, dr1 = kNone, dr2 = kNone, dr3 = kNone;
+			ur.word0 = ur.word1 = kNoWord;
+			ur.old0 = ur.old1 = 0u;
+			if (ROUND == 2 && OP != OP_DELETE && sorted && own && lazy && A != P)
+				res = resolve_late_alternate(table, g, S, state, r.sig, r.loc, idx, A, ur, dr0, dr1, dr2, dr3);
+			late = late || res == 2;
+			if (res == 1) {
+				state[idx] = ST_ROUND2;
+				undo[idx] = ur;
+				ndone++;
+				done = true;
+				if ((dr0 & dr1 & dr2 & dr3) != kNone)
+					ctl->any_tail = 1u;
+			}
+			if (sorted) {
+				tail_list_add(s_tl, &s_tln, dr0, dr0 != kNone);
+				tail_list_add(s_tl, &s_tln, dr1, dr1 != kNone);
+				tail_list_add(s_tl, &s_tln, dr2, dr2 != kNone);
+				tail_list_add(s_tl, &s_tln, dr3, dr3 != kNone);
+			}
+			if (own && res == 0) {
 				Undo u;
 				u.word0 = kNoWord;
 				u.word1 = kNoWord;
@@ -534,7 +558,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 					uint32_t log_slot = 0;
 					chained = chains_here &&
 						try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1,
-								ROUND == 2 ? owner : nullptr);
+								ROUND == 2 ? owner : nullptr, S.rec, S.heads, S.next, S.bin_shift, sorted, state);
 					hard = !chained;
 					u.word0 = log_slot;
 				}

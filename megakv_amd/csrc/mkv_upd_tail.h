@@ -1861,8 +1861,8 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
 		int dbg_path, int round2_hint, uint32_t req_cap, Sorted S, int sorted_hint)
 {
-	// (S, sorted_hint: the pass was enqueued as a BIG one -- partition, then apply per bucket, mkv_upd_apply.h; if it ran
-	// that way, Ctl::sorted_fail, the commits of k_apply are looked for in its bins: Tv::sorted)
+	// (S, sorted_hint: a BIG pass -- partition, then apply per bucket, mkv_upd_apply.h: the commits of k_apply are looked
+	// for in its bins, Tv::sorted)
 	// (round2_hint >= 0: ROUND 2 runs here, as the launch's first phase, with that record_hint -- a launch that
 	// finds nothing to do costs 4.6 - 5 us in this chain, and since a bucket's second registrant helps itself
 	// in round 1 the usual batch leaves round 2 nothing: what is left of its losers takes the lanes of this
@@ -2107,7 +2107,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	tv.chain_logs = chain_logs;
 	tv.ctl = ctl;
 	tv.sorted = S;
-	tv.sorted_on = sorted_hint != 0 && ctl->sorted_fail != (uint32_t)stamp1;
+	tv.sorted_on = sorted_hint != 0;
 	uint32_t rounds_total = 0;
 	while (work_left) {
 		const uint32_t m = s_n;
@@ -2343,7 +2343,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 	const uint32_t t = threadIdx.x;
 	if (t == 0) {
 		if (host_flag)
-			host_flag[0] = host_flag[1] = host_flag[3] = host_flag[4] = 0;     // (in step with hf_last / hf_losers / hf_walk below)
+			host_flag[0] = host_flag[1] = host_flag[3] = host_flag[4] = host_flag[5] = 0;     // (in step with hf_last / hf_losers / hf_walk / hf_sorted below)
 		ctl->stamp_base = ctl->stamp_cur = first_stamp;
 		ctl->ep_pending = 0;
 		ctl->total = 0;
@@ -2354,6 +2354,7 @@ __global__ void k_init_ctl(Ctl *ctl, unsigned long long first_stamp, uint32_t *h
 		ctl->sorted_fail = 0;
 		ctl->sorted_nlosers = 0;
 		ctl->sorted_passes = ctl->sorted_fallbacks = 0;
+		ctl->hf_sorted = 0;
 		for (int k = 0; k < kShards; k++)
 			ctl->committed[0][k].n = ctl->committed[1][k].n = ctl->committed[2][k].n = ctl->committed[3][k].n = 0;
 		for (uint32_t k = 0; k < kTlGroups; k++)

@@ -114,6 +114,8 @@ struct Workspace {
 	                                       // of the tail launch (kTailLanes)
 	Sorted sorted = {};                    // big passes (mkv_upd_apply.h): the bins, their hash tables and logs, the list for round 2
 	bool cycle_sorted = false;             // the first half of an mkv_cycle insert enqueued the partition, not the mark pass
+	uint32_t sorted_acted = 0;             // the verdict of the big-pass path on itself (host flag word 5) last acted on
+	int sorted_cooldown = 0;               // big passes still to be run the old way because of it
 	Ctl *ctl = nullptr;
 	// mkv_cycle only: side stream on which the table-independent mark pass of the
 	// insert overlaps the search kernel, and the fork/join events
@@ -249,21 +251,21 @@ static int ensure_ws(Workspace **out, uint64_t nbuckets, int64_t req_cap, hipStr
 	// big passes: at most 2^kSortBinsLog2 bins of kSortBinCap records whatever the table (30 MiB), a list entry per request
 	constexpr size_t kBinsMax = (size_t)1 << kSortBinsLog2;
 	ok = ok && hipMalloc(&w->sorted.rec, kBinsMax * kSortBinCap * sizeof(uint4)) == hipSuccess;
-	ok = ok && hipMalloc(&w->sorted.cursor, 2 * kBinsMax * sizeof(uint32_t)) == hipSuccess;
+	ok = ok && hipMalloc(&w->sorted.cursor, (kSortCursorStride + 1) * kBinsMax * sizeof(uint32_t)) == hipSuccess;
 	ok = ok && hipMalloc(&w->sorted.heads, kBinsMax * kSortHeads * sizeof(uint16_t)) == hipSuccess;
 	ok = ok && hipMalloc(&w->sorted.next, kBinsMax * kSortBinCap * sizeof(uint16_t)) == hipSuccess;
 	ok = ok && hipMalloc(&w->sorted.undo, kBinsMax * kSortBinCap * sizeof(uint2)) == hipSuccess;
 	ok = ok && hipMalloc(&w->sorted.losers, (size_t)rc * 4) == hipSuccess;
 	if (ok) {
-		w->sorted.count = w->sorted.cursor + kBinsMax;
-		ok = hipMemsetAsync(w->sorted.cursor, 0, 2 * kBinsMax * sizeof(uint32_t), stream) == hipSuccess;
+		w->sorted.count = w->sorted.cursor + kSortCursorStride * kBinsMax;
+		ok = hipMemsetAsync(w->sorted.cursor, 0, (kSortCursorStride + 1) * kBinsMax * sizeof(uint32_t), stream) == hipSuccess;
 	}
 	if (ok) {
 		void *hf = nullptr;
 		ok = hipHostMalloc(&hf, 64, hipHostMallocMapped) == hipSuccess;
 		if (ok) {
 			w->host_flag = reinterpret_cast<volatile uint32_t *>(hf);
-			w->host_flag[0] = w->host_flag[1] = w->host_flag[3] = w->host_flag[4] = 0;
+			w->host_flag[0] = w->host_flag[1] = w->host_flag[3] = w->host_flag[4] = w->host_flag[5] = 0;
 			w->host_flag[2] = dropped_seen;          // (the count goes on over a regrown workspace)
 			w->dropped_seen = dropped_seen;
 			void *dp = nullptr;
@@ -421,12 +423,11 @@ static int64_t ws_need(const ReqSrc &src, long long hint = 0)
 // K1 alone: touches the requests and the workspace, never the table.
 template <Op OP>
 static void launch_mark(Workspace *w, const DevGeom &g, const ReqSrc &src, hipStream_t stream,
-		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone, bool fallback = false)
+		const uint32_t *table, uint32_t lo = 0, uint32_t hi = kNone)
 {
-	// (fallback: behind a big pass's partition -- the launch leaves at once unless that gave up, mark_body)
 	hipLaunchKernelGGL((k_mark<OP>), dim3((unsigned)MKV_DIAG(mark_alone_blocks)), dim3(256), 0, stream, w->ctl, src, g,
 			w->owner[0], w->owner[4], w->reqc, w->state, (uint32_t)w->req_cap, lo, hi, table,
-			tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0) | (fallback ? 0x200 : 0),
+			tuning().lazy_alt | (w->host_flag && w->host_flag[4] ? 0x100 : 0),
 			tuning().plans ? w->undo : nullptr, w->lost);
 }
 
@@ -439,19 +440,37 @@ static Sorted sorted_of(Workspace *w, const DevGeom &g)
 		bucket_bits++;
 	S.bin_shift = bucket_bits > kSortBinsLog2 ? bucket_bits - kSortBinsLog2 : 0u;
 	S.nbins = (uint32_t)(((uint64_t)g.hash_mask + 1u) >> S.bin_shift);
+	S.host_flag = w->host_flag_dev;
 	return S;
 }
 
 // A pass goes that way when it is announced big enough to pay for the extra launches (Tuning::sorted_min), is the
 // call's only pass, and an even spread over the bins would fill them to two thirds at most (a skewed one overflows
-// a bin, which the device finds out: Ctl::sorted_fail, and the pass runs the old way behind the partition).
+// a bin, which the device finds out: Ctl::sorted_fail -- k_apply then leaves the whole pass to round 2 and the tail).
 static bool sorted_wanted(Workspace *w, const DevGeom &g, long long hint, bool is_delete, int nchunks)
 {
 	const long long smin = tuning().sorted_min;
 	if (is_delete || smin <= 0 || hint < smin || nchunks != 1 || !w->sorted.rec)
 		return false;
 	const Sorted S = sorted_of(w, g);
-	return hint <= (long long)S.nbins * (long long)(kSortBinCap * 2u / 3u);
+	if (hint > (long long)S.nbins * (long long)(kSortBinCap * 2u / 3u))
+		return false;
+	// The path's verdict on itself (word 5 of the host-mapped flags, written by round 2 of such a pass and read here
+	// without synchronising -- a pass or two late, which only costs time): a pass that fell back, or left over more
+	// than one request in 256 (a well-filled table: the left-overs are what such a pass costs), sends the next
+	// Tuning::sorted_cooldown big passes the old way; then one is tried again.
+	if (w->host_flag) {
+		const uint32_t word = w->host_flag[5];
+		if ((word & 1u) && word != w->sorted_acted) {
+			w->sorted_acted = word;
+			w->sorted_cooldown = tuning().sorted_cooldown;
+		}
+	}
+	if (w->sorted_cooldown > 0) {
+		w->sorted_cooldown--;
+		return false;
+	}
+	return true;
 }
 
 static uint32_t part_blocks_for(long long hint)
@@ -570,7 +589,8 @@ static int run_update(const DevGeom &g, uint32_t *table, const ReqSrc &src, hipS
 				hipLaunchKernelGGL((k_part<OP>), dim3(part_blocks_for(hint)), dim3(kPartThreads), 0, stream, w->ctl, src, g,
 						sorted_of(w, g), w->reqc, w->state, (uint32_t)w->req_cap, hi);
 		}
-		launch_mark<OP>(w, g, src, stream, table, lo, hi, sorted);
+		if (!sorted)
+			launch_mark<OP>(w, g, src, stream, table, lo, hi);
 		rc = launch_rounds<OP>(w, g, table, stream, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : hint,
 				true, sorted);
 		if (rc != MKV_OK)
@@ -611,14 +631,14 @@ template <Op OP>
 static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStream_t stream,
 		uint32_t lo, uint32_t hi, int first_chunk, int last_chunk, hipEvent_t done_ev, long long hint, bool plans_ok, bool sorted)
 {
-	// (sorted: the pass's requests went through the partition, k_part / k_search_part, and a fall-back mark pass is
-	// enqueued behind that: k_apply comes first here, and the rounds and the tail are told -- bits 9 / 10 of the
-	// hint -- to ask the device which way the pass went, Ctl::sorted_fail)
+	// (sorted: the pass's requests went through the partition, k_part / k_search_part -- no mark pass, no round 1:
+	// k_apply, then round 2 over what it left over, bit 9 of the hint, then the tail)
 	Sorted S = {};
 	if constexpr (OP != OP_DELETE) {
 		if (sorted) {
 			S = sorted_of(w, g);
-			hipLaunchKernelGGL((k_apply<OP>), dim3(S.nbins), dim3(kApplyThreads), 0, stream, w->ctl, g, table, S, w->state, w->owner[1]);
+			hipLaunchKernelGGL((k_apply<OP>), dim3(S.nbins), dim3(kApplyThreads), 0, stream, w->ctl, g, table, S, w->state, w->owner[1],
+					w->reqc);
 		}
 	}
 	// (hint: the caller's upper bound on the pass's requests, 0 = unknown)
@@ -631,7 +651,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	// bit 3 -- no groups of duplicates; bit 5 -- no self-help of a bucket's second registrant
 	// bit 6 -- round 1 carries out the mark pass's plans (kPlanBit)
 	const int rhint = (MKV_DIAG(debug_skip) & 4) | (tuning().dup_groups ? 0 : 8) | (tuning().self_help ? 0 : 32) |
-			(plans_ok && tuning().plans ? 64 : 0) | (sorted ? 512 | 1024 : 0);
+			(plans_ok && tuning().plans ? 64 : 0) | (sorted ? 512 : 0);
 	// (a pass announced with fewer requests than round 1's grid has lanes: as many work-groups as it takes --
 	// 208 instead of 512 are 0.5 us of a 52 K-request pass)
 	// (not while round 1 has been leaving round 2 a lot, or chains have been running late: what a work-group
@@ -648,13 +668,17 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 		r1_blocks = (hint + 255) / 256 > 2048 ? 2048 : (hint + 255) / 256;
 		big_grid = true;
 	}
-	hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
-			w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-			rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost, S);
+	if (!sorted)
+		hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
+				w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
+				rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost, S);
 	// round 2: inside the tail launch (k_tail's first phase), unless the pass is announced with more
 	// requests than that launch has lanes for in a few turns, or is a delete
 	// (word 3 of the tail kernel's flags, read without synchronising -- a pass late, which only costs time:
 	// round 1 has been leaving round 2 a lot: duplicates of hot keys, say)
+	// (a big pass's round 2 runs over a LIST -- what k_apply left over -- in a launch of its own: inside the tail
+	// launch, 32 work-groups, it took 40 us where the two launches take 15 + 23, and 71 against 15 + 37 once a
+	// thousand requests are left over: profiles/r06_sorted_path.txt)
 	const bool merged = OP != OP_DELETE && tuning().merge_round2 != 0 && hint <= (long long)tuning().merge_max && !sorted &&
 			!(w->host_flag && w->host_flag[3] && tuning().merge_round2 == 1);
 	// (round 2 looks at every request's tag to find its few: a lane per announced request, within 2048
@@ -847,17 +871,17 @@ extern "C" int mkv_cycle_insert_end(const mkv_geom_t *geom, bucket_t *table, iel
 	for (int c = 0; c < nchunks; c++) {
 		uint32_t lo, hi;
 		mkv::chunk_range(c, ck, &lo, &hi);
-		// (a big pass, partitioned in the search launch: its fall-back's mark pass runs here, behind the cycle's
-		// deletes -- its plans stand; the partition itself never looked at the table)
+		// (a big pass, partitioned in the search launch: the partition never looked at the table, and k_apply reads it
+		// behind the cycle's deletes)
 		const bool sorted = c == 0 && w->cycle_sorted;
 		if (d.scheme == MKV_SCHEME_2CHOICE) {
-			if (c > 0 || sorted)
-				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi, sorted);
+			if (c > 0)
+				mkv::launch_mark<mkv::OP_2CHOICE>(w, d, src, s, t, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_2CHOICE>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint,
 					c > 0 || !stale || sorted, sorted);
 		} else {
-			if (c > 0 || sorted)
-				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi, sorted);
+			if (c > 0)
+				mkv::launch_mark<mkv::OP_CUCKOO>(w, d, src, s, t, lo, hi);
 			rc = mkv::launch_rounds<mkv::OP_CUCKOO>(w, d, t, s, lo, hi, c == 0, c == nchunks - 1, nullptr, nchunks > 1 ? (long long)ck.step : size_hint,
 					c > 0 || !stale || sorted, sorted);
 		}

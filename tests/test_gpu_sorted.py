@@ -1,6 +1,7 @@
 """Big insert passes: partition into bins, apply per bucket with whole-bucket write-back, left-overs through
 round 2 and the tail (megakv_amd/csrc/mkv_upd_apply.h).  The path is taken by passes announced with at least
-Tuning::sorted_min requests (131 072 by default); here the tuning forces it at every size, so that small
+Tuning::sorted_min requests (0 = never by default: the path is exact but not faster than the reservation
+rounds); here the tuning forces it at every size, so that small
 geometries -- where buckets are shared heavily, chains are long and the oracle finishes in no time -- exercise
 it: the whole table against the oracle after every call, both schemes, through mkv_insert_hinted and through
 mkv_cycle (search + delete + insert, the partition riding in the search launch).
@@ -24,8 +25,10 @@ SCHEMES = [SCHEME_CUCKOO, SCHEME_2CHOICE]
 def _forced():
     L = load_library()
     assert L.mkv_set_tuning(b"sorted_min", 1) == 0
+    assert L.mkv_set_tuning(b"sorted_cooldown", 0) == 0       # (never back off: every pass here takes the path)
     yield
-    assert L.mkv_set_tuning(b"sorted_min", 131072) == 0
+    assert L.mkv_set_tuning(b"sorted_min", 0) == 0
+    assert L.mkv_set_tuning(b"sorted_cooldown", 32) == 0
 
 
 def sorted_stats():
