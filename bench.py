@@ -110,6 +110,7 @@ def parse(argv=None):
                          "child passes of this command's workload under rocprofv3 --pmc (FETCH_SIZE, WRITE_SIZE; ~15 s each)")
     ap.add_argument("--no-cpu", action="store_true", help="skip the cpu_baseline leg")
     ap.add_argument("--no-pcie", action="store_true", help="skip the host-buffer (PCIe-inclusive) side measurement")
+    ap.add_argument("--no-sched", action="store_true", help="skip the scheduler-regime side measurement (16 workers' small cycles)")
     ap.add_argument("--cpu-batches", type=int, default=400,
                     help="batches of the same workload replayed on the CPU oracle (~10 s single-threaded)")
     ap.add_argument("--graph", action="store_true", help="replay each step from a captured hipGraph")
@@ -702,6 +703,14 @@ def main():
         except Exception as ex:                                   # noqa: BLE001
             pcie = {"error": f"{type(ex).__name__}: {ex}"}
 
+    # the reference's own operating point: one scheduler cycle of 16 workers at its batch sizes
+    sched = None
+    if rank == 0 and not sharded and not args.no_sched:
+        try:
+            sched = scheduler_regime(engine, run_stream)
+        except Exception as ex:                                   # noqa: BLE001
+            sched = {"error": f"{type(ex).__name__}: {ex}"}
+
     cpu = None
     if rank == 0 and not sharded and not args.no_cpu:
         try:
@@ -740,7 +749,7 @@ def main():
             "set_loc_correct_last_timed": set_ok, "table_entries": entries,
             "table_entries_ok": entries.get("ok") if isinstance(entries, dict) else None,
             "step_algorithmic": step_algorithmic(stream_gen, cpu, elapsed / args.steps),
-            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "prewarm_s": round(t_prewarm, 3),
+            "roofline": roofline, "cpu_baseline": cpu, "pcie_inclusive": pcie, "scheduler_regime": sched, "prewarm_s": round(t_prewarm, 3),
             "host_submit_ms_per_step": round(t_submit / args.steps * 1e3, 5),
             "setup_s": {"preload": round(t_preload, 2), "generate": round(t_gen, 2)},
         }
@@ -968,6 +977,99 @@ class SingleGpu:
     def count_entries(self, dist=None):
         """occupied slots (signature != 0) of the table"""
         return int((self.idx.table.view(-1, 16)[:, :8] != 0).sum().item())
+
+
+def scheduler_regime(engine, stream, workers=16, ns=7000, ni=6000, nd=1000, cycles=48):
+    """Side measurement, never `value`: the regime the reference's caller runs in -- per cycle and worker a few
+    thousand searches, inserts (8 blocks) and deletes, 16 workers (src/mega.c:107,136,143-144,163-165;
+    src/mega_scheduler.c:393-504) -- as ONE mkv_cycle_workers call per cycle on a table of its own (a quarter of the
+    benchmark's: MEM_P - 2), requests resident in HBM.  `enqueued`: the cycles back to back on one stream, one wait at
+    the end -- the device's time per cycle; `synced`: a host wait after every cycle, as the scheduler has it
+    (cudaDeviceSynchronize, :504) -- launch and wake-up latency included.  Results of the last cycle's searches
+    are checked (every key inserted a cycle earlier comes back with its location)."""
+    import ctypes
+    from megakv_amd.index import _dev_ptr, _stream_ptr
+    from megakv_amd.lib import MkvWorker
+    g = M.Geometry(mem_p=max(engine.idx.geom.mem_p - 2, 20), scheme=engine.idx.geom.scheme)
+    idx = M.HashIndex(g, lib=engine.idx.lib)
+    L = idx.lib
+    dev = lambda a: torch.from_numpy(np.ascontiguousarray(a).view(np.int32)).cuda()
+    key = 1
+    work, prev = [], None
+    for c in range(cycles):
+        row, cur = [], []
+        for w in range(workers):
+            k = np.arange(key, key + ni, dtype=np.uint64)
+            key += ni
+            z = (k * np.uint64(0x9E3779B97F4A7C15)) ^ (k >> np.uint64(29))
+            z = (z ^ (z >> np.uint64(32))) * np.uint64(0xD6E8FEB86659FD93)
+            sig = (z & np.uint64(0xffffffff)).astype(np.uint32)
+            sig[sig == 0] = 1
+            hsh = (z >> np.uint64(32)).astype(np.uint32)
+            e = np.stack([sig, hsh, k.astype(np.uint32)], axis=1)
+            region = (hsh >> np.uint32(29)).astype(np.int64)          # the receiver's binning, src/mega_recv.c:476-477
+            blocks = [dev(e[region == b].reshape(-1, 3)) for b in range(8)]
+            ptrs, cnts, keep = idx.stage_blocks(blocks)
+            src = prev[w] if prev is not None else e                 # search what the worker inserted a cycle ago ...
+            pick = np.arange(ns) % src.shape[0]
+            q = dev(src[pick, :2])
+            out = torch.empty((ns, 2), dtype=torch.int32, device="cuda")
+            d = dev(src[-nd:]) if (nd and prev is not None) else None  # ... and delete the last of it (behind the search)
+            row.append((q, out, d, ptrs, cnts, keep, src[pick, 2].copy()))
+            cur.append(e)
+        work.append(row)
+        prev = cur
+    torch.cuda.synchronize()
+
+    # the argument arrays of every cycle, built ahead (a C host has them in its worker structures)
+    args_of = []
+    for c in range(cycles):
+        ws = (MkvWorker * workers)()
+        for w in range(workers):
+            q, out, d, ptrs, cnts, keep, _ = work[c][w]
+            ws[w].search_in, ws[w].search_out, ws[w].num_search = _dev_ptr(q).value, _dev_ptr(out).value, ns
+            ws[w].delete_in, ws[w].num_delete = (_dev_ptr(d).value if d is not None else None), (nd if d is not None else 0)
+            ws[w].blk_input, ws[w].blk_elem_num, ws[w].num_blks = _dev_ptr(ptrs).value, _dev_ptr(cnts).value, 8
+        args_of.append(ws)
+    gref, tptr, sptr = ctypes.byref(idx._g), _dev_ptr(idx.table), _stream_ptr(stream)
+
+    def one(c):
+        rc = L.mkv_cycle_workers(gref, tptr, args_of[c], workers, sptr)
+        if rc != 0:
+            raise RuntimeError(f"mkv_cycle_workers: {rc}")
+
+    out = {}
+    for mode in ("enqueued", "synced"):
+        idx.table.zero_()
+        torch.cuda.synchronize()
+        for c in range(4):
+            one(c)
+        stream.synchronize()
+        t0 = time.perf_counter()
+        for c in range(4, cycles):
+            one(c)
+            if mode == "synced":
+                stream.synchronize()
+        stream.synchronize()
+        out[mode] = (time.perf_counter() - t0) / (cycles - 4)
+    # the last cycle's searches: keys inserted a cycle earlier, none of them deleted before that search
+    wrong = 0
+    for w in range(workers):
+        q, o, d, ptrs, cnts, keep, want = work[cycles - 1][w]
+        res = o.cpu().numpy().view(np.uint32)
+        wrong += int(np.count_nonzero(np.where(res[:, 0] != 0, res[:, 0], res[:, 1]) != want))
+    ok = wrong == 0
+    ops = workers * (ns + ni + nd)
+    alg = workers * (ns * 144 + ni * 84 + nd * 80)                  # bytes per cycle: 144 per GET, ~84 per SET, ~80 per delete
+    del idx
+    return {"what": f"{workers} workers x ({ns} searches, {ni} inserts in 8 blocks, {nd} deletes) per cycle, one mkv_cycle_workers call a cycle, "
+                    f"MEM_P={g.mem_p}, requests resident in HBM",
+            "us_per_cycle_enqueued": round(out["enqueued"] * 1e6, 1), "mops_enqueued": round(ops / out["enqueued"] / 1e6, 1),
+            "us_per_cycle_synced": round(out["synced"] * 1e6, 1), "mops_synced": round(ops / out["synced"] / 1e6, 1),
+            "algorithmic_bytes_per_cycle": alg,
+            "frac_of_hbm_peak": round(alg / out["enqueued"] / 8e12, 4),
+            "bound": "latency: seven dependent launches of a few microseconds of memory traffic each",
+            "searches_correct": ok, "searches_wrong": wrong}
 
 
 def pcie_inclusive(engine, batches, stream, args):

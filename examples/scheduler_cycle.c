@@ -133,7 +133,9 @@ int main(int argc, char **argv)
 
 	uint32_t next_key = 1;
 	uint64_t total_search = 0, total_insert = 0, total_delete = 0;
-	struct timespec t0, t1;
+	struct timespec t0, t1, c0, c1;
+	double sched_us = 0;
+	int sched_n = 0;
 	clock_gettime(CLOCK_MONOTONIC, &t0);
 
 	for (c = 0; c < cycles; c++) {
@@ -157,6 +159,7 @@ int main(int argc, char **argv)
 		}
 
 		/* --- scheduler: one cycle --- */
+		clock_gettime(CLOCK_MONOTONIC, &c0);
 		if (ONECALL) {
 			/* the copies of every worker on one stream, then ONE library call for the whole cycle */
 			mkv_worker_t mw[MAX_WORKERS];
@@ -262,6 +265,9 @@ int main(int argc, char **argv)
 				CUDA_SAFE_CALL(cudaStreamSynchronize(w[id].stream));
 		else
 			CUDA_SAFE_CALL(cudaDeviceSynchronize());
+		clock_gettime(CLOCK_MONOTONIC, &c1);
+		if (c >= cycles / 4)	/* (the first cycles create the library's workspaces) */
+			sched_us += 1e6 * (c1.tv_sec - c0.tv_sec) + (c1.tv_nsec - c0.tv_nsec) / 1e3, sched_n++;
 
 		/* --- senders: consume results (src/mega_send.c:408-414) --- */
 		for (id = 0; id < WORKERS; id++) {
@@ -319,6 +325,11 @@ int main(int argc, char **argv)
 			(unsigned long long)total_search, (unsigned long long)total_insert,
 			(unsigned long long)total_delete, us, (total_search + total_insert + total_delete) / us, errors,
 			free_setup > free_end ? (double)(free_setup - free_end) / 1048576.0 : 0.0);
+	/* the scheduler's own share: from its first call of a cycle to the return of the cycle's synchronisation (the rest
+	 * is this program's receivers and senders: making the next batches, checking the results) */
+	if (sched_n)
+		printf("scheduler section: %.1f us per cycle over the last %d cycles -> %.1f Mops\n", sched_us / sched_n, sched_n,
+				(double)(total_search + total_insert + total_delete) / cycles / (sched_us / sched_n));
 	if (DIGEST) {
 		uint64_t *host = (uint64_t *)malloc(HT_SIZE), h = 1469598103934665603ULL;
 		size_t q;

@@ -22,6 +22,8 @@ static hipMemcpyKind kind_of(enum cudaMemcpyKind k)
 // its turn.  Without the mode mkv_flush() finds nothing and mkv_defer_copy() says "now".
 extern "C" int mkv_flush(void);
 extern "C" int mkv_defer_copy(void *dst, const void *src, size_t n, void *stream);
+extern "C" int mkv_defer_copy_in(void *dst, const void *src, size_t n, void *stream);
+extern "C" void mkv_pinned_note(void *p, size_t n, int add);
 extern "C" int mkv_defer_memset(void *p, int value, size_t n, void *stream);
 extern "C" void mkv_defer_touch(void);
 
@@ -40,11 +42,17 @@ cudaError_t cudaFree(void *p)
 }
 cudaError_t cudaHostAlloc(void **p, size_t n, unsigned int flags)
 {
-	return (cudaError_t)hipHostMalloc(p, n, flags);
+	// (pinned buffers made here are known to the deferred mode: copies to and from them can wait for the cycle
+	// and go as ONE launch, mkv_abi.hip)
+	const cudaError_t e = (cudaError_t)hipHostMalloc(p, n, flags);
+	if (!e && p && *p)
+		mkv_pinned_note(*p, n, 1);
+	return e;
 }
 cudaError_t cudaFreeHost(void *p)
 {
 	const cudaError_t f = flushed();
+	mkv_pinned_note(p, 0, 0);
 	return f ? f : (cudaError_t)hipHostFree(p);
 }
 cudaError_t cudaMemset(void *p, int v, size_t n)
@@ -68,6 +76,8 @@ cudaError_t cudaMemcpyAsync(void *d, const void *s, size_t n, enum cudaMemcpyKin
 	if (k == cudaMemcpyDeviceToHost) {
 		if (mkv_defer_copy(d, s, n, (void *)st))
 			return (cudaError_t)hipSuccess;
+	} else if (k == cudaMemcpyHostToDevice && mkv_defer_copy_in(d, s, n, (void *)st)) {
+		return (cudaError_t)hipSuccess;     // (from a pinned buffer, deferred mode: it goes with the cycle's other copies)
 	} else {
 		mkv_defer_touch();
 	}

@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <atomic>
+#include <map>
 #include <mutex>
 #include <vector>
 
@@ -60,6 +62,23 @@ struct DeferredCopy {
 	hipStream_t stream;         // the stream the host issued it on (the flush makes that stream wait for it)
 };
 
+// Pinned host buffers the host got from the library's cudaHostAlloc (cuda_names.hip): device-accessible at the same
+// address, and -- unlike pageable memory, which the runtime stages before an asynchronous copy returns -- not the
+// host's to change between cudaMemcpyAsync and the next synchronisation.
+std::mutex g_pinned_mutex;
+std::map<const char *, size_t> g_pinned;    // by first byte (a scheduler with 16 workers holds 200 of them, and asks 200 times a cycle)
+
+bool pinned_holds(const void *p, size_t n)
+{
+	std::lock_guard<std::mutex> lock(g_pinned_mutex);
+	const char *c = reinterpret_cast<const char *>(p);
+	auto it = g_pinned.upper_bound(c);
+	if (it == g_pinned.begin())
+		return false;
+	--it;
+	return c >= it->first && c + n <= it->first + it->second;
+}
+
 struct DeferredWorker {
 	hipStream_t stream;
 	bucket_t *table;
@@ -68,9 +87,11 @@ struct DeferredWorker {
 };
 
 std::mutex g_defer_mutex;
+std::atomic<int> g_defer_queued{0};         // something is recorded, queued or held: what mkv_defer_barrier looks at first
 int g_defer_mode = -1;                     // -1: not looked up yet
 std::vector<DeferredWorker> g_defer;
 std::vector<DeferredCopy> g_defer_copies;
+std::vector<DeferredCopy> g_defer_in;       // host-to-device copies from pinned buffers, waiting for the cycle (copy_segments)
 
 // The scheduler clears a worker's result buffer right before its search (cudaMemsetAsync, src/mega_scheduler.c:
 // 406-407): the cycle's search writes every result, zeros for misses, so that launch is for nothing.  A memset to
@@ -132,6 +153,7 @@ DeferredWorker *defer_slot(hipStream_t stream, bucket_t *table, int kind)
 	d.stream = stream;
 	d.table = table;
 	g_defer.push_back(d);
+	g_defer_queued.store(1, std::memory_order_relaxed);
 	return &g_defer.back();
 }
 
@@ -141,15 +163,143 @@ thread_local hipStream_t t_copy_stream = nullptr;
 thread_local bool t_copies_pending = false;
 thread_local int t_copy_rc = MKV_OK;
 
+// Small copies from pageable memory are snapshot into a pinned arena (mkv_defer_copy_in): kSnapArenas of them, one per
+// flush in turn (the launch that reads an arena is long over when its turn comes again).
+constexpr size_t kSnapMax = 4096, kSnapArena = 256 * 1024;
+constexpr int kSnapArenas = 4;
+char *g_snap = nullptr;
+size_t g_snap_used = 0;
+int g_snap_cur = 0;
+
+bool snap_room(size_t n)
+{
+	if (!g_snap && hipHostMalloc(reinterpret_cast<void **>(&g_snap), kSnapArena * kSnapArenas, hipHostMallocDefault) != hipSuccess)
+		g_snap = nullptr;
+	return g_snap && g_snap_used + ((n + 15u) & ~(size_t)15u) <= kSnapArena;
+}
+
+const void *snap_take(const void *src, size_t n)
+{
+	char *at = g_snap + (size_t)g_snap_cur * kSnapArena + g_snap_used;
+	memcpy(at, src, n);
+	g_snap_used += (n + 15u) & ~(size_t)15u;
+	return at;
+}
+
+// The reference's scheduler stages every worker's requests and results with a copy each (src/mega_scheduler.c:404-419,
+// 452, 487-494): 12 copies per worker and cycle, 192 with 16 workers, of 32 bytes to 100 KB -- launch-bound, 1.4 ms of
+// a cycle whose kernels take a tenth of that.  In deferred mode the copies between DEVICE memory and PINNED host
+// buffers of the library's cudaHostAlloc wait for the cycle and go as ONE launch each way: a kernel that reads (writes)
+// the pinned buffers over PCIe, a segment per copy.  What the host asked for is what it gets -- the same bytes in the
+// same places by the time it synchronises; copies from pageable memory go out at once as before.
+struct CopySeg {
+	void *dst;
+	const void *src;
+	unsigned long long n;
+};
+constexpr int kSegTables = 8, kSegCap = 1024;
+CopySeg *g_seg_tables = nullptr;            // kSegTables tables of kSegCap segments, pinned (the kernel reads them over PCIe)
+int g_seg_next = 0;
+
+__global__ __launch_bounds__(256) void k_copy_segments(const CopySeg *__restrict__ segs)
+{
+	const CopySeg sg = segs[blockIdx.y];
+	const unsigned long long n = sg.n;
+	char *d = reinterpret_cast<char *>(sg.dst);
+	const char *s = reinterpret_cast<const char *>(sg.src);
+	const unsigned long long lane = (unsigned long long)blockIdx.x * blockDim.x + threadIdx.x, lanes = (unsigned long long)gridDim.x * blockDim.x;
+	if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 15u) == 0u) {
+		const unsigned long long n16 = n >> 4;
+		const uint4 *s4 = reinterpret_cast<const uint4 *>(s);
+		uint4 *d4 = reinterpret_cast<uint4 *>(d);
+		for (unsigned long long i = lane; i < n16; i += lanes)
+			d4[i] = s4[i];
+		for (unsigned long long i = (n16 << 4) + lane; i < n; i += lanes)
+			d[i] = s[i];
+	} else if (((reinterpret_cast<uintptr_t>(d) | reinterpret_cast<uintptr_t>(s)) & 3u) == 0u) {
+		const unsigned long long n4 = n >> 2;
+		const uint32_t *s1 = reinterpret_cast<const uint32_t *>(s);
+		uint32_t *d1 = reinterpret_cast<uint32_t *>(d);
+		for (unsigned long long i = lane; i < n4; i += lanes)
+			d1[i] = s1[i];
+		for (unsigned long long i = (n4 << 2) + lane; i < n; i += lanes)
+			d[i] = s[i];
+	} else {
+		for (unsigned long long i = lane; i < n; i += lanes)
+			d[i] = s[i];
+	}
+}
+
+// the copies of `v` as one launch on `s` (several if there are more than a table holds); individual copies if the
+// tables cannot be had
+int copy_segments(std::vector<DeferredCopy> &v, hipMemcpyKind kind, hipStream_t s)
+{
+	int rc = MKV_OK;
+	if (v.empty())
+		return rc;
+	if (!g_seg_tables && hipHostMalloc(reinterpret_cast<void **>(&g_seg_tables), sizeof(CopySeg) * kSegTables * kSegCap,
+			hipHostMallocDefault) != hipSuccess)
+		g_seg_tables = nullptr;
+	if (!g_seg_tables || v.size() < 4) {
+		for (const DeferredCopy &c : v)
+			if (hipMemcpyAsync(c.dst, c.src, c.n, kind, s) != hipSuccess)
+				rc = MKV_EHIP;
+		v.clear();
+		return rc;
+	}
+	for (size_t at = 0; at < v.size(); at += kSegCap) {
+		// (a table is the host's to rewrite once the launch that read it is over: kSegTables launches ago at the
+		// least, each followed by whatever made the host flush -- a wait, as a rule; the ring is insurance)
+		CopySeg *tab = g_seg_tables + (size_t)g_seg_next * kSegCap;
+		g_seg_next = (g_seg_next + 1) % kSegTables;
+		const size_t m = v.size() - at < (size_t)kSegCap ? v.size() - at : (size_t)kSegCap;
+		unsigned long long longest = 0;
+		for (size_t k = 0; k < m; k++) {
+			tab[k].dst = v[at + k].dst;
+			tab[k].src = v[at + k].src;
+			tab[k].n = v[at + k].n;
+			longest = v[at + k].n > longest ? v[at + k].n : longest;
+		}
+		// (work-groups per segment by the longest one: 16 bytes a lane, ONE turn -- a turn is a round trip over PCIe --
+		// within 64 work-groups; the work-groups of a shorter segment find nothing and leave)
+		unsigned gx = (unsigned)((longest + 256u * 16u - 1u) / (256u * 16u));
+		gx = gx < 1u ? 1u : (gx > 64u ? 64u : gx);
+		hipLaunchKernelGGL(k_copy_segments, dim3(gx, (unsigned)m), dim3(256), 0, s, tab);
+		if (hipGetLastError() != hipSuccess)
+			rc = MKV_EHIP;
+	}
+	v.clear();
+	return rc;
+}
+
 void issue_deferred_copies(hipStream_t s)
 {
 	if (!t_copies_pending)
 		return;
 	t_copies_pending = false;
-	for (const DeferredCopy &c : g_defer_copies)
-		if (hipMemcpyAsync(c.dst, c.src, c.n, hipMemcpyDeviceToHost, s) != hipSuccess)
+	// results into pinned buffers of the library's cudaHostAlloc: one launch; the others a copy each
+	std::vector<DeferredCopy> batch;
+	for (const DeferredCopy &c : g_defer_copies) {
+		if (pinned_holds(c.dst, c.n))
+			batch.push_back(c);
+		else if (hipMemcpyAsync(c.dst, c.src, c.n, hipMemcpyDeviceToHost, s) != hipSuccess)
 			t_copy_rc = MKV_EHIP;
+	}
+	if (copy_segments(batch, hipMemcpyDeviceToHost, s) != MKV_OK)
+		t_copy_rc = MKV_EHIP;
 	g_defer_copies.clear();
+}
+
+// the queued host-to-device copies: behind what their own streams hold already? -- no: they go on ONE stream, the
+// flush's, ahead of the cycle, and every stream they were issued on is made to wait for the flush (join_streams_locked)
+int issue_deferred_in(hipStream_t s)
+{
+	const int rc = copy_segments(g_defer_in, hipMemcpyHostToDevice, s);
+	if (g_snap_used) {
+		g_snap_used = 0;
+		g_snap_cur = (g_snap_cur + 1) % kSnapArenas;
+	}
+	return rc;
 }
 
 // A flush issues the whole cycle and the queued result copies on ONE stream, s0 (the first worker's).  The
@@ -173,12 +323,24 @@ int join_streams_locked(hipStream_t s0, const std::vector<hipStream_t> &others)
 	return MKV_OK;
 }
 
+thread_local bool t_in_flush = false;       // (the flush itself calls mkv_cycle / mkv_cycle_workers)
+
+int defer_flush_locked_inner();
 int defer_flush_locked()
 {
+	t_in_flush = true;
+	const int rc = defer_flush_locked_inner();
+	t_in_flush = false;
+	g_defer_queued.store(0, std::memory_order_relaxed);
+	return rc;
+}
+
+int defer_flush_locked_inner()
+{
 	int rc = release_memset_locked();
-	if (g_defer.empty() && g_defer_copies.empty())
+	if (g_defer.empty() && g_defer_copies.empty() && g_defer_in.empty())
 		return rc;
-	hipStream_t s0 = g_defer.empty() ? g_defer_copies[0].stream : g_defer[0].stream;
+	hipStream_t s0 = !g_defer.empty() ? g_defer[0].stream : !g_defer_in.empty() ? g_defer_in[0].stream : g_defer_copies[0].stream;
 	std::vector<hipStream_t> others;
 	auto note_stream = [&](hipStream_t o) {
 		if (o == s0)
@@ -192,14 +354,20 @@ int defer_flush_locked()
 		note_stream(d.stream);
 	for (const DeferredCopy &c : g_defer_copies)
 		note_stream(c.stream);
+	for (const DeferredCopy &c : g_defer_in)
+		note_stream(c.stream);
+	const bool had_in = !g_defer_in.empty();
 	size_t i = 0;
-	if (g_defer.size() > 1) {
+	if (g_defer.size() > 1 || (had_in && !others.empty())) {
 		// What the host queued on the workers' own streams (request copies, memsets) is done first: ONE wait for
 		// the device, not one per stream (a blocking wait is tens of microseconds of wake-up each -- sixteen of
 		// them per cycle were a quarter of a staged cycle's time)
 		if (hipDeviceSynchronize() != hipSuccess)
 			rc = MKV_EHIP;
 	}
+	// the request copies that waited for the cycle: one launch, ahead of it
+	if (rc == MKV_OK)
+		rc = issue_deferred_in(s0);
 	// (one worker: the copies go out behind its search, where the host issued them; several: behind the whole
 	// cycle -- sixteen copies between the search and the updates on the one stream hold the updates up)
 	t_copies_pending = !g_defer_copies.empty() && g_defer.size() == 1;
@@ -238,10 +406,42 @@ int defer_flush_locked()
 		rc = join_streams_locked(s0, others);
 	g_defer.clear();
 	g_defer_copies.clear();
+	g_defer_in.clear();
 	return rc;
 }
 
 }  // namespace
+
+// for the library's cudaHostAlloc / cudaFreeHost
+extern "C" void mkv_pinned_note(void *p, size_t n, int add)
+{
+	std::lock_guard<std::mutex> lock(g_pinned_mutex);
+	if (add)
+		g_pinned[reinterpret_cast<const char *>(p)] = n;
+	else
+		g_pinned.erase(reinterpret_cast<const char *>(p));
+}
+
+// for the library's cudaMemcpyAsync, host to device: a copy from a pinned buffer of the library's cudaHostAlloc waits
+// for the cycle in deferred mode (1: queued; 0: issue it now)
+extern "C" int mkv_defer_copy_in(void *dst, const void *src, size_t n, void *stream)
+{
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	if (!defer_on_locked() || !n)
+		return 0;
+	if (!pinned_holds(src, n)) {
+		// Pageable memory is the host's again the moment the call returns: a SMALL copy from it (the scheduler's
+		// block counts, 32 bytes a worker and cycle -- each a launch of its own and 10 - 15 us of the host's time
+		// otherwise) is taken NOW, into a pinned arena of the library's, and goes with the cycle's other copies.
+		if (n > kSnapMax || !snap_room(n))
+			return 0;
+		src = snap_take(src, n);
+	}
+	die_on(release_memset_locked(), "held memset");
+	g_defer_in.push_back(DeferredCopy{dst, src, n, (hipStream_t)stream});
+	g_defer_queued.store(1, std::memory_order_relaxed);
+	return 1;
+}
 
 // called by mkv_cycle / mkv_cycle_workers behind their search launch (nothing to do outside a deferred flush)
 extern "C" void mkv_after_search(void *stream)
@@ -256,6 +456,18 @@ extern "C" void mkv_set_defer(int on)
 	if (!on)
 		die_on(defer_flush_locked(), "mkv_set_defer/flush");
 	g_defer_mode = on ? 1 : 0;
+}
+
+// For the library's OWN entry points (mkv_search, mkv_insert, mkv_delete, mkv_cycle, mkv_cycle_workers ...) when a host
+// mixes them with the drop-in names in deferred mode: what the drop-in side has recorded or queued -- request copies
+// from pinned buffers above all -- goes out first, so that the call finds its inputs where the host put them.  Nothing
+// to do (one relaxed load) unless something is queued; a no-op inside the flush itself.
+extern "C" int mkv_defer_barrier(void)
+{
+	if (t_in_flush || g_defer_queued.load(std::memory_order_relaxed) == 0)
+		return MKV_OK;
+	std::lock_guard<std::mutex> lock(g_defer_mutex);
+	return defer_flush_locked();
 }
 
 // issues whatever the deferred mode has recorded (no wait); MKV_OK when there is nothing
@@ -275,6 +487,7 @@ extern "C" int mkv_defer_memset(void *p, int value, size_t n, void *stream)
 	if (value != 0 || !p || !n)
 		return 0;
 	g_held = HeldMemset{p, n, (hipStream_t)stream, true};
+	g_defer_queued.store(1, std::memory_order_relaxed);
 	return 1;
 }
 
@@ -283,6 +496,11 @@ extern "C" void mkv_defer_touch(void)
 {
 	std::lock_guard<std::mutex> lock(g_defer_mutex);
 	die_on(release_memset_locked(), "held memset");
+	// (an asynchronous call that goes out at once -- a copy from pageable memory, a device-to-device copy -- while
+	// copies from pinned buffers wait for the cycle and nothing is recorded yet that they could belong to: they go
+	// first, in the order the host issued them)
+	if (!g_defer_in.empty() && g_defer.empty())
+		die_on(defer_flush_locked(), "queued copies");
 }
 
 // for the library's cudaMemcpyAsync: a device-to-host copy on a stream with recorded work waits its turn
@@ -295,6 +513,7 @@ extern "C" int mkv_defer_copy(void *dst, const void *src, size_t n, void *stream
 		return 0;
 	// (any stream: the recorded cycle may write what the copy reads whatever stream it names)
 	g_defer_copies.push_back(DeferredCopy{dst, src, n, (hipStream_t)stream});
+	g_defer_queued.store(1, std::memory_order_relaxed);
 	return 1;
 }
 
@@ -454,7 +673,9 @@ extern "C" int mkv_cycle(const mkv_geom_t *geom, bucket_t *table, const selem_t 
 		ielem_t **blk_input, int *blk_elem_num, int num_blks, int64_t insert_hint, uint32_t search_flags,
 		void *stream, void *timer, int slot)
 {
-	int rc = MKV_OK;
+	int rc = mkv_defer_barrier();
+	if (rc != MKV_OK)
+		return rc;
 	MkvTimer *tm = reinterpret_cast<MkvTimer *>(timer);
 	if (tm && (slot < 0 || slot >= tm->slots))
 		return MKV_EINVAL;

@@ -151,6 +151,7 @@ DiagTuning &diag_tuning()
 
 extern "C" int mkv_search_timed(const mkv_geom_t *geom, const selem_t *in, loc_t *out, const bucket_t *table,
 		int64_t num_elem, uint32_t flags, void *stream, void *ev_start, void *ev_stop);
+extern "C" int mkv_defer_barrier(void);
 
 extern "C" int mkv_search(const mkv_geom_t *geom, const selem_t *in, loc_t *out,
 		const bucket_t *table, int64_t num_elem, uint32_t flags, void *stream)
@@ -170,6 +171,9 @@ extern "C" int mkv_search_timed(const mkv_geom_t *geom, const selem_t *in, loc_t
 		return MKV_OK;
 	if (!in || !out || !table)
 		return MKV_EINVAL;
+	const int brc = mkv_defer_barrier();        // (the drop-in side's queued request copies, deferred mode: mkv_abi.hip)
+	if (brc != MKV_OK)
+		return brc;
 	const uint2 *in2 = reinterpret_cast<const uint2 *>(in);
 	const uint4 *t4 = reinterpret_cast<const uint4 *>(table);
 	hipStream_t s = (hipStream_t)stream;

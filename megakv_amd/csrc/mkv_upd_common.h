@@ -223,6 +223,19 @@ struct ReqSrc {
 	uint32_t cnt_stride;                // blk_elem_num[b * cnt_stride] (1 = the ABI's dense int[])
 };
 
+// All workers of a scheduler cycle (mkv_cycle_workers): where each worker's requests are -- the insert blocks through
+// the worker's own device arrays of block pointers and counts (the ABI's), the delete requests by value.  Passed to
+// the fused search launch by value: its mark work-groups read the workers' arrays themselves (mark_body, GATHER).
+constexpr int kMaxWorkers = 32;
+struct GatherBlocks {
+	const uint32_t *const *ins_ptrs[kMaxWorkers];    // worker w's device array of block pointers
+	const int *ins_cnts[kMaxWorkers];                // ... and of block counts
+	uint32_t ins_first[kMaxWorkers + 1];             // worker w's first block in the cycle's (worker-major) block order
+	const uint32_t *del_ptr[kMaxWorkers];
+	int del_cnt[kMaxWorkers];
+	int nw;
+};
+
 // ---- coherent access helpers ---------------------------------------------------
 // Inside the tail work-group values written with atomics (owner / count tables)
 // or by other waves of the group are read back: those loads bypass the L1.

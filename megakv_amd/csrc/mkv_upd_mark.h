@@ -12,10 +12,12 @@ namespace mkv {
 // ---- K1: mark -----------------------------------------------------------------
 // (undo, lost_flags: where the plans and the flags of kPlanBit go -- null: none are made)
 // (lazy_free: Tuning::lazy_alt; bit 8: the last passes walked many eviction chains -- the walks ahead do not flag, prewalk_register)
-template <Op OP>
+// (GATHER: the blocks are the workers' of a scheduler cycle, found through gb -- src.nblk says how many)
+template <Op OP, bool GATHER = false>
 __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl *ctl, const ReqSrc &src,
 		const DevGeom &g, unsigned long long *owner, unsigned long long *second, uint4 *reqc, uint8_t *state, uint32_t req_cap,
-		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, uint32_t lazy_free, Undo *undo, uint32_t *lost_flags)
+		uint32_t lo_idx, uint32_t hi_idx, const uint32_t *table, uint32_t lazy_free, Undo *undo, uint32_t *lost_flags,
+		const GatherBlocks &gb)
 {
 	__shared__ uint32_t s_prefix[kMaxBlocks + 1];
 	__shared__ const uint32_t *s_ptr[kMaxBlocks];
@@ -54,8 +56,21 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 		}
 	} else {
 		for (uint32_t b = t; b < nblk; b += blockDim.x) {
-			const int c = src.blk_elem_num[(size_t)b * src.cnt_stride];
-			s_ptr[b] = src.blk_input[b];        // fetched beside the counts: one round trip
+			int c;
+			if (GATHER && OP == OP_DELETE) {
+				c = gb.del_cnt[b];                  // (a delete "block" is a worker's delete array)
+				s_ptr[b] = gb.del_ptr[b];
+			} else if (GATHER) {
+				int w = 0;
+				while (w + 1 < gb.nw && b >= gb.ins_first[w + 1])
+					w++;
+				const uint32_t k = b - gb.ins_first[w];
+				c = gb.ins_cnts[w][k];
+				s_ptr[b] = gb.ins_ptrs[w][k];
+			} else {
+				c = src.blk_elem_num[(size_t)b * src.cnt_stride];
+				s_ptr[b] = src.blk_input[b];        // fetched beside the counts: one round trip
+			}
 			s_prefix[b + 1] = c > 0 ? (uint32_t)c : 0u;
 		}
 		__syncthreads();
@@ -336,7 +351,7 @@ __global__ __launch_bounds__(256) void k_mark(Ctl *ctl, ReqSrc src, DevGeom g,
 		uint32_t hi_idx, const uint32_t *table, int lazy_on, Undo *undo, uint32_t *lost)
 {
 	mark_body<OP>(blockIdx.x, gridDim.x, ctl, src, g, owner, second, reqc, state, req_cap, lo_idx, hi_idx, table, (uint32_t)lazy_on,
-			undo, lost);
+			undo, lost, GatherBlocks());
 }
 
 // mkv_cycle: the mark pass never touches the table, so it rides in the search
@@ -352,7 +367,7 @@ __global__ __launch_bounds__(256) void k_search_mark(const uint2 *__restrict__ i
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost);
+				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost, GatherBlocks());
 	else
 		search_body<4, true, false>(blockIdx.x - mark_blocks, in, out, table, n, g.hash_mask, g.blk_mask);
 }
@@ -369,7 +384,7 @@ __global__ __launch_bounds__(256) void k_search_slots_mark(const uint32_t *__res
 	const uint32_t mark_blocks = gridDim.x - search_blocks;
 	if (blockIdx.x < mark_blocks)
 		mark_body<OP>(blockIdx.x, mark_blocks, ctl, src, g, owner, second, reqc, state, req_cap, 0u, hi_idx,
-				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost);
+				reinterpret_cast<const uint32_t *>(table), (uint32_t)lazy_on, undo, lost, GatherBlocks());
 	else
 		search_slots_body(blockIdx.x - mark_blocks, recvbuf, slot_words, cap_get, out, table, g.hash_mask,
 				g.blk_mask, chunks_per_slot, self, self_out);

@@ -683,8 +683,11 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 			!(w->host_flag && w->host_flag[3] && tuning().merge_round2 == 1);
 	// (round 2 looks at every request's tag to find its few: a lane per announced request, within 2048
 	// work-groups -- 524 K tags on the 512 work-groups of round 1 took 15 us, on 2048 they take 6.5)
+	// (... and a pass announced small as many work-groups as it has requests for: a delete pass of a scheduler cycle,
+	// 16 K requests, leaves round 2 nothing as a rule -- the launch is its cost)
 	long long r2_blocks = (hint + 255) / 256;
-	r2_blocks = r2_blocks < tuning().round_blocks ? tuning().round_blocks : (r2_blocks > 2048 ? 2048 : r2_blocks);
+	if (hint <= 0 || r2_blocks > tuning().round_blocks)
+		r2_blocks = r2_blocks < tuning().round_blocks ? tuning().round_blocks : (r2_blocks > 2048 ? 2048 : r2_blocks);
 	if (!merged)
 		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
@@ -701,6 +704,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 
 extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, long long size_hint, void *stream);
+extern "C" int mkv_defer_barrier(void);
 
 extern "C" int mkv_insert(const mkv_geom_t *geom, bucket_t *table, ielem_t **blk_input,
 		int *blk_elem_num, int num_blks, void *stream)
@@ -716,6 +720,9 @@ extern "C" int mkv_insert_hinted(const mkv_geom_t *geom, bucket_t *table, ielem_
 		return MKV_EINVAL;
 	if (num_blks == 0)
 		return MKV_OK;
+	const int brc = mkv_defer_barrier();
+	if (brc != MKV_OK)
+		return brc;
 	if (!table || !blk_input || !blk_elem_num)
 		return MKV_EINVAL;
 	mkv::ReqSrc src;
@@ -999,18 +1006,17 @@ extern "C" int mkv_slots_cycle_self(const mkv_geom_t *geom, const uint32_t *recv
 // The reference's scheduler runs, per cycle, memset + gpu_hash_search + gpu_hash_delete + gpu_hash_insert
 // for each of up to 16 workers on a stream each (src/mega_scheduler.c:393-502) with at most 32 767
 // searches and 8 x 4 096 inserts per worker (src/mega.c:136,143-144): 16 x 9 launches of a few
-// microseconds of work each, the updates serialised.  Here the whole cycle is four pieces of work:
-// ONE search launch over every worker's requests (a miss writes 0: no memset), one tiny launch that
-// gathers the workers' block pointers and counts (device arrays the host rewrites per cycle, as the
-// ABI has them) into one array, ONE delete pass over the workers' delete arrays as its blocks and ONE
-// insert pass over all the workers' blocks, worker-major.  Order: every search sees the table as the
+// microseconds of work each, the updates serialised.  Here the whole cycle is three pieces of work:
+// ONE launch that searches every worker's requests (a miss writes 0: no memset) and marks the cycle's
+// deletes and inserts beside the searches (k_search_multi_mark: the mark work-groups read the workers'
+// block pointers and counts -- device arrays the host rewrites per cycle, as the ABI has them --
+// themselves), then the rounds of ONE delete pass over the workers' delete arrays as its blocks and of
+// ONE insert pass over all the workers' blocks, worker-major.  Order: every search sees the table as the
 // cycle found it; then the deletes in (worker, index) order; then the inserts in (worker, block, index)
 // order -- what the per-worker calls give when the workers' keys do not meet within a cycle (per worker
 // they run delete then insert: a worker deleting what an EARLIER worker inserts in the same cycle is
 // the one case that differs).
 namespace mkv {
-
-constexpr int kMaxWorkers = 32;
 
 struct MultiSearch {
 	const uint2 *in[kMaxWorkers];
@@ -1029,52 +1035,53 @@ __global__ __launch_bounds__(256) void k_search_multi(MultiSearch a, const uint4
 	search_body<4, true, false>(blockIdx.x - a.first[w], a.in[w], a.out[w], table, (int64_t)a.n[w], hash_mask, blk_mask);
 }
 
-struct GatherBlocks {
-	const uint32_t *const *ins_ptrs[kMaxWorkers];    // worker w's device array of block pointers
-	const int *ins_cnts[kMaxWorkers];                // ... and of block counts
-	uint32_t ins_first[kMaxWorkers + 1];             // worker w's first block in the gathered array
-	const uint32_t *del_ptr[kMaxWorkers];
-	int del_cnt[kMaxWorkers];
-	int nw;
+// the searches of all workers, the mark pass of the cycle's deletes (on the device's first workspace) and the mark
+// pass of its inserts (on the second) in ONE launch: the mark work-groups come first, they are few and latency-bound.
+// (Before: search, a one-work-group launch gathering the workers' block lists, a mark launch for the deletes and one
+// for the inserts -- 8 + 5 + 11 + 20 us of a 96-us cycle: profiles/r06_scheduler_regime.txt.)
+struct MarkArgs {
+	Ctl *ctl;
+	unsigned long long *owner, *second;
+	uint4 *reqc;
+	uint8_t *state;
+	Undo *undo;
+	uint32_t *lost;
+	uint32_t req_cap;
+	uint32_t nblk;
+	uint32_t blocks;        // work-groups of this mark pass in the launch
+	int lazy_on;
 };
 
-__global__ __launch_bounds__(1024) void k_gather_blocks(GatherBlocks a, const uint32_t **ins_ptrs, int *ins_cnts, const uint32_t **del_ptrs,
-		int *del_cnts)
+template <Op OP>
+__global__ __launch_bounds__(256) void k_search_multi_mark(MultiSearch a, const uint4 *__restrict__ table, DevGeom g, GatherBlocks gb,
+		MarkArgs del, MarkArgs ins)
 {
-	const uint32_t t = threadIdx.x;
-	if (t < a.ins_first[a.nw]) {
-		int w = 0;
-		while (w + 1 < a.nw && t >= a.ins_first[w + 1])
-			w++;
-		const uint32_t b = t - a.ins_first[w];
-		ins_ptrs[t] = a.ins_ptrs[w][b];
-		ins_cnts[t] = a.ins_cnts[w][b];
+	const uint32_t b = blockIdx.x;
+	ReqSrc src = {};
+	src.cnt_stride = 1;
+	if (b < del.blocks) {
+		src.nblk = del.nblk;
+		mark_body<OP_DELETE, true>(b, del.blocks, del.ctl, src, g, del.owner, del.second, del.reqc, del.state, del.req_cap, 0u, kNone,
+				nullptr, 0u, nullptr, nullptr, gb);
+		return;
 	}
-	if (t < (uint32_t)a.nw) {
-		del_ptrs[t] = a.del_ptr[t];
-		del_cnts[t] = a.del_cnt[t];
+	if (b < del.blocks + ins.blocks) {
+		src.nblk = ins.nblk;
+		mark_body<OP, true>(b - del.blocks, ins.blocks, ins.ctl, src, g, ins.owner, ins.second, ins.reqc, ins.state, ins.req_cap, 0u,
+				kNone, reinterpret_cast<const uint32_t *>(table), (uint32_t)ins.lazy_on, ins.undo, ins.lost, gb);
+		return;
 	}
-}
-
-// the gathered arrays: one set per device, made on first use (a cycle's calls are one turn: CallGuard)
-struct WorkerArrays {
-	const uint32_t **ins_ptrs = nullptr, **del_ptrs = nullptr;
-	int *ins_cnts = nullptr, *del_cnts = nullptr;
-};
-static WorkerArrays g_wk[64];
-
-static void free_worker_arrays(WorkerArrays *a)
-{
-	if (a->ins_ptrs) (void)hipFree(a->ins_ptrs);
-	if (a->ins_cnts) (void)hipFree(a->ins_cnts);
-	if (a->del_ptrs) (void)hipFree(a->del_ptrs);
-	if (a->del_cnts) (void)hipFree(a->del_cnts);
-	*a = WorkerArrays();
+	const uint32_t sb = b - del.blocks - ins.blocks;
+	int w = 0;
+	while (w + 1 < a.nw && sb >= a.first[w + 1])
+		w++;
+	search_body<4, true, false>(sb - a.first[w], a.in[w], a.out[w], table, (int64_t)a.n[w], g.hash_mask, g.blk_mask);
 }
 
 }  // namespace mkv
 
 extern "C" void mkv_after_search(void *stream);
+extern "C" int mkv_defer_barrier(void);
 
 extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const mkv_worker_t *workers, int nworkers,
 		void *stream)
@@ -1082,6 +1089,9 @@ extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const 
 	mkv::DevGeom d;
 	if (!mkv::make_dev_geom(geom, &d) || !table || !workers || nworkers < 1 || nworkers > mkv::kMaxWorkers)
 		return MKV_EINVAL;
+	const int brc = mkv_defer_barrier();        // (the drop-in side's queued request copies, deferred mode: mkv_abi.hip)
+	if (brc != MKV_OK)
+		return brc;
 	int dev = 0;
 	if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64)
 		return MKV_EHIP;
@@ -1119,66 +1129,80 @@ extern "C" int mkv_cycle_workers(const mkv_geom_t *geom, bucket_t *table, const 
 	if (nblk > (uint32_t)mkv::kMaxBlocks)
 		return MKV_EINVAL;
 	mkv::CallGuard call;                        // (the parts below are one turn)
-	mkv::WorkerArrays &wa = mkv::g_wk[dev];
-	if (!wa.ins_ptrs) {
-		// (all four or none: a call that finds the first pointer set takes the set for complete)
-		mkv::WorkerArrays na;
-		const size_t n = (size_t)mkv::kMaxBlocks;
-		if (hipMalloc(&na.ins_ptrs, n * sizeof(void *)) != hipSuccess || hipMalloc(&na.ins_cnts, n * sizeof(int)) != hipSuccess ||
-				hipMalloc(&na.del_ptrs, mkv::kMaxWorkers * sizeof(void *)) != hipSuccess ||
-				hipMalloc(&na.del_cnts, mkv::kMaxWorkers * sizeof(int)) != hipSuccess) {
-			mkv::free_worker_arrays(&na);
-			return MKV_ENOMEM;
-		}
-		wa = na;
-	}
+	mkv::Workspace *w0 = nullptr, *w1 = nullptr;
 	if (nblk || ndel) {
-		// A call that is refused enqueues nothing: whatever can refuse it comes before the search launch.
-		// (The gathered lists are one set per device: a call on another stream must not rewrite them under this
-		// device's last update -- the order the updates below would take anyway, taken now; and the update
-		// workspace is sized for what the cycle carries.)
+		// A call that is refused enqueues nothing: whatever can refuse it comes before the launch.  (The updates take
+		// their place in the device's issue order now; the deletes use the device's first workspace, the inserts its
+		// second one -- the two mark passes run side by side.)
 		const int orc = mkv::order_updates(s);
 		if (orc != MKV_OK)
 			return orc;
-		mkv::Workspace *w = nullptr;
 		mkv::ReqSrc probe = {};
 		probe.single_n = ndel;
-		const int wrc = mkv::ensure_ws(&w, (uint64_t)d.hash_mask + 1, mkv::ws_need(probe, 0), s);
+		int wrc = ndel ? mkv::ensure_ws(&w0, (uint64_t)d.hash_mask + 1, mkv::ws_need(probe, 0), s) : MKV_OK;
+		if (wrc == MKV_OK && nblk) {
+			probe.single_n = 0;
+			wrc = mkv::ensure_ws(&w1, (uint64_t)d.hash_mask + 1, mkv::ws_need(probe, 0), s, mkv::kCycleSalt);
+		}
 		if (wrc != MKV_OK)
 			return wrc;
 	}
-	if (blocks)
+	const bool cuckoo = d.scheme != MKV_SCHEME_2CHOICE;
+	if (w0 || w1) {
+		mkv::MarkArgs del = {}, ins = {};
+		if (w0) {
+			del.ctl = w0->ctl;
+			del.owner = w0->owner[0];
+			del.second = w0->owner[4];
+			del.reqc = w0->reqc;
+			del.state = w0->state;
+			del.req_cap = (uint32_t)w0->req_cap;
+			del.nblk = (uint32_t)nworkers;
+			del.blocks = (uint32_t)((ndel + 255) / 256 > 256 ? 256 : (ndel + 255) / 256);
+		}
+		if (w1) {
+			ins.ctl = w1->ctl;
+			ins.owner = w1->owner[0];
+			ins.second = w1->owner[4];
+			ins.reqc = w1->reqc;
+			ins.state = w1->state;
+			ins.undo = mkv::tuning().plans ? w1->undo : nullptr;
+			ins.lost = w1->lost;
+			ins.req_cap = (uint32_t)w1->req_cap;
+			ins.nblk = nblk;
+			// (the size of the pass is the device's to know: a lane per request of what the reference's scheduler hands
+			// a worker at most -- 8 x 4 096 -- would be 2 048 work-groups with 16 workers; four per block is one turn
+			// for the usual 6 000 inserts per worker and costs the launch nothing)
+			ins.blocks = mkv::mark_blocks_for(0, w1->barrier_score > 0);
+			if (ins.blocks < 4u * nblk)
+				ins.blocks = 4u * nblk > 1024u ? 1024u : 4u * nblk;
+			ins.lazy_on = mkv::tuning().lazy_alt | (w1->host_flag && w1->host_flag[4] ? 0x100 : 0);
+			w1->cycle_sorted = false;
+		}
+		const dim3 grid(del.blocks + ins.blocks + blocks), blk(256);
+		if (cuckoo)
+			hipLaunchKernelGGL((mkv::k_search_multi_mark<mkv::OP_CUCKOO>), grid, blk, 0, s, ms, reinterpret_cast<const uint4 *>(table), d, gb,
+					del, ins);
+		else
+			hipLaunchKernelGGL((mkv::k_search_multi_mark<mkv::OP_2CHOICE>), grid, blk, 0, s, ms, reinterpret_cast<const uint4 *>(table), d, gb,
+					del, ins);
+	} else if (blocks) {
 		hipLaunchKernelGGL(mkv::k_search_multi, dim3(blocks), dim3(256), 0, s, ms, reinterpret_cast<const uint4 *>(table),
 				d.hash_mask, d.blk_mask);
+	}
 	mkv_after_search(s);        // (the deferred mode's queued result copies: mkv_abi.hip)
-	if (nblk || ndel)
-		hipLaunchKernelGGL(mkv::k_gather_blocks, dim3(1), dim3(1024), 0, s, gb, wa.ins_ptrs, wa.ins_cnts, wa.del_ptrs,
-				wa.del_cnts);
 	if (hipGetLastError() != hipSuccess)
 		return MKV_EHIP;
 	uint32_t *t = reinterpret_cast<uint32_t *>(table);
 	int rc = MKV_OK;
-	if (ndel) {
-		mkv::ReqSrc src;
-		src.blk_input = wa.del_ptrs;
-		src.single = nullptr;
-		src.blk_elem_num = wa.del_cnts;
-		src.single_n = 0;
-		src.nblk = (uint32_t)nworkers;
-		src.cnt_stride = 1;
-		rc = mkv::run_update<mkv::OP_DELETE>(d, t, src, s, ndel);
-	}
-	if (rc == MKV_OK && nblk) {
-		mkv::ReqSrc src;
-		src.blk_input = wa.ins_ptrs;
-		src.single = nullptr;
-		src.blk_elem_num = wa.ins_cnts;
-		src.single_n = 0;
-		src.nblk = nblk;
-		src.cnt_stride = 1;
-		rc = d.scheme == MKV_SCHEME_2CHOICE ? mkv::run_update<mkv::OP_2CHOICE>(d, t, src, s, 0)
-		                                    : mkv::run_update<mkv::OP_CUCKOO>(d, t, src, s, 0);
-	}
+	if (w0)
+		rc = mkv::launch_rounds<mkv::OP_DELETE>(w0, d, t, s, 0, mkv::kNone, 1, 1, nullptr, ndel);
+	// (the inserts' mark pass read the table ahead of the cycle's deletes: its plans do not stand if there were any)
+	if (rc == MKV_OK && w1)
+		rc = cuckoo ? mkv::launch_rounds<mkv::OP_CUCKOO>(w1, d, t, s, 0, mkv::kNone, 1, 1, nullptr, 0, ndel == 0)
+		            : mkv::launch_rounds<mkv::OP_2CHOICE>(w1, d, t, s, 0, mkv::kNone, 1, 1, nullptr, 0, ndel == 0);
+	if (rc == MKV_OK && (w0 || w1))
+		rc = mkv::updates_issued(s);
 	return rc;
 }
 
@@ -1192,6 +1216,9 @@ extern "C" int mkv_delete(const mkv_geom_t *geom, delem_t *in, bucket_t *table,
 		return MKV_OK;
 	if (!table || !in)
 		return MKV_EINVAL;
+	const int brc = mkv_defer_barrier();
+	if (brc != MKV_OK)
+		return brc;
 	mkv::ReqSrc src;
 	src.blk_input = nullptr;
 	src.single = reinterpret_cast<const uint32_t *>(in);
@@ -1246,8 +1273,6 @@ extern "C" void mkv_release_all(void)
 		delete kv.second;
 	}
 	mkv::g_ws.clear();
-	for (int dev = 0; dev < 64; dev++)
-		mkv::free_worker_arrays(&mkv::g_wk[dev]);
 	for (auto &kv : mkv::g_order)
 		if (kv.second.ev)
 			(void)hipEventDestroy(kv.second.ev);
