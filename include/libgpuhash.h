@@ -27,12 +27,17 @@
  *   - gpu_hash_insert / gpu_hash_delete keep a device workspace (reservation tables, request
  *     state), created on the first call that needs it -- call mkv_reserve() (megakv_hip.h) at
  *     start-up to keep the allocation out of the request path;
- *   - one insert/delete call may carry at most MKV_REQ_CAP requests (environment variable,
- *     default 4 194 304; the reference's hosts stay below 32 768 per call,
- *     src/mega.c:143-144,163-165).  The counts are device memory, so an oversize batch is only
- *     detected on the device: it is NOT applied; the next insert/delete call reports it on
- *     stderr, once per dropped batch, and mkv_dropped_batches() (megakv_hip.h) counts them --
- *     nothing aborts.  mkv_insert_hinted takes the batch size and grows the workspace instead.
+ *   - the workspace holds MKV_REQ_CAP requests (environment variable, default 4 194 304; the
+ *     reference's hosts stay below 32 768 per call, src/mega.c:143-144,163-165) unless the library
+ *     knows the size of a batch.  gpu_hash_delete's count is an argument.  gpu_hash_insert's counts
+ *     are device memory -- but a host that wrote them the reference's way, with cudaMemcpy /
+ *     cudaMemcpyAsync from host memory through this library (src/mega_scheduler.c:487-494), has
+ *     shown them to it on the way: a batch of any size up to 16 777 200 requests is then sized, the
+ *     workspace grown and the batch run in passes.  Only counts the library never saw (written by a
+ *     kernel of the host's) leave it blind: such a batch beyond the workspace is detected on the
+ *     device and NOT applied; the next insert/delete call reports it on stderr, once per dropped
+ *     batch, and mkv_dropped_batches() (megakv_hip.h) counts them -- nothing aborts.
+ *     mkv_insert_hinted takes the batch size as an argument.
  *
  * Result definition: search output and final table state are bit-identical to
  * the reference kernels executed one request at a time in (block, index) order

@@ -290,6 +290,20 @@ int mkv_slots_cycle(const mkv_geom_t *geom, const uint32_t *recvbuf, int nslots,
 /* out[e] = back[where[e]] for the n_get requests of the batch that was packed with
  * perm_get = where (a request that was dropped by an overflowing slot gets 0). */
 int mkv_unpack_results(const loc_t *back, const int32_t *where, int64_t n_get, loc_t *out, void *stream);
+/* The pack with a rank's own slot written elsewhere (self_slot: its receive buffer; self < 0: none) and,
+ * with tile_meta (mkv_pack_meta_words(n_get) words, or NULL), a note of where every tile of GETs went -- one
+ * contiguous run per shard: mkv_unpack_results_tiled then brings a tile's results back run by run, streamed
+ * through LDS, instead of gathering 8 bytes per request.  tile_meta is written only by the pack that is ONE
+ * launch (mkv_pack_one_launch(n_set, nshards, scratch_bytes) != 0: ask first); the un-pack must see the
+ * same tuning "pack_threads" as the pack. */
+int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_bytes);
+int64_t mkv_pack_meta_words(int64_t n_get);
+int mkv_pack_requests_meta(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, uint32_t *tile_meta, void *stream);
+int mkv_unpack_results_tiled(const loc_t *back, const int32_t *where, int64_t n_get, loc_t *out,
+		const uint32_t *tile_meta, int nshards, int64_t cap_get, void *stream);
 
 /* Request packets of the reference's protocol on the device (src/mega_recv.c:292-545,
  * README.md:70-81): payloads = npackets UDP payloads at `stride` bytes (a multiple of 4,

@@ -24,6 +24,8 @@ extern "C" int mkv_flush(void);
 extern "C" int mkv_defer_copy(void *dst, const void *src, size_t n, void *stream);
 extern "C" int mkv_defer_copy_in(void *dst, const void *src, size_t n, void *stream);
 extern "C" void mkv_pinned_note(void *p, size_t n, int add);
+extern "C" void mkv_note_h2d(void *dst, const void *src, size_t n);
+extern "C" void mkv_note_write(void *dst, size_t n);
 extern "C" int mkv_defer_memset(void *p, int value, size_t n, void *stream);
 extern "C" void mkv_defer_touch(void);
 
@@ -58,21 +60,33 @@ cudaError_t cudaFreeHost(void *p)
 cudaError_t cudaMemset(void *p, int v, size_t n)
 {
 	const cudaError_t f = flushed();
+	mkv_note_write(p, n);
 	return f ? f : (cudaError_t)hipMemset(p, v, n);
 }
 cudaError_t cudaMemsetAsync(void *p, int v, size_t n, cudaStream_t s)
 {
+	mkv_note_write(p, n);
 	if (mkv_defer_memset(p, v, n, (void *)s))
 		return (cudaError_t)hipSuccess;     // (held: the search that follows may make it superfluous, mkv_abi.hip)
 	return (cudaError_t)hipMemsetAsync(p, v, n, (hipStream_t)s);
 }
+// (what the host copies into small device arrays is remembered -- gpu_hash_insert's block counts: mkv_abi.hip)
+static void note_copy(void *d, const void *s, size_t n, enum cudaMemcpyKind k)
+{
+	if (k == cudaMemcpyHostToDevice)
+		mkv_note_h2d(d, s, n);
+	else if (k == cudaMemcpyDeviceToDevice || k == cudaMemcpyDefault)
+		mkv_note_write(d, n);
+}
 cudaError_t cudaMemcpy(void *d, const void *s, size_t n, enum cudaMemcpyKind k)
 {
 	const cudaError_t f = flushed();
+	note_copy(d, s, n, k);
 	return f ? f : (cudaError_t)hipMemcpy(d, s, n, kind_of(k));
 }
 cudaError_t cudaMemcpyAsync(void *d, const void *s, size_t n, enum cudaMemcpyKind k, cudaStream_t st)
 {
+	note_copy(d, s, n, k);
 	if (k == cudaMemcpyDeviceToHost) {
 		if (mkv_defer_copy(d, s, n, (void *)st))
 			return (cudaError_t)hipSuccess;

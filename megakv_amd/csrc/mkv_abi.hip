@@ -412,6 +412,79 @@ int defer_flush_locked_inner()
 
 }  // namespace
 
+// ---- what the host copied into small device arrays: the block counts of gpu_hash_insert ----------------------
+// The ABI hands gpu_hash_insert its block counts in DEVICE memory (ref libgpuhash/gpu_hash.cu:236-237), so the
+// library does not know how big a batch is -- and an update workspace holds MKV_REQ_CAP requests unless told
+// otherwise (mkv_insert_hinted).  The reference's hosts write those counts with a copy from host memory right before
+// the call (src/mega_scheduler.c:487-494), through the library's own cudaMemcpy / cudaMemcpyAsync: small
+// host-to-device copies are remembered here (the bytes, by destination), and gpu_hash_insert looks its count array
+// up -- a batch of any size is then sized and run in passes like a hinted one, not dropped.  Anything else the
+// library sees written over such an array (memset, another copy) forgets it; counts a kernel of the host's wrote
+// are not seen at all -- such a batch is bounded by the workspace as before.
+namespace {
+struct NotedCopy {
+	const char *dst = nullptr;
+	size_t n = 0;
+	int words[1024];
+};
+constexpr int kNoted = 32;
+std::mutex g_noted_mutex;
+NotedCopy *g_noted = nullptr;       // kNoted entries, round robin
+int g_noted_next = 0;
+
+void forget_noted_locked(const char *d, size_t n)
+{
+	if (!g_noted)
+		return;
+	for (int k = 0; k < kNoted; k++)
+		if (g_noted[k].dst && d < g_noted[k].dst + g_noted[k].n && g_noted[k].dst < d + n)
+			g_noted[k].dst = nullptr;
+}
+}  // namespace
+
+// a host-to-device copy through the library's cudaMemcpy / cudaMemcpyAsync (src: host memory, still valid)
+extern "C" void mkv_note_h2d(void *dst, const void *src, size_t n)
+{
+	std::lock_guard<std::mutex> lock(g_noted_mutex);
+	forget_noted_locked(reinterpret_cast<const char *>(dst), n);
+	if (n == 0 || n > sizeof(NotedCopy::words) || (n & 3u))
+		return;
+	if (!g_noted)
+		g_noted = new NotedCopy[kNoted];
+	NotedCopy &e = g_noted[g_noted_next];
+	g_noted_next = (g_noted_next + 1) % kNoted;
+	e.dst = reinterpret_cast<const char *>(dst);
+	e.n = n;
+	memcpy(e.words, src, n);
+}
+
+// device memory written some other way the library sees (memset, device-to-device copy)
+extern "C" void mkv_note_write(void *dst, size_t n)
+{
+	std::lock_guard<std::mutex> lock(g_noted_mutex);
+	forget_noted_locked(reinterpret_cast<const char *>(dst), n);
+}
+
+// the sum of the `count` ints at device address p if the host is known to have copied them there; -1: unknown
+static long long noted_total(const int *p, int count)
+{
+	std::lock_guard<std::mutex> lock(g_noted_mutex);
+	if (!g_noted || count <= 0)
+		return -1;
+	const char *c = reinterpret_cast<const char *>(p);
+	for (int k = 0; k < kNoted; k++) {
+		const NotedCopy &e = g_noted[k];
+		if (e.dst && c >= e.dst && c + (size_t)count * 4u <= e.dst + e.n) {
+			const int *w = e.words + (c - e.dst) / 4;
+			long long sum = 0;
+			for (int b = 0; b < count; b++)
+				sum += w[b] > 0 ? w[b] : 0;
+			return sum;
+		}
+	}
+	return -1;
+}
+
 // for the library's cudaHostAlloc / cudaFreeHost
 extern "C" void mkv_pinned_note(void *p, size_t n, int add)
 {
@@ -567,8 +640,11 @@ extern "C" void gpu_hash_insert(bucket_t *hash_table, ielem_t **blk_input, int *
 		// recorded, in the order the host issued the calls)
 		die_on(defer_flush_locked(), "gpu_hash_insert/flush");
 	}
-	die_on(mkv_insert(&kGeom, hash_table, blk_input, blk_elem_num, num_blks, (void *)stream),
-			"gpu_hash_insert");
+	// (the size of the batch, if the host's copy of the counts came by the library: a batch beyond the workspace is
+	// then run in passes; 0 = unknown, bounded by MKV_REQ_CAP)
+	const long long known = noted_total(blk_elem_num, num_blks);
+	die_on(mkv_insert_hinted(&kGeom, hash_table, blk_input, blk_elem_num, num_blks,
+				known > mkv::tuning().req_cap && known <= (1ll << 24) - 16 ? known : 0, (void *)stream), "gpu_hash_insert");
 }
 
 extern "C" void gpu_hash_delete(delem_t *in, bucket_t *hash_table, int num_elem, int num_thread,

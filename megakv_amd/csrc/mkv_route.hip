@@ -366,6 +366,7 @@ constexpr int kCursorStride = 32;    // words between two shards' cursors (a 128
 constexpr int kPackArrive = kPackBins * kCursorStride, kPackDone = kPackArrive + kCursorStride;
 constexpr int kPackCtlWords = kPackDone + kCursorStride;    // cursors, arrive, done; then the SET tiles' counts
 constexpr int64_t kTileR8From = 1 << 19;                    // batches from this many GETs on: 8 per lane, else 4
+constexpr int kPackMetaWords = 2 * kPackBins + 1;           // per GET tile: s_off[0 .. kPackBins], s_base[0 .. kPackBins)
 
 // lanes per work-group of the one-launch pack (tuning "pack_threads": 256, 512 or 1024)
 static inline int pack_threads()
@@ -434,8 +435,11 @@ __global__ __launch_bounds__(THREADS) void k_pack_tiles(const uint32_t *__restri
 		const uint32_t *__restrict__ sets, int64_t n_set, uint32_t hash_mask, uint32_t shift, int nshards,
 		uint32_t *__restrict__ sendbuf, int64_t slot_words, uint32_t cap_get, uint32_t cap_set,
 		int32_t *__restrict__ perm_get, uint32_t *ctl, int *overflow, uint32_t set_tiles, uint32_t get_tiles,
-		uint32_t self, uint32_t *__restrict__ self_slot)
+		uint32_t self, uint32_t *__restrict__ self_slot, uint32_t *__restrict__ tile_meta)
 {
+	// (tile_meta: where every GET tile's runs went -- per tile kPackMetaWords words: the runs' places in the tile's
+	// staging order, s_off[0 .. kPackBins], then their first places in the slots, s_base[0 .. kPackBins) -- for the
+	// un-pack that brings a tile's results back run by run, k_unpack_tiled; null: not kept)
 	// (self_slot: the slot of shard `self` is written THERE -- the rank's own receive buffer: what a
 	// rank sends to itself need not pass through the exchange; self >= nshards: none)
 	constexpr int kTile = THREADS * R, kSetTile = THREADS * 4, NW = THREADS / 64;
@@ -583,6 +587,12 @@ __global__ __launch_bounds__(THREADS) void k_pack_tiles(const uint32_t *__restri
 				s_off[kPackBins] = incl;
 		}
 		__syncthreads();
+		if (tile_meta && t <= kPackBins) {
+			uint32_t *m = tile_meta + (size_t)tile * kPackMetaWords;
+			m[t] = s_off[t];
+			if (t < kPackBins)
+				m[kPackBins + 1 + t] = s_base[t];
+		}
 		uint32_t wbase = 0;                    // lane k: this wave's first place inside shard k's run of the tile
 		if (lane < G)
 			for (uint32_t wv = 0; wv < wave; wv++)
@@ -692,6 +702,78 @@ __global__ __launch_bounds__(256) void k_unpack_results(const uint2 *__restrict_
 	}
 }
 
+// The same by TILES of the pack (k_pack_tiles, tile_meta): a tile's requests went to the slots as one contiguous run
+// per shard, so their results come back as one contiguous run per shard -- streamed into LDS, a 16-byte piece a lane,
+// in the order the pack staged them -- and every request picks its result from there: no gather from global memory
+// (k_unpack_results asks the memory side for 8 bytes per request from eight places at once, beside a search that
+// is bound by the memory side's request rate: 7.5 us alone, 17.6 us in an eight-rank schedule).
+template <int R, int THREADS>
+__global__ __launch_bounds__(THREADS) void k_unpack_tiled(const uint2 *__restrict__ back, const int32_t *__restrict__ where,
+		int64_t n_get, uint2 *__restrict__ out, const uint32_t *__restrict__ tile_meta, int nshards, uint32_t cap_get)
+{
+	constexpr int kTile = THREADS * R;
+	__shared__ uint2 s_stage[kTile];
+	__shared__ uint32_t s_off[kPackBins + 1], s_base[kPackBins];
+	const uint32_t t = threadIdx.x, G = (uint32_t)nshards;
+	const uint32_t tile = blockIdx.x;
+	const int64_t tile0 = (int64_t)tile * kTile;
+	const uint32_t *m = tile_meta + (size_t)tile * kPackMetaWords;
+	if (t <= kPackBins)
+		s_off[t] = m[t];
+	if (t < kPackBins)
+		s_base[t] = m[kPackBins + 1 + t];
+	__syncthreads();
+	for (uint32_t k = 0; k < G; k++) {
+		const uint32_t lo = s_off[k], n = s_off[k + 1u] - lo, base = s_base[k];
+		const uint2 *src = back + (size_t)k * cap_get + base;
+		// (a run starts anywhere in its slot: the first lanes take single results up to a 16-byte boundary, then pairs)
+		const uint32_t head = (uint32_t)((reinterpret_cast<uintptr_t>(src) >> 3) & 1u) & (n ? 1u : 0u);
+		if (t < head)
+			s_stage[lo] = base < cap_get ? src[0] : make_uint2(0u, 0u);
+		const uint32_t pairs = (n - head) >> 1;
+		const uint4 *src4 = reinterpret_cast<const uint4 *>(src + head);
+		for (uint32_t j = t; j < pairs; j += THREADS) {
+			const uint32_t at = head + 2u * j;
+			uint4 v = make_uint4(0u, 0u, 0u, 0u);
+			if (base + at + 1u < cap_get)
+				v = src4[j];
+			else if (base + at < cap_get)
+				v = make_uint4(src[at].x, src[at].y, 0u, 0u);
+			s_stage[lo + at] = make_uint2(v.x, v.y);
+			s_stage[lo + at + 1u] = make_uint2(v.z, v.w);
+		}
+		if (t == 0 && ((n - head) & 1u)) {
+			const uint32_t at = n - 1u;
+			s_stage[lo + at] = base + at < cap_get ? src[at] : make_uint2(0u, 0u);
+		}
+	}
+	__syncthreads();
+	const bool wide = ((reinterpret_cast<uintptr_t>(where) & 7u) | (reinterpret_cast<uintptr_t>(out) & 15u)) == 0u;
+#pragma unroll
+	for (int i = 0; i < R / 2; i++) {
+		const int64_t e = tile0 + 2 * ((int64_t)i * THREADS + t);
+		if (e >= n_get)
+			continue;
+		const int32_t w0 = where[e], w1 = e + 1 < n_get ? where[e + 1] : -1;
+		uint2 a = make_uint2(0u, 0u), b = a;
+		if (w0 >= 0) {
+			const uint32_t k = (uint32_t)w0 / cap_get;
+			a = s_stage[s_off[k] + ((uint32_t)w0 - k * cap_get - s_base[k])];
+		}
+		if (w1 >= 0) {
+			const uint32_t k = (uint32_t)w1 / cap_get;
+			b = s_stage[s_off[k] + ((uint32_t)w1 - k * cap_get - s_base[k])];
+		}
+		if (wide && e + 2 <= n_get) {
+			*reinterpret_cast<uint4 *>(out + e) = make_uint4(a.x, a.y, b.x, b.y);
+		} else {
+			out[e] = a;
+			if (e + 1 < n_get)
+				out[e + 1] = b;
+		}
+	}
+}
+
 }  // namespace mkv
 
 extern "C" int64_t mkv_pack_slot_words(int64_t cap_get, int64_t cap_set)
@@ -757,10 +839,33 @@ extern "C" int mkv_pack_requests(const selem_t *gets, int64_t n_get, const ielem
 // The same with the slot of shard `self` written to self_slot instead of its place in sendbuf (the
 // sharded engine: a rank's requests for its own shard go straight into its receive buffer).
 // self < 0: none.  Not with the three-pass fall-back (MKV_EINVAL: the caller packs without).
+extern "C" int mkv_pack_requests_meta(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, uint32_t *tile_meta, void *stream);
+
 extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
 		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
 		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
 		int self, uint32_t *self_slot, void *stream)
+{
+	return mkv_pack_requests_meta(gets, n_get, sets, n_set, hash_mask_agg, shard_shift, nshards, sendbuf, cap_get, cap_set,
+			perm_get, scratch, scratch_bytes, overflow, self, self_slot, nullptr, stream);
+}
+
+// words of the tile_meta array of mkv_pack_requests_meta / mkv_unpack_results_tiled for batches of up to n_get GETs
+extern "C" int64_t mkv_pack_meta_words(int64_t n_get)
+{
+	return ((n_get > 0 ? n_get : 0) / 1024 + 2) * mkv::kPackMetaWords;      // (the smallest GET tile: 256 lanes x 4)
+}
+
+// The same; with tile_meta (mkv_pack_meta_words(n_get) words, or NULL) the one-launch pack notes where every tile's
+// runs went, for mkv_unpack_results_tiled.  tile_meta is only written when the pack is ONE launch
+// (mkv_pack_one_launch): a caller that wants the tiled un-pack asks that first.
+extern "C" int mkv_pack_requests_meta(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, uint32_t *tile_meta, void *stream)
 {
 	if (self >= nshards || (self >= 0 && !self_slot))
 		return MKV_EINVAL;
@@ -792,7 +897,7 @@ extern "C" int mkv_pack_requests_self(const selem_t *gets, int64_t n_get, const 
 		hipLaunchKernelGGL((mkv::k_pack_tiles<R, T>), dim3((unsigned)blocks), dim3(T), 0, s, g32, n_get, s32, n_set, \
 				hash_mask_agg, shard_shift, nshards, sendbuf, slot_words, (uint32_t)cap_get, (uint32_t)cap_set, perm_get, \
 				reinterpret_cast<uint32_t *>(scratch), overflow, (uint32_t)set_tiles, (uint32_t)get_tiles, \
-				self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot)
+				self >= 0 ? (uint32_t)self : 0xffffffffu, self_slot, tile_meta)
 		if (threads == 1024) {
 			if (r8) MKV_PACK_LAUNCH(8, 1024); else MKV_PACK_LAUNCH(4, 1024);
 		} else if (threads == 512) {
@@ -849,6 +954,37 @@ extern "C" int mkv_unpack_results(const loc_t *back, const int32_t *where, int64
 		blocks = 4096;
 	hipLaunchKernelGGL(mkv::k_unpack_results, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream,
 			reinterpret_cast<const uint2 *>(back), where, n_get, reinterpret_cast<uint2 *>(out));
+	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
+}
+
+// the un-pack by the pack's tiles (k_unpack_tiled): tile_meta as mkv_pack_requests_meta of THIS batch left it (a pack
+// in one launch, the same tuning "pack_threads" since), nshards and cap_get as packed
+extern "C" int mkv_unpack_results_tiled(const loc_t *back, const int32_t *where, int64_t n_get, loc_t *out,
+		const uint32_t *tile_meta, int nshards, int64_t cap_get, void *stream)
+{
+	if (n_get < 0 || (n_get && (!back || !where || !out || !tile_meta)) || nshards < 1 || nshards > mkv::kPackBins ||
+			cap_get <= 0 || cap_get > 0x7fffffffLL)
+		return MKV_EINVAL;
+	if (n_get == 0)
+		return MKV_OK;
+	const bool r8 = n_get >= mkv::kTileR8From;
+	const int threads = mkv::pack_threads();
+	const int64_t get_tile = (int64_t)threads * (r8 ? 8 : 4);
+	const int64_t tiles = (n_get + get_tile - 1) / get_tile;
+	hipStream_t s = (hipStream_t)stream;
+	const uint2 *b2 = reinterpret_cast<const uint2 *>(back);
+	uint2 *o2 = reinterpret_cast<uint2 *>(out);
+#define MKV_UNPACK_LAUNCH(R, T) \
+	hipLaunchKernelGGL((mkv::k_unpack_tiled<R, T>), dim3((unsigned)tiles), dim3(T), 0, s, b2, where, n_get, o2, tile_meta, nshards, \
+			(uint32_t)cap_get)
+	if (threads == 1024) {
+		if (r8) MKV_UNPACK_LAUNCH(8, 1024); else MKV_UNPACK_LAUNCH(4, 1024);
+	} else if (threads == 512) {
+		if (r8) MKV_UNPACK_LAUNCH(8, 512); else MKV_UNPACK_LAUNCH(4, 512);
+	} else {
+		if (r8) MKV_UNPACK_LAUNCH(8, 256); else MKV_UNPACK_LAUNCH(4, 256);
+	}
+#undef MKV_UNPACK_LAUNCH
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

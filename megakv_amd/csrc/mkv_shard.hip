@@ -25,6 +25,13 @@
 #include "megakv_hip.h"
 
 extern "C" int mkv_pack_one_launch(int64_t n_set, int nshards, int64_t scratch_bytes);
+extern "C" int64_t mkv_pack_meta_words(int64_t n_get);
+extern "C" int mkv_pack_requests_meta(const selem_t *gets, int64_t n_get, const ielem_t *sets, int64_t n_set,
+		uint32_t hash_mask_agg, uint32_t shard_shift, int nshards, uint32_t *sendbuf, int64_t cap_get,
+		int64_t cap_set, int32_t *perm_get, void *scratch, int64_t scratch_bytes, int *overflow,
+		int self, uint32_t *self_slot, uint32_t *tile_meta, void *stream);
+extern "C" int mkv_unpack_results_tiled(const loc_t *back, const int32_t *where, int64_t n_get, loc_t *out,
+		const uint32_t *tile_meta, int nshards, int64_t cap_get, void *stream);
 
 namespace {
 
@@ -50,6 +57,7 @@ struct Lane {
 	// the un-pack of batch i, which nobody waits for, may still be reading the other one.
 	loc_t *back_slots[2] = {nullptr, nullptr};
 	int32_t *perm2[2] = {nullptr, nullptr};
+	uint32_t *meta2[2] = {nullptr, nullptr};    // where each GET tile's runs went (mkv_pack_requests_meta), beside perm2
 	uint32_t *scratch = nullptr;
 	ielem_t **set_ptrs = nullptr;
 	hipEvent_t ev_local[2] = {nullptr, nullptr};   // alternated so a pending wait keeps its event
@@ -67,6 +75,7 @@ struct mkv_shard {
 	uint32_t agg_mask = 0, shift = 0;
 	int *overflow = nullptr;
 	int loopback = 0;               // rccl_path "loopback": the exchanges are local copies (tests)
+	bool tiled_unpack = false;      // the un-pack goes by the pack's tiles (k_unpack_tiled)
 	int self_direct = 0;            // what a rank sends to itself bypasses the exchange (the pack writes that slot
 	                                // into the receive buffer, the slot search its results into the buffer of
 	                                // returned results); the peers' slots go by grouped send / receive.  Settled
@@ -332,6 +341,8 @@ extern "C" void mkv_shard_destroy(mkv_shard *e)
 		if (l.out_slots) (void)hipFree(l.out_slots);
 		for (loc_t *b : l.back_slots)
 			if (b) (void)hipFree(b);
+		for (uint32_t *m : l.meta2)
+			if (m) (void)hipFree(m);
 		for (int32_t *w : l.perm2)
 			if (w) (void)hipFree(w);
 		if (l.scratch) (void)hipFree(l.scratch);
@@ -411,6 +422,15 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 	// has fewer tiles): settled here once, from arguments every rank passes alike, so that no rank
 	// changes the form of its exchanges in the middle of a run or apart from its peers.
 	e->self_direct = mkv_pack_one_launch(n_set, world, e->scratch_bytes) != 0;
+	// ... and the one-launch pack notes where its tiles' runs went: the un-pack can stream the results back run by run
+	// instead of gathering them request by request (k_unpack_tiled).  Measured on one MI355X, 2^20-request batches, 95/5
+	// Zipf (profiles/r06_loopback.txt): one rank 57.1 -> 54.5 us per batch through bench.py, 59.7 -> 58.0 looped back;
+	// EIGHT looped-back ranks 79.9 -> 82.5 us -- a tile then holds eight runs of a thousand results, and 122 work-groups
+	// of 1 024 lanes with two meetings each do not keep up with 4 096 independent ones.  So: up to two ranks by default
+	// (MKV_SHARD_TILED_UNPACK=0 / 1: never / whenever the pack is one launch).
+	e->tiled_unpack = e->self_direct && cap_get > 0 && world <= 2;
+	if (const char *v = getenv("MKV_SHARD_TILED_UNPACK"))
+		e->tiled_unpack = e->self_direct && cap_get > 0 && atoi(v) != 0;
 	if (const char *v = getenv("MKV_SHARD_SELF"))
 		e->self_direct = e->self_direct && atoi(v) != 0;
 
@@ -463,6 +483,8 @@ extern "C" int mkv_shard_create(mkv_shard **out, const mkv_geom_t *geom, int wor
 			SH_HIP(e, hipMalloc(&l.back_slots[k2], res_bytes));
 			SH_HIP(e, hipMemset(l.back_slots[k2], 0, res_bytes));
 			SH_HIP(e, hipMalloc(&l.perm2[k2], where_bytes));   // where each GET went
+			SH_HIP(e, hipMalloc(&l.meta2[k2], (size_t)mkv_pack_meta_words(n_get) * 4));
+			SH_HIP(e, hipMemset(l.meta2[k2], 0, (size_t)mkv_pack_meta_words(n_get) * 4));
 		}
 		SH_HIP(e, hipMalloc(&l.scratch, (size_t)e->scratch_bytes + 64));
 		SH_HIP(e, hipMemset(l.scratch, 0, (size_t)e->scratch_bytes + 64));   // the pack's control words start at zero
@@ -722,12 +744,10 @@ static int run_batches(mkv_shard *e, int nbatches, const selem_t *const *gets, c
 			return fail(e, MKV_ETOOBIG, "batch larger than the engine was created for", nullptr);
 		Span sp("pack", set, j, s, tr);
 		int32_t *where = l.perm2[(j / B) & 1];
-		const int rc = e->self_direct ?
-				mkv_pack_requests_self(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
-						e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, e->rank,
-						l.recvbuf + (size_t)e->rank * (size_t)e->slot_words, s) :
-				mkv_pack_requests(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
-						e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, s);
+		uint32_t *meta = e->tiled_unpack ? l.meta2[(j / B) & 1] : nullptr;
+		const int rc = mkv_pack_requests_meta(gets[j], n_get[j], sets[j], n_set[j], e->agg_mask, e->shift, e->world, l.sendbuf,
+				e->cap_get, e->cap_set, where, l.scratch, e->scratch_bytes, e->overflow, e->self_direct ? e->rank : -1,
+				e->self_direct ? l.recvbuf + (size_t)e->rank * (size_t)e->slot_words : nullptr, meta, s);
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_pack_requests", nullptr);
 		return MKV_OK;
@@ -799,7 +819,9 @@ static int run_batches(mkv_shard *e, int nbatches, const selem_t *const *gets, c
 #endif
 		{
 			Span sp("unpack", b, i, S, tr);
-			rc = mkv_unpack_results(l.back_slots[k], l.perm2[k], n_get[i], outs[i], S);
+			rc = e->tiled_unpack ? mkv_unpack_results_tiled(l.back_slots[k], l.perm2[k], n_get[i], outs[i], l.meta2[k], e->world,
+							e->cap_get, S)
+					: mkv_unpack_results(l.back_slots[k], l.perm2[k], n_get[i], outs[i], S);
 		}
 		if (rc != MKV_OK)
 			return fail(e, rc, "mkv_unpack_results", nullptr);

@@ -64,3 +64,50 @@ def test_oversize_unhinted_batch_is_loud():
     assert p.returncode == 0, p.stderr[-3000:]
     assert "first call returned" in p.stdout and "went on" in p.stdout
     assert "more requests than the update workspace holds" in p.stderr and "dropped" in p.stderr
+
+
+DROPIN = r"""
+import ctypes, numpy as np, torch
+import megakv_amd as M
+from megakv_amd.lib import load_library
+from oracle import oracle as O
+L = load_library()
+g = M.Geometry(mem_p=30)                   # the drop-in entry points have their geometry baked in
+og = O.geom(mem_p=30)
+table = torch.zeros(g.ht_size // 4, dtype=torch.int32, device="cuda")
+rng = np.random.default_rng(6)
+n = 40000                                  # twenty times what the workspace is told to hold (MKV_REQ_CAP=2048)
+e = np.empty((n, 3), np.uint32)
+e[:, 0] = rng.integers(1, 2**32, size=n, dtype=np.uint64)
+e[:, 1] = rng.integers(0, 2**32, size=n, dtype=np.uint64)
+e[:, 2] = rng.integers(1, 2**32, size=n, dtype=np.uint64)
+region = (e[:, 1] & g.hash_mask) >> (30 - 6 - 3)
+blocks = [np.ascontiguousarray(e[region == b]) for b in range(8)]
+dblocks = [torch.from_numpy(b.view(np.int32)).cuda() for b in blocks]
+ptrs = torch.tensor([b.data_ptr() for b in dblocks], dtype=torch.int64).cuda()
+counts_d = torch.zeros(8, dtype=torch.int32, device="cuda")
+counts_h = np.array([b.shape[0] for b in blocks], dtype=np.int32)       # host memory, pageable
+torch.cuda.synchronize()
+# the reference's way: the counts go to the device with the library's own copy (src/mega_scheduler.c:487-494)
+L.cudaMemcpyAsync.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_size_t, ctypes.c_int, ctypes.c_void_p]
+assert L.cudaMemcpyAsync(counts_d.data_ptr(), counts_h.ctypes.data, counts_h.nbytes, 1, None) == 0
+M.gpu_hash_insert(table, ptrs, counts_d, 8, None)
+torch.cuda.synchronize()
+exp = O.new_table(og)
+O.insert(og, exp, blocks)
+got = table.cpu().numpy().view(np.uint32).reshape(-1, 16)
+touched = np.unique(np.nonzero(exp.any(axis=1))[0])
+assert np.array_equal(got[touched], exp[touched]) and int(np.count_nonzero(got)) == int(np.count_nonzero(exp))
+assert L.mkv_dropped_batches() == 0
+print("sized by the counts the host copied")
+"""
+
+
+def test_oversize_batch_through_the_dropin_names_is_run_in_passes():
+    """gpu_hash_insert has no size argument (ref libgpuhash/gpu_hash.cu:521-556 takes any count): a host that copies
+    its block counts to the device through the library's cudaMemcpyAsync -- the reference's scheduler does,
+    src/mega_scheduler.c:487-494 -- has shown them to the library, which sizes the batch by them: forty thousand
+    requests against a workspace told to hold two thousand are applied, exactly, nothing dropped."""
+    env = dict(os.environ, MKV_REQ_CAP="2048", PYTHONPATH=ROOT)
+    p = subprocess.run([sys.executable, "-c", DROPIN], cwd=ROOT, env=env, capture_output=True, text=True, timeout=600)
+    assert p.returncode == 0 and "sized by the counts the host copied" in p.stdout, p.stderr[-3000:]

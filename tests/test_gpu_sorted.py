@@ -26,6 +26,7 @@ def _forced():
     L = load_library()
     assert L.mkv_set_tuning(b"sorted_min", 1) == 0
     assert L.mkv_set_tuning(b"sorted_cooldown", 0) == 0       # (never back off: every pass here takes the path)
+    assert L.mkv_set_tuning(b"insert_chunk", 524288) == 0     # (one pass per call: other suites of a run leave it smaller)
     yield
     assert L.mkv_set_tuning(b"sorted_min", 0) == 0
     assert L.mkv_set_tuning(b"sorted_cooldown", 32) == 0
