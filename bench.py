@@ -681,10 +681,21 @@ def main():
     # phases, not a ledger of the timed region) -- what a SCALE record is read against BASELINE.md section 4 with.
     phases = None
     if sharded and native and args.steps >= 26:
+        # (the traced pass is a collective of its own -- every rank runs its exchanges -- and the gather behind it is one
+        # too: a rank that failed must not leave the others waiting in them.  What a rank raised is kept, the ranks agree
+        # on success with an all-reduce that every rank reaches, and only then enter the gather.)
+        mine, err = None, None
         try:
             with torch.cuda.stream(run_stream):
                 mine = engine.native.phases_us(batches[args.warmup:args.warmup + args.steps], run_stream)
-            barrier()
+        except Exception as ex:                                   # noqa: BLE001
+            err = f"{type(ex).__name__}: {ex}"
+        ok = torch.tensor([0.0 if err else 1.0], dtype=torch.float32, device=device)
+        if world > 1:
+            dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+        if float(ok.item()) < 0.5:
+            phases = {"error": err or "another rank failed its traced pass"}
+        else:
             t = torch.tensor([mine["pack"], mine["exchange"], mine["local"], mine["unpack"]], dtype=torch.float32, device=device)
             allr = [torch.zeros_like(t) for _ in range(world)]
             if world > 1:
@@ -692,8 +703,6 @@ def main():
             else:
                 allr = [t]
             phases = [{k: round(float(v), 2) for k, v in zip(("pack", "exchange", "local", "unpack"), a.tolist())} for a in allr]
-        except Exception as ex:                                   # noqa: BLE001
-            phases = {"error": f"{type(ex).__name__}: {ex}"}
 
     # side measurements: whatever happens in them, the line with `value` is still printed
     pcie = None
@@ -1264,10 +1273,12 @@ def live_traffic(args, fused):
         return None, "this run is itself under a profiler"
     kern = "k_search_mark" if fused else "k_search<"
     warm, steps = 5, 20
-    child = ["python3", os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm), "--repeats", "1",
+    # (the interpreter this run runs under, by its real path: a "python3" looked up on PATH may be another one without
+    # torch, or a wrapper script that execs the real one behind the profiler's preloaded library -- which this pool forbids)
+    child = [os.path.realpath(sys.executable), os.path.abspath(__file__), "--gpus", "1", "--steps", str(steps), "--warmup", str(warm), "--repeats", "1",
              "--workload", args.workload, "--keying", args.keying, "--sets", args.sets, "--scheme", args.scheme,
              "--lf", str(args.lf), "--batch-log2", str(args.batch_log2), "--mem-p", str(args.mem_p), "--overlap", args.overlap,
-             "--no-cpu", "--no-pcie", "--no-abi", "--no-events", "--no-live-traffic", "--prewarm-ms", "0"]
+             "--no-cpu", "--no-pcie", "--no-abi", "--no-sched", "--no-events", "--no-live-traffic", "--prewarm-ms", "0"]
     if args.memset:
         child.append("--memset")
     if args.sorted_gets:
