@@ -34,6 +34,8 @@ def _defaults():
         L.mkv_set_tuning(b"self_help", 1)
         L.mkv_set_tuning(b"merge_round2", 1)
         L.mkv_set_tuning(b"plans", 1)
+        L.mkv_set_tuning(b"sorted_min", 0)
+        L.mkv_set_tuning(b"sorted_cooldown", 32)
 
 
 _FIRST = int(__import__("os").environ.get("MKV_FUZZ_FIRST", "0"))       # (campaigns: a later range of seeds)
@@ -165,8 +167,12 @@ def _run(seed, forced):
     L.mkv_set_tuning(b"merge_round2", int(rng4.choice([1, 1, 0])))
     # round 1 carrying out the mark pass's plans (round 5): on (the default) or off
     L.mkv_set_tuning(b"plans", int(np.random.default_rng(19000 + seed).choice([1, 1, 1, 0])))
+    # big insert passes (round 6: partition into bins, apply per bucket -- mkv_upd_apply.h): off (the default), or forced
+    # at every size for one seed in four (never backing off)
+    L.mkv_set_tuning(b"sorted_min", int(np.random.default_rng(23000 + seed).choice([0, 0, 0, 1])))
+    L.mkv_set_tuning(b"sorted_cooldown", 0)
     for name in (b"tail_groups", b"grid_min", b"calm_factor", b"tail_rounds", b"insert_chunk", b"round_blocks",
-                 b"self_help", b"merge_round2", b"plans"):   # bisecting aid
+                 b"self_help", b"merge_round2", b"plans", b"sorted_min", b"sorted_cooldown"):   # bisecting aid
         v = __import__("os").environ.get("MKV_FUZZ_" + name.decode().upper())
         if v is not None:
             assert L.mkv_set_tuning(name, int(v)) == 0, name
@@ -262,6 +268,10 @@ def _run_cycles(seed, deletes):
     L.mkv_set_tuning(b"plans", int(np.random.default_rng(19000 + seed).choice([1, 1, 1, 0])))
     if not deletes:
         L.mkv_set_tuning(b"insert_chunk", 65536)     # (one pass)
+    # big insert passes (round 6): the partition rides in the cycle's search launch -- forced for one seed in four
+    sm = __import__("os").environ.get("MKV_FUZZ_SORTED_MIN")
+    L.mkv_set_tuning(b"sorted_min", int(sm) if sm is not None else int(np.random.default_rng(23000 + seed).choice([0, 0, 0, 1])))
+    L.mkv_set_tuning(b"sorted_cooldown", 0)
     sig_space = int(rng.choice([40, 5000, 1 << 20]))
     exp = random_table(g, rng, float(rng.choice([0.0, 0.3, 0.7, 0.9])), sig_space)
     idx = HashIndex(g, lib=L)

@@ -23,3 +23,7 @@ run MKV_FUZZ_MERGE_ROUND2=0 MKV_FUZZ_SELF_HELP=0 MKV_FUZZ_TAIL_GROUPS=5
 # round 5: round 1 never / always carries out the mark pass's plans; cycles (the mark pass inside the search launch, deletes between it and round 1)
 run MKV_FUZZ_PLANS=0 MKV_FUZZ_TAIL_GROUPS=32
 run MKV_FUZZ_PLANS=1 MKV_FUZZ_ROUND_BLOCKS=512 MKV_FUZZ_MERGE_ROUND2=1
+# round 6: big insert passes forced at every size (bins, apply per bucket, round 2 over the left-overs, the tail's fourth source)
+run MKV_FUZZ_SORTED_MIN=1 MKV_FUZZ_INSERT_CHUNK=65536 MKV_FUZZ_TAIL_GROUPS=32
+run MKV_FUZZ_SORTED_MIN=1 MKV_FUZZ_INSERT_CHUNK=65536 MKV_FUZZ_DEBUG_SKIP=2 MKV_FUZZ_TAIL_GROUPS=2 MKV_FUZZ_ROUND_BLOCKS=1
+run MKV_FUZZ_SORTED_MIN=1 MKV_FUZZ_INSERT_CHUNK=65536 MKV_FUZZ_DEBUG_SKIP=1 MKV_FUZZ_TAIL_ROUNDS=0 MKV_FUZZ_BIG=1
