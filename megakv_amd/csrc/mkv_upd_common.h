@@ -170,10 +170,6 @@ struct Ctl {
 	uint32_t hf_last[2];             // what the host-mapped flag words hold (they are written only when they change)
 	uint32_t hf_losers;              // ... and word 3: round 1 left many requests to round 2 in the last pass
 	uint32_t hf_walk;                // ... and word 4: one request in sixteen (or more) ran an eviction chain in the last pass
-	uint32_t sorted_nlosers;         // big passes: requests k_apply left to round 2 (listed in Sorted::losers); reset by the partition
-	uint32_t sorted_passes;          // ... passes k_apply has run so far / passes whose partition gave up (mkv_sorted_stats)
-	uint32_t sorted_fallbacks;
-	uint32_t hf_sorted;              // what word 5 of the host-mapped flags holds (round_body, sorted)
 	uint32_t dbg[8];                 // diagnostics (in-group rounds): why requests became a round's barrier
 	uint32_t tail_phase[16];         // diagnostics: 10 ns ticks per tail phase, summed over the call's passes
 	                                 // (8..15: inside the grid-wide rounds, work-group 0's view)
@@ -205,6 +201,11 @@ struct Ctl {
 	// on an idle chip: profiles/r04_plan_ahead_experiment.txt)
 	// (at the end of the block: the fields before it keep offsets a load instruction can hold)
 	struct { uint32_t n; uint32_t pad[15]; } committed[4][kShards];     // ([2]: round 1's self-help commits, [3]: its losers)
+	// big passes (mkv_upd_apply.h) -- behind everything else: the words the usual kernels read keep the offsets they had
+	uint32_t sorted_nlosers;         // requests k_apply left to round 2 (listed in Sorted::losers); reset by the partition
+	uint32_t sorted_passes;          // passes k_apply has run so far / passes whose partition gave up (mkv_sorted_stats)
+	uint32_t sorted_fallbacks;
+	uint32_t hf_sorted;              // what word 5 of the host-mapped flags holds (round_body, sorted)
 };
 
 struct Req {

@@ -231,11 +231,13 @@ __device__ __forceinline__ void mark_body(uint32_t block, uint32_t nblocks, Ctl 
 // Without conflict the chain's touch set is disjoint from every other request's,
 // so its position in the order is immaterial.  Everything is logged for the
 // roll-back behind a barrier.  Follows ref gpu_hash.cu:357-423.
+template <bool SORTED>
 __device__ bool try_chain(uint32_t *table, const DevGeom &g, const Req &r, uint32_t A, uint32_t idx,
 		unsigned long long *owner1, unsigned long long stamp1, Ctl *ctl, ChainLog *logs, uint32_t *log_slot,
 		bool own_ok, const unsigned long long *owner2, const uint4 *s_rec, const uint16_t *s_heads, const uint16_t *s_next,
-		uint32_t s_bin_shift, bool sorted_on, const uint8_t *state)
+		uint32_t s_bin_shift, bool sorted_flag, const uint8_t *state)
 {
+	const bool sorted_on = SORTED && sorted_flag;
 	// (the bins by their parts: a reference to the kernel's argument would put it into scratch memory for this call)
 	Sorted S = {};
 	S.rec = const_cast<uint4 *>(s_rec);
@@ -415,15 +417,16 @@ __device__ __forceinline__ bool shadow_live(const uint8_t *state, const Undo *un
 // (st, sh: the candidate's tag and cache entry, fetched by the caller -- who asks about up to three
 // candidates of a bucket fetches them all at once instead of one after the other's verdict)
 __device__ __forceinline__ bool round_commit_used_pre(uint32_t st, const uint4 &sh, const Undo *undo,
-		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
+		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff, bool sorted_on = false)
 {
+	// (sorted_on: the pass may hold commits of k_apply -- a constant in every instantiation, so the usual ones carry no check)
 	if (!tag_logged(st))
 		return false;                       // pending, done by the tail, or taken back (or selected already)
 	*eff = (sh.w & kLeadBit) ? (sh.w >> 8) : c;
 	const uint32_t P = sh.y & g.hash_mask;
 	if (b == P)
 		return true;
-	if (sorted_commit(st, sh.w))
+	if (sorted_on && sorted_commit(st, sh.w))
 		return false;                       // (a commit of k_apply, big passes: settled in its primary bucket; its record is in its bin)
 	const bool chain = st == ST_CHAIN1 || st == ST_CHAIN2;
 	const uint32_t w0 = undo[c].word0;
@@ -439,12 +442,12 @@ __device__ __forceinline__ bool round_commit_used_pre(uint32_t st, const uint4 &
 	return false;
 }
 __device__ __forceinline__ bool round_commit_used(const uint8_t *state, const uint4 *reqc, const Undo *undo,
-		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
+		const ChainLog *chain_logs, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff, bool sorted_on = false)
 {
 	const uint32_t st = state[c];
 	if (!tag_logged(st))
 		return false;
-	return round_commit_used_pre(st, reqc[c], undo, chain_logs, g, c, b, eff);
+	return round_commit_used_pre(st, reqc[c], undo, chain_logs, g, c, b, eff, sorted_on);
 }
 
 }  // namespace mkv

@@ -87,7 +87,9 @@ struct RoundLds {
 
 // (block of nblocks: the work-group's place among those that share the round -- the launch's own for
 // rounds launched by themselves)
-template <Op OP, int ROUND, int QCAP>
+// (SORTED: the instantiation for big passes, mkv_upd_apply.h -- the usual launches carry none of its code: a round 2
+// that only scans 524 K tags took 8.3 us with it compiled in, 6.6 without, and the tail launch 18.1 against 17.0)
+template <Op OP, int ROUND, int QCAP, bool SORTED = false>
 __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t nblocks_launched, unsigned char *lds, Ctl *ctl,
 		const DevGeom &g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
@@ -101,7 +103,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	// k_apply committed on a bucket is in its bin.  No groups of duplicates.
 	const uint32_t *list = list_arg;
 	uint32_t list_n = list_n_arg;
-	const bool sorted = ROUND == 2 && (record_hint & 512) != 0 && list == nullptr;
+	const bool sorted = SORTED && ROUND == 2 && (record_hint & 512) != 0 && list == nullptr;
 	if (sorted) {
 		list = S.losers;
 		list_n = ctl->sorted_nlosers;
@@ -250,15 +252,18 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 	uint32_t dg_qmax = 0;
 #endif
 	uint32_t base = start + block * blockDim.x;
-	uint32_t lpos = block * blockDim.x;             // (list mode: this turn's first entry of the list)
+	// (list mode: this turn's first entry of the list.  Only the instantiation for big passes walks a list on several
+	// work-groups and turns; the usual one takes its handful in ONE turn of one work-group, as it always did -- the
+	// expressions are kept apart so that the usual kernels compile to what they were)
+	uint32_t lpos = SORTED ? block * blockDim.x : 0u;
 	uint32_t pf_a = 0u, pf_b = 0u;
 	// (Fetching a turn's requests and tags a turn ahead was built and measured: no difference -- the turns of a
 	// long pass are bound by the memory system's rate of random accesses, not by their round trips.)
-	for (bool more = list ? lpos < list_n : (base < count && base >= start); ; ) {
+	for (bool more = list ? (SORTED ? lpos < list_n : list_n != 0u) : (base < count && base >= start); ; ) {
 		asm volatile("" ::"v"(pf_a), "v"(pf_b));       // (last turn's touches have long arrived)
 		if (more) {
-			const bool listed = list != nullptr && lpos + threadIdx.x < list_n;
-			const uint32_t idx = list ? (listed ? list[lpos + threadIdx.x] : 0u) : base + threadIdx.x;
+			const bool listed = list != nullptr && (SORTED ? lpos + threadIdx.x < list_n : threadIdx.x < list_n);
+			const uint32_t idx = list ? (listed ? list[SORTED ? lpos + threadIdx.x : threadIdx.x] : 0u) : base + threadIdx.x;
 			const bool in_range = list ? listed : idx < count;
 			// first round trip: request and its state -- independent loads
 			const bool pre = base == pre_base && pre_ok;
@@ -468,8 +473,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 			else
 				loser_list_add(s_ll, &s_lln, idx, lose);
 			base += span;
-			lpos += span;
-			more = list ? lpos < list_n : (base < count && base >= start);
+			if (SORTED) {
+				lpos += span;
+				more = list ? lpos < list_n : (base < count && base >= start);
+			} else {
+				more = list == nullptr && base < count && base >= start;
+			}
 		}
 		__syncthreads();
 		if (ROUND == 1 && s_fused) {
@@ -512,12 +521,12 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 				const unsigned long long v1 = owner_r1[A];
 				const uint32_t c1 = (v1 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v1 & ((1ull << kIdxBits) - 1ull)) : kNone;
 				uint32_t e1 = 0;
-				late = c1 != kNone && round_commit_used(state, reqc, undo, chain_logs, g, c1, A, &e1) && e1 > idx;
+				late = c1 != kNone && round_commit_used(state, reqc, undo, chain_logs, g, c1, A, &e1, sorted) && e1 > idx;
 				// ... or by the bucket's second registrant helping itself there in round 1 (self-help above)
 				const unsigned long long v3 = second[A];
 				const uint32_t c3 = (v3 >> kIdxBits) == kStampMax - stamp1 ? (uint32_t)(v3 & ((1ull << kIdxBits) - 1ull)) : kNone;
 				if (!late && c3 != kNone && c3 != c1 && c3 > idx)
-					late = round_commit_used(state, reqc, undo, chain_logs, g, c3, A, &e1) && e1 > idx;
+					late = round_commit_used(state, reqc, undo, chain_logs, g, c3, A, &e1, sorted) && e1 > idx;
 			}
 			const bool own = live && !late && (A == P || owner[A] == key);
 			// ... or by k_apply (a big pass): whatever it committed there of later requests is in the bin -- taken out,
@@ -557,7 +566,7 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 					atomicMin(&ctl->first_hard, idx);
 					uint32_t log_slot = 0;
 					chained = chains_here &&
-						try_chain(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1,
+						try_chain<SORTED>(table, g, r, A, idx, owner_r1, stamp1, ctl, chain_logs, &log_slot, ROUND == 1,
 								ROUND == 2 ? owner : nullptr, S.rec, S.heads, S.next, S.bin_shift, sorted, state);
 					hard = !chained;
 					u.word0 = log_slot;
@@ -671,14 +680,15 @@ __device__ __forceinline__ void round_body(const uint32_t block, const uint32_t 
 }
 
 
-template <Op OP, int ROUND>
+template <Op OP, int ROUND, bool SORTED = false>
 __global__ __launch_bounds__(256) void k_round(Ctl *ctl, DevGeom g, uint32_t *table,
 		const unsigned long long *owner, unsigned long long *owner_next, const uint4 *reqc, uint8_t *state,
 		Undo *undo, ChainLog *chain_logs, uint32_t lo_idx, uint32_t hi_idx, uint32_t req_cap, int record_hint,
-		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, Sorted S)
+		unsigned long long *emax, const unsigned long long *second, const uint32_t *lost, typename SortedArg<SORTED>::type Sarg)
 {
+	const Sorted S = sorted_of_arg(Sarg);
 	__shared__ __align__(16) unsigned char lds[RoundLds<ROUND, kDeferCap>::bytes];
-	round_body<OP, ROUND, kDeferCap>(blockIdx.x, gridDim.x, lds, ctl, g, table, owner, owner_next, reqc, state, undo,
+	round_body<OP, ROUND, kDeferCap, SORTED>(blockIdx.x, gridDim.x, lds, ctl, g, table, owner, owner_next, reqc, state, undo,
 			chain_logs, lo_idx, hi_idx, req_cap, record_hint, emax, second, lost, S);
 }
 

@@ -40,6 +40,14 @@ struct Sorted {
 	uint32_t nbins;
 };
 
+// what a kernel that may serve a big pass takes for its bins: the usual instantiation takes NOTHING (an empty
+// argument, no registers), the one for big passes the structure above
+struct NoSorted {};
+template <bool SORTED> struct SortedArg { typedef NoSorted type; };
+template <> struct SortedArg<true> { typedef Sorted type; };
+__device__ __forceinline__ Sorted sorted_of_arg(const Sorted &s) { return s; }
+__device__ __forceinline__ Sorted sorted_of_arg(const NoSorted &) { return Sorted{}; }
+
 __device__ __forceinline__ Undo sorted_undo_of(uint32_t P, uint2 u)
 {
 	Undo r;

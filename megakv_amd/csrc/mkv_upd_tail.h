@@ -80,7 +80,7 @@ __device__ __forceinline__ void trace_ev(uint32_t code, uint32_t a, uint32_t b, 
 
 __device__ __forceinline__ bool commit_used(const Tv &tv, const DevGeom &g, uint32_t c, uint32_t b, uint32_t *eff)
 {
-	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b, eff);
+	return round_commit_used(tv.state, tv.reqc, tv.undo, tv.chain_logs, g, c, b, eff, tv.sorted_on);
 }
 // the tags and cache entries of a bucket's (up to three) candidates, asked for together: one round trip
 // instead of up to six in a row (a request of the in-order replay spends its time in exactly these)
@@ -101,7 +101,7 @@ __device__ __forceinline__ void load_cands(const Tv &tv, uint32_t c1, uint32_t c
 __device__ __forceinline__ bool commit_used_pre(const Tv &tv, const DevGeom &g, uint32_t st, const uint4 &sh, uint32_t c,
 		uint32_t b, uint32_t *eff)
 {
-	return round_commit_used_pre(st, sh, tv.undo, tv.chain_logs, g, c, b, eff);
+	return round_commit_used_pre(st, sh, tv.undo, tv.chain_logs, g, c, b, eff, tv.sorted_on);
 }
 
 // the candidates of bucket b from its reservation words (kNone: none of this pass): its lowest registrant of
@@ -1852,15 +1852,16 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 // otherwise the helpers leave at once and work-group 0 does the rest: reservation rounds,
 // then the in-order replay per closed region.  A chain that meets an order violation makes
 // the launch roll back the later commits of that region and take them on as well.
-template <Op OP>
+template <Op OP, bool SORTED = false>
 __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint32_t *table,
 		unsigned long long *owner, unsigned long long *altmin, unsigned long long *cnt, const unsigned long long *owner1,
 		const unsigned long long *owner2, const unsigned long long *second, const uint4 *reqc, uint8_t *state, const Undo *undo,
 		const ChainLog *chain_logs,
 		uint32_t *glist, int max_rounds,
 		uint32_t lo_idx, uint32_t hi_idx, int first_chunk, int last_chunk, uint32_t *host_flag, uint32_t grid_min, uint32_t grid_progress,
-		int dbg_path, int round2_hint, uint32_t req_cap, Sorted S, int sorted_hint)
+		int dbg_path, int round2_hint, uint32_t req_cap, typename SortedArg<SORTED>::type Sarg, int sorted_hint)
 {
+	const Sorted S = sorted_of_arg(Sarg);
 	// (S, sorted_hint: a BIG pass -- partition, then apply per bucket, mkv_upd_apply.h: the commits of k_apply are looked
 	// for in its bins, Tv::sorted)
 	// (round2_hint >= 0: ROUND 2 runs here, as the launch's first phase, with that record_hint -- a launch that
@@ -1969,7 +1970,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		if (wg != 0)
 			return;
 		nwg = 1u;
-		round_body<OP, 2, kTailThreads>(0u, 1u, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
+		round_body<OP, 2, kTailThreads, SORTED>(0u, 1u, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
 				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
 				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, S, s_few, s_few_n);
 		asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // (every lane's stores have left before anybody reads on)
@@ -1981,7 +1982,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	} else if (round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u) {
 		// (every work-group reads the same flag: round 1, the kernel before, set it)
 		static_assert(RoundLds<2, kTailThreads>::bytes <= sizeof(lkeys), "round 2's LDS in the work list's");
-		round_body<OP, 2, kTailThreads>(wg, nwg, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
+		round_body<OP, 2, kTailThreads, SORTED>(wg, nwg, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
 				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
 				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, S);
 		grid_sync(&ctl->sync_r2, nwg);
@@ -2107,7 +2108,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	tv.chain_logs = chain_logs;
 	tv.ctl = ctl;
 	tv.sorted = S;
-	tv.sorted_on = sorted_hint != 0;
+	tv.sorted_on = SORTED && sorted_hint != 0;      // (a constant false in the usual instantiation: the bins' code is not in it)
 	uint32_t rounds_total = 0;
 	while (work_left) {
 		const uint32_t m = s_n;

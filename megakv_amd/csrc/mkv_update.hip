@@ -671,7 +671,7 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	if (!sorted)
 		hipLaunchKernelGGL((k_round<OP, 1>), dim3((unsigned)r1_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[0], w->owner[1], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-				rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost, S);
+				rhint | (big_grid ? 256 : 0), w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], w->lost, NoSorted());
 	// round 2: inside the tail launch (k_tail's first phase), unless the pass is announced with more
 	// requests than that launch has lanes for in a few turns, or is a delete
 	// (word 3 of the tail kernel's flags, read without synchronising -- a pass late, which only costs time:
@@ -688,15 +688,33 @@ static int launch_rounds(Workspace *w, const DevGeom &g, uint32_t *table, hipStr
 	long long r2_blocks = (hint + 255) / 256;
 	if (hint <= 0 || r2_blocks > tuning().round_blocks)
 		r2_blocks = r2_blocks < tuning().round_blocks ? tuning().round_blocks : (r2_blocks > 2048 ? 2048 : r2_blocks);
-	if (!merged)
+	if (!merged && !sorted)
 		hipLaunchKernelGGL((k_round<OP, 2>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
 				w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
-				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr, S);
-	MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
-			w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
-			tail_rounds, lo, hi, first_chunk,
-			last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min), (uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3,
-			merged ? rhint : -1, (uint32_t)w->req_cap, S, sorted ? 1 : 0);
+				rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr, NoSorted());
+	if constexpr (OP != OP_DELETE) {
+		if (sorted)     // (the instantiations that know of the bins: k_round<.., 2, true>, k_tail<.., true>)
+			hipLaunchKernelGGL((k_round<OP, 2, true>), dim3((unsigned)r2_blocks), dim3(256), 0, stream, w->ctl, g, table,
+					w->owner[1], w->owner[0], w->reqc, w->state, w->undo, w->chain_logs, lo, hi, (uint32_t)w->req_cap,
+					rhint, w->cnt + ((size_t)g.hash_mask + 1u), w->owner[4], (const uint32_t *)nullptr, S);
+	}
+	bool tail_done = false;
+	if constexpr (OP != OP_DELETE) {
+		if (sorted) {
+			MKV_LAUNCH_TIMED((k_tail<OP, true>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
+					w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+					tail_rounds, lo, hi, first_chunk,
+					last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min), (uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3,
+					-1, (uint32_t)w->req_cap, S, 1);
+			tail_done = true;
+		}
+	}
+	if (!tail_done)
+		MKV_LAUNCH_TIMED((k_tail<OP>), dim3(tail_groups_for<OP>()), dim3(kTailThreads), stream, (hipEvent_t) nullptr, done_ev, w->ctl, g, table, w->owner[2],
+				w->owner[3], w->cnt, w->owner[0], w->owner[1], w->owner[4], w->reqc, w->state, w->undo, w->chain_logs, w->glist,
+				tail_rounds, lo, hi, first_chunk,
+				last_chunk, w->host_flag_dev, (uint32_t)MKV_DIAG(grid_min), (uint32_t)MKV_DIAG(grid_progress), MKV_DIAG(debug_skip) & 3,
+				merged ? rhint : -1, (uint32_t)w->req_cap, NoSorted(), 0);
 	return hipGetLastError() == hipSuccess ? MKV_OK : MKV_EHIP;
 }
 

@@ -8,7 +8,7 @@ for rep in $(seq $reps); do
   for v in "$@"; do
     [ $v = tree ] && cp /tmp/lib_tree.so $lib || cp _ab/libmegakv_hip_$v.so $lib
     old=""; case $v in r0*) old=1;; esac
-    MKV_LIB_OLD_BUILD=$old timeout 600 python3 bench.py --no-cpu --no-pcie $args 2>/dev/null | python3 -c "
+    MKV_LIB_OLD_BUILD=$old timeout 600 python3 bench.py --no-cpu --no-pcie --no-live-traffic --no-abi --no-sched $args 2>/dev/null | python3 -c "
 import json,sys
 d=json.loads(sys.stdin.read()); print('$v', d['value'], round(d['ms_per_step']*1e3,2), d['roofline']['launch_us'])"
   done

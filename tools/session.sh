@@ -1,6 +1,11 @@
 #!/bin/bash
-cd "$GRAFT_REPO_ROOT"
-export MKV_FUZZ_CYCLE_CASES=300 MKV_FUZZ_NODEL_CASES=300
-bash tools/fuzz_campaign.sh 2000 2>&1 | tee gpurun_out/fuzz_r05_s2.txt | tail -18
-echo "-- big tables"
-MKV_FUZZ_BIG=1 MKV_FUZZ_CASES=300 MKV_FUZZ_CYCLE_CASES=24 MKV_FUZZ_NODEL_CASES=24 timeout 2400 python -m pytest tests/test_gpu_fuzz.py -q -x 2>&1 | grep -E "passed|failed" | tail -1 | tee -a gpurun_out/fuzz_r05_s2.txt
+# tail phases, S-upd: tree's diagnostics build vs r05's
+lib=megakv_amd/_lib/libmegakv_hip_diag.so
+cp $lib /tmp/libd_tree.so
+for v in tree r05 tree r05; do
+  [ $v = tree ] && cp /tmp/libd_tree.so $lib || cp _ab/libmegakv_hip_r05diag.so $lib
+  old=""; [ $v = r05 ] && old=1
+  echo "== $v"
+  MKV_LIB_OLD_BUILD=$old python3 tools/tail_phases.py zipf95 upd 8 2>&1 | tail -6 | sed 's/helped.*tail_parallel/tail_parallel/' | cut -c1-330
+done
+cp /tmp/libd_tree.so $lib
