@@ -52,8 +52,12 @@ def main():
         idx.insert(blocks)
         b.record()
         torch.cuda.synchronize()
+        try:
+            big = idx.sorted_stats()
+        except Exception:                       # (an earlier round's build of the library, tools/ab_lines.sh)
+            big = None
         print(f"batch {i}: {a.elapsed_time(b) * 1e3:9.1f} us  {idx.last_update_info()} tail phases us {idx.tail_phases_us()} "
-              f"big passes {idx.sorted_stats()}", flush=True)
+              f"big passes {big}", flush=True)
 
 
 if __name__ == "__main__":

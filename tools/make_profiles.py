@@ -30,8 +30,8 @@ def find(raw, name, suffix):
 
 def short(n):
     s = n.split("(")[0].replace("void ", "")
-    if "k_round<" in n:          # rounds 1 and 2 are instances of one template: keep them apart
-        s += "round " + n.split("k_round<")[1].split(">")[0].split(",")[-1].strip() + ">"
+    if "k_round<" in n:          # rounds 1 and 2 are instances of one template (Op, round[, big-pass build]): keep them apart
+        s += "round " + n.split("k_round<")[1].split(">")[0].split(",")[1].strip() + ">"
     return s
 
 
