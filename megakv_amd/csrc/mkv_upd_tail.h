@@ -303,6 +303,13 @@ __device__ __forceinline__ void wg_sync()
 	__syncthreads();
 }
 
+// a meeting of the work-group for what it keeps in LDS only: stores to global memory stay on their way (wg_sync and
+// __syncthreads wait until every one of them has been acknowledged -- a round trip)
+__device__ __forceinline__ void lds_sync()
+{
+	asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
 // All work-groups of the launch meet here.  They are few (Tuning::tail_groups) and stay resident
 // while they wait, so the others always get to run.  Release before, acquire after.
 __device__ __forceinline__ void grid_sync(uint32_t *counter, uint32_t nwg)
@@ -395,8 +402,10 @@ __device__ __forceinline__ void lds_sort(uint32_t *keys, uint32_t n2)
 // stays pending.  Returns the number replayed.
 template <Op OP>
 __device__ __forceinline__ uint32_t replay_regions(uint32_t *table, const DevGeom &g, const uint4 *reqc, uint8_t *state,
-		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const Tv &tv, uint32_t *s_count)
+		const uint32_t *lkeys, uint8_t *lreg, uint32_t n, const Tv &tv, uint32_t *s_count, uint32_t *s_viol)
 {
+	// (*s_viol, zero on entry: set when a request of the list reported an order violation -- the caller need not ask
+	// the control block; only then does the work-group wait for its stores before it goes on)
 	const uint32_t t = threadIdx.x;
 	for (uint32_t i = t; i < n; i += blockDim.x) {
 		const uint32_t idx = lkeys[i];
@@ -436,6 +445,8 @@ __device__ __forceinline__ uint32_t replay_regions(uint32_t *table, const DevGeo
 						state[idx] = ST_DONE;
 						MKV_TR(2u, idx, 0u, 0u);
 						d++;
+					} else {
+						*s_viol = 1u;
 					}
 				}
 				stop = __shfl(rc, 0) != 0;
@@ -444,7 +455,9 @@ __device__ __forceinline__ uint32_t replay_regions(uint32_t *table, const DevGeo
 		if (lane == 0 && d)
 			atomicAdd(s_count, d);
 	}
-	wg_sync();
+	lds_sync();
+	if (*s_viol)
+		wg_sync();
 	return *s_count;
 }
 
@@ -932,15 +945,19 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 					others += cnt_of(ld_agent(&cnt[A]), stamp) - 1u;
 				}
 				bool bad = clean ? room == 0u : room < 1u + others;
+#ifdef MKV_DIAGNOSTICS
 				if (bad && !clean)
 					atomicAdd(&ctl->dbg[2], 1u);
+#endif
 				if (bad && clean) {
 					// hard right now: it may still run this round if its chain is all its own
 					if (walk_and_claim(table, g, req_of(rc), P, A, idx, owner, stamp, tv, s_rbar, sig_at(lo, hi, rc.x & 7u))) {
 						state[idx] = ST_CHAIN_OK;
 						bad = false;
 					} else {
+#ifdef MKV_DIAGNOSTICS
 						atomicAdd(&ctl->dbg[1], 1u);
+#endif
 					}
 				}
 				if (bad)
@@ -1076,9 +1093,11 @@ __device__ __forceinline__ uint32_t tail_rounds(Ctl *ctl, const DevGeom &g, uint
 		left = *s_left;
 		if (t == 0) {
 			*s_par += progress;
+#ifdef MKV_DIAGNOSTICS
 			ctl->dbg[5] += progress + left;
 			ctl->dbg[6] += 1u;
 			ctl->dbg[4] += progress;
+#endif
 		}
 		__syncthreads();
 		// a round that resolves less than the one-at-a-time replay would in its time
@@ -1752,97 +1771,120 @@ __device__ __forceinline__ void tail_epilogue(Ctl *ctl, const uint32_t *phase_ti
 {
 	// (rec_sums: round 1's per-work-group records summed -- commits, of those by self-help, losers: Ctl::wg_rec)
 	const uint32_t t = threadIdx.x;
-	if (t < 64) {
-		// statistics shards: one wave sums them
-		uint32_t c1 = ctl->committed[0][t].n, c2 = ctl->committed[1][t].n;      // (cleared by the next mark pass)
-		for (int off = 32; off > 0; off >>= 1) {
-			c1 += __shfl_down(c1, off);
-			c2 += __shfl_down(c2, off);
-		}
-		uint32_t c3 = ctl->committed[2][t].n, c4 = ctl->committed[3][t].n;
-		for (int off = 32; off > 0; off >>= 1) {
-			c3 += __shfl_down(c3, off);
-			c4 += __shfl_down(c4, off);
-		}
-		if (t == 0) {
-			c1 += rec_sums[0];
-			c3 += rec_sums[1];
-			c4 += rec_sums[2];
-			ctl->last.round1 = (first_chunk ? 0u : ctl->last.round1) + c1;
-			ctl->last.round2 = (first_chunk ? 0u : ctl->last.round2) + c2;
-			ctl->last.helped = (first_chunk ? 0u : ctl->last.helped) + c3;
-			ctl->last.losers = (first_chunk ? 0u : ctl->last.losers) + c4;
-			// word 3 of the host's flags: round 1 left round 2 more than a handful -- the host then gives round 2
-			// a launch of its own (more lanes than this launch has) until a pass leaves few again
-			const uint32_t many = c4 > kMergeLosersMax ? 1u : 0u;
-			if (host_flag && many != ctl->hf_losers) {
-				host_flag[3] = many;
-				ctl->hf_losers = many;
-			}
-		}
-	}
+	if (t >= 64)
+		return;
+	// Every word the epilogue reads is asked for HERE, before anything waits for an answer: one round trip.  (A lane
+	// that loads a word, decides, stores and loads the next made five to seven of them in a row -- 3 us of a launch
+	// that had replayed one request.)
+	// statistics shards: one wave sums them (cleared by the next mark pass)
+	uint32_t c1 = ctl->committed[0][t].n, c2 = ctl->committed[1][t].n;
+	uint32_t c3 = ctl->committed[2][t].n, c4 = ctl->committed[3][t].n;
+	uint32_t w_hfl = 0, w_hf0 = 0, w_hf1 = 0, w_hfw = 0, w_fh = 0, w_ov = 0, w_cok = 0, w_ht = 0, w_cn = 0;
+	unsigned long long w_stamp = 0;
 	if (t == 0) {
-		// diagnostics of this call (summed over its chunks), then the control block of the next pass
-		for (int k = 0; k < 16; k++)
-			ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + ((IDLE || !phase_ticks) ? 0u : phase_ticks[k]);
-		for (int k = 0; k < 8; k++) {                  // (diagnostic counts ride in the slots of the grid-wide rounds' ticks)
-			ctl->tail_phase[8 + k] += ctl->dbg[k] * 100u;
-			ctl->dbg[k] = 0;
-		}
-		ctl->last.total = total_all;
-		ctl->last.tail_parallel = (first_chunk ? 0u : ctl->last.tail_parallel) + par;
-		ctl->last.tail_serial = (first_chunk ? 0u : ctl->last.tail_serial) + serial;
-		ctl->last.undone = (first_chunk ? 0u : ctl->last.undone) + undone;
-		ctl->last.tail_rounds = (first_chunk ? 0u : ctl->last.tail_rounds) + rounds_total;
-		const uint32_t fh = ctl->first_hard;
-		ctl->last.first_hard = first_chunk ? fh : (fh < ctl->last.first_hard ? fh : ctl->last.first_hard);
-		ctl->last.overflow = ctl->overflow;
-		ctl->last.chains = (first_chunk ? 0u : ctl->last.chains) + ctl->chain_ok;
-		// (the two "barrier" fields of the diagnostics now count: order violations handled, and hard
-		// requests the grid-wide rounds left to the tail)
-		ctl->last.bar_chain = (first_chunk ? 0u : ctl->last.bar_chain) + viols;
-		ctl->last.bar_class = (first_chunk ? 0u : ctl->last.bar_class) + ctl->hard_tail;
-		// word 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
-		// an order violation grows with the square of the pass size); word 1: the 40-bit round stamps
-		// are nearly used up -- the host clears the reservation tables before a later call
-		// (ensure_ws); word 2: batches that exceeded the workspace and were dropped, so far.  Only
-		// this kernel writes the words; the host only reads them.
-		if (last_chunk && host_flag) {
-			// (a store to host memory makes the end of this kernel wait for the PCIe write: 4 us between
-			// this launch and the next search, every step -- the words are written when they change)
-			const uint32_t f0 = (ctl->last.bar_chain + ctl->last.bar_class) != 0u ? 1u : 0u;
-			const uint32_t f1 = ctl->stamp_base > kStampMax - kStampReserve ? 1u : 0u;
-			if (f0 != ctl->hf_last[0]) {
-				host_flag[0] = f0;
-				ctl->hf_last[0] = f0;
-			}
-			if (f1 != ctl->hf_last[1]) {
-				host_flag[1] = f1;
-				ctl->hf_last[1] = f1;
-			}
-			if (ctl->overflow)
-				host_flag[2] = host_flag[2] + 1u;
-			// word 4: the pass walked many eviction chains (a well-filled table) -- the host then has the next mark
-			// passes' walks ahead register without returning atomics (prewalk_register)
-			const uint32_t f4 = ctl->chain_n * 16u > total_all ? 1u : 0u;
-			if (f4 != ctl->hf_walk) {
-				host_flag[4] = f4;
-				ctl->hf_walk = f4;
-			}
-		}
-		ctl->hard_tail = 0;
-		ctl->chain_n = 0;
-		ctl->chain_ok = 0;
-		ctl->any_loser = 0;
-		ctl->any_tail = 0;
-		ctl->any_hard = 0;
-		ctl->first_hard = kNone;
-		ctl->total = 0;
-		// stamps: rounds 1 and 2, what the tail's rounds took, one spare
-		ctl->stamp_base = ctl->stamp_base + 3ull + rounds_total;
-		ctl->ep_pending = 0u;
-		ctl->carry_lo = kNone;
+		w_hfl = ld_agent32(&ctl->hf_losers);
+		w_hf0 = ld_agent32(&ctl->hf_last[0]);
+		w_hf1 = ld_agent32(&ctl->hf_last[1]);
+		w_hfw = ld_agent32(&ctl->hf_walk);
+		w_fh = ld_agent32(&ctl->first_hard);
+		w_ov = ld_agent32(&ctl->overflow);
+		w_cok = ld_agent32(&ctl->chain_ok);
+		w_ht = ld_agent32(&ctl->hard_tail);
+		w_cn = ld_agent32(&ctl->chain_n);
+		w_stamp = ld_agent(&ctl->stamp_base);
 	}
+	for (int off = 32; off > 0; off >>= 1) {
+		c1 += __shfl_down(c1, off);
+		c2 += __shfl_down(c2, off);
+		c3 += __shfl_down(c3, off);
+		c4 += __shfl_down(c4, off);
+	}
+	if (t != 0)
+		return;
+	c1 += rec_sums[0];
+	c3 += rec_sums[1];
+	c4 += rec_sums[2];
+	// (a call in several passes: the earlier passes' counts are added to -- one more round trip, for those calls only)
+	Info acc{};
+	acc.first_hard = kNone;
+	if (!first_chunk)
+		acc = ctl->last;
+	ctl->last.round1 = acc.round1 + c1;
+	ctl->last.round2 = acc.round2 + c2;
+	ctl->last.helped = acc.helped + c3;
+	ctl->last.losers = acc.losers + c4;
+	// word 3 of the host's flags: round 1 left round 2 more than a handful -- the host then gives round 2
+	// a launch of its own (more lanes than this launch has) until a pass leaves few again
+	const uint32_t many = c4 > kMergeLosersMax ? 1u : 0u;
+	if (host_flag && many != w_hfl) {
+		host_flag[3] = many;
+		ctl->hf_losers = many;
+	}
+#ifdef MKV_DIAGNOSTICS
+	// diagnostics of this call (summed over its chunks)
+	for (int k = 0; k < 16; k++)
+		ctl->tail_phase[k] = (first_chunk ? 0u : ctl->tail_phase[k]) + ((IDLE || !phase_ticks) ? 0u : phase_ticks[k]);
+	for (int k = 0; k < 8; k++) {                  // (diagnostic counts ride in the slots of the grid-wide rounds' ticks)
+		ctl->tail_phase[8 + k] += ctl->dbg[k] * 100u;
+		ctl->dbg[k] = 0;
+	}
+#else
+	(void)phase_ticks;
+#endif
+	// ... then the control block of the next pass
+	ctl->last.total = total_all;
+	ctl->last.tail_parallel = acc.tail_parallel + par;
+	ctl->last.tail_serial = acc.tail_serial + serial;
+	ctl->last.undone = acc.undone + undone;
+	ctl->last.tail_rounds = acc.tail_rounds + rounds_total;
+	ctl->last.first_hard = w_fh < acc.first_hard ? w_fh : acc.first_hard;
+	ctl->last.overflow = w_ov;
+	ctl->last.chains = acc.chains + w_cok;
+	// (the two "barrier" fields of the diagnostics now count: order violations handled, and hard
+	// requests the grid-wide rounds left to the tail)
+	const uint32_t bar_chain = acc.bar_chain + viols, bar_class = acc.bar_class + w_ht;
+	ctl->last.bar_chain = bar_chain;
+	ctl->last.bar_class = bar_class;
+	// word 0: chains ran late in this call (the next hinted batch is chunked finely: the chance of
+	// an order violation grows with the square of the pass size); word 1: the 40-bit round stamps
+	// are nearly used up -- the host clears the reservation tables before a later call
+	// (ensure_ws); word 2: batches that exceeded the workspace and were dropped, so far.  Only
+	// this kernel writes the words; the host only reads them.
+	if (last_chunk && host_flag) {
+		// (a store to host memory makes the end of this kernel wait for the PCIe write: 4 us between
+		// this launch and the next search, every step -- the words are written when they change)
+		const uint32_t f0 = (bar_chain + bar_class) != 0u ? 1u : 0u;
+		const uint32_t f1 = w_stamp > kStampMax - kStampReserve ? 1u : 0u;
+		if (f0 != w_hf0) {
+			host_flag[0] = f0;
+			ctl->hf_last[0] = f0;
+		}
+		if (f1 != w_hf1) {
+			host_flag[1] = f1;
+			ctl->hf_last[1] = f1;
+		}
+		if (w_ov)
+			host_flag[2] = host_flag[2] + 1u;
+		// word 4: the pass walked many eviction chains (a well-filled table) -- the host then has the next mark
+		// passes' walks ahead register without returning atomics (prewalk_register)
+		const uint32_t f4 = w_cn * 16u > total_all ? 1u : 0u;
+		if (f4 != w_hfw) {
+			host_flag[4] = f4;
+			ctl->hf_walk = f4;
+		}
+	}
+	ctl->hard_tail = 0;
+	ctl->chain_n = 0;
+	ctl->chain_ok = 0;
+	ctl->any_loser = 0;
+	ctl->any_tail = 0;
+	ctl->any_hard = 0;
+	ctl->first_hard = kNone;
+	ctl->total = 0;
+	// stamps: rounds 1 and 2, what the tail's rounds took, one spare
+	ctl->stamp_base = w_stamp + 3ull + rounds_total;
+	ctl->ep_pending = 0u;
+	ctl->carry_lo = kNone;
 }
 
 // ---- the tail launch ----------------------------------------------------------------------
@@ -1880,7 +1922,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	__shared__ uint32_t s_rbar[kMaxRegions];    // barrier of the current in-group round
 	__shared__ uint32_t s_rmin[kMaxRegions];    // lowest pending index per region
 	__shared__ uint32_t s_below[kMaxRegions];   // requests before the round's barrier that the round has left pending
-	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols;
+	__shared__ uint32_t s_n, s_progress, s_undone, s_par, s_serial, s_left, s_dupw, s_done12, s_viols, s_rviol;
 	const uint32_t t = threadIdx.x, wg = blockIdx.x;
 	uint32_t nwg = gridDim.x;
 	// (time per phase: diagnostics builds only, make DIAG=1 -- sixteen registers held for the whole
@@ -1916,7 +1958,30 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	static_assert(offsetof(Ctl, any_loser) % 16 == 0 && offsetof(Ctl, force_tail) == offsetof(Ctl, any_loser) + 12, "one load");
 	if ((flags.x | flags.y | flags.z | flags.w) == 0u && first_chunk && last_chunk)
 		return;
-	const uint32_t total_all = ctl->total;
+	// What the launch goes on to read from the control block is asked for together, HERE: one round trip where the
+	// words read one after the other's answer (the pass's size, the carried index, the stamp, the lists' counts, the
+	// commit counters) made five.  (Round 2 as this launch's first phase writes the lists' counts and its commit
+	// counters: those are read behind it then, as before.)
+	// (... and with round 2 ahead nothing is asked for that it does not need: its first meeting would wait for the answers)
+	static_assert(offsetof(Ctl, ep_pending) % 16 == 0 && offsetof(Ctl, total) == offsetof(Ctl, ep_pending) + 4 &&
+			offsetof(Ctl, carry_lo) == offsetof(Ctl, ep_pending) + 12, "one load");
+	const bool r2_here = round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u;   // (round 2 runs in this launch)
+	uint4 head1 = make_uint4(0u, 0u, 0u, 0u);                                    // {ep_pending, total, overflow, carry_lo}
+	unsigned long long stamp1 = 0ull;                                            // round-1 stamp of this pass
+	uint32_t pre_g1 = 0u, pre_g2 = 0u, pre_cnt = 0u, pre_done = 0u;
+	uint2 pre_e = make_uint2(kNone, kNone);       // the first two entries this lane would list (work-group 0 lists)
+	static_assert(offsetof(Ctl, tl) % 8 == 0 && kTlPer >= 2u, "one 8-byte load");
+	if (!r2_here) {
+		if (wg == 0)
+			pre_e = *reinterpret_cast<const uint2 *>(&ctl->tl[my_round][my_wg][0]);
+		head1 = *reinterpret_cast<const uint4 *>(&ctl->ep_pending);
+		stamp1 = ctl->stamp_base;
+		pre_g1 = ctl->tl_groups[0];
+		pre_g2 = ctl->tl_groups[1];
+		pre_cnt = ctl->tl_cnt[my_round][my_wg];
+		if (t < 64u)
+			pre_done = ctl->committed[0][t].n + ctl->committed[1][t].n;
+	}
 	// Round 1 left round 2 a handful (the usual pass has one loser in two cases of three: a third registrant of a
 	// bucket, a request behind one that holds the bucket as its alternate, a second registrant of a full bucket) and
 	// listed them (Ctl::ll): this work-group runs round 2 over the list and goes on alone -- no scan of the pass's
@@ -1940,7 +2005,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			}                                                                           \
 		}                                                                               \
 	} while (0)
-	const bool try_few = round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u && first_chunk && last_chunk;
+	const bool try_few = r2_here && first_chunk && last_chunk;
 	if (try_few) {
 		if (t == 0) {
 			s_few_n = 0u;
@@ -1966,6 +2031,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		__syncthreads();
 	}
 	few = try_few && s_few_bad == 0u && s_few_n != 0u;      // (none listed: round 1 ran on more work-groups than it has records for)
+	uint32_t p_any_tail = flags.y;      // (no round 2 in this launch: only kernels before this one set the flag)
 	if (few) {
 		if (wg != 0)
 			return;
@@ -1977,21 +2043,27 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		wg_sync();
 		// ... and that was it, as a rule: the pass's epilogue stays pending then, as on the way out above
 		// (the next mark pass resets the round's flag; its commits are counted where the host finds them)
-		if (ld_agent32(&ctl->any_tail) == 0u && flags.w == 0u)
+		p_any_tail = ld_agent32(&ctl->any_tail);
+		if (p_any_tail == 0u && flags.w == 0u)
 			return;
-	} else if (round2_hint >= 0 && OP != OP_DELETE && flags.x != 0u) {
+	} else if (r2_here) {
 		// (every work-group reads the same flag: round 1, the kernel before, set it)
 		static_assert(RoundLds<2, kTailThreads>::bytes <= sizeof(lkeys), "round 2's LDS in the work list's");
 		round_body<OP, 2, kTailThreads, SORTED>(wg, nwg, reinterpret_cast<unsigned char *>(lkeys), ctl, g, table, owner2,
 				const_cast<unsigned long long *>(owner1), reqc, state, const_cast<Undo *>(undo), const_cast<ChainLog *>(chain_logs),
 				lo_idx, hi_idx, req_cap, round2_hint, cnt + ((size_t)g.hash_mask + 1u), second, nullptr, S);
 		grid_sync(&ctl->sync_r2, nwg);
+		p_any_tail = ld_agent32(&ctl->any_tail);
 	}
+	if (r2_here) {
+		head1 = *reinterpret_cast<const uint4 *>(&ctl->ep_pending);
+		stamp1 = ctl->stamp_base;
+	}
+	const uint32_t total_all = head1.y;
 	// Round 2 left nothing (or the epilogue is wanted for its own sake): no lists, no scans, no meetings --
 	// every work-group reads the one flag (final: only kernels before this one in the stream -- or the
 	// phase above, behind its meeting -- set it) and work-group 0 leaves the control block ready for the
 	// next pass.
-	const uint32_t p_any_tail = ld_agent32(&ctl->any_tail);
 	if (p_any_tail == 0u) {
 		if (wg == 0) {
 			if (t == 0)
@@ -2004,7 +2076,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		return;
 	}
 	const uint32_t total = hi_idx < total_all ? hi_idx : total_all;   // this chunk ends here
-	const uint32_t carry_in = ctl->carry_lo;
+	const uint32_t carry_in = head1.w;
 	// what the grid-wide rounds left, listed by themselves (tail_list_add) -- unless a work-group left
 	// more than its place holds, shadows without a leader are about (not listed), or the call runs in
 	// several passes.  Every work-group of this launch reads the counts and decides alike.
@@ -2016,15 +2088,17 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	}
 	__syncthreads();
 	MKV_SUM_RECS();          // (read behind the next barrier: s_done12 below, the epilogue at the end)
-	const bool list_ok = first_chunk && last_chunk && carry_in >= lo_idx && ctl->loose == 0u && p_any_tail != 0u;
-	const uint32_t tl_g1 = list_ok ? ctl->tl_groups[0] : 0u;
-	const uint32_t tl_g2 = list_ok && ctl->any_loser != 0u ? ctl->tl_groups[1] : 0u;    // (round 2 leaves at once without losers)
+	const uint32_t p_loose = r2_here ? ctl->loose : flags.z;
+	const bool list_ok = first_chunk && last_chunk && carry_in >= lo_idx && p_loose == 0u && p_any_tail != 0u;
+	const uint32_t tl_g1 = !list_ok ? 0u : r2_here ? ctl->tl_groups[0] : pre_g1;
+	const uint32_t tl_g2 = !list_ok || flags.x == 0u ? 0u : r2_here ? ctl->tl_groups[1] : pre_g2;    // (round 2 leaves at once without losers)
 	uint32_t my_cnt = 0, my_base = 0;
 	if (list_ok) {
 		if (tl_g1 > kTlGroups || tl_g2 > kTlGroups) {
 			s_tl_over = 1u;
 		} else if (my_wg < (my_round ? tl_g2 : tl_g1)) {
-			my_cnt = ctl->tl_cnt[my_round][my_wg] + (my_round == 0u ? ctl->wg_rec[my_wg].stat.x : 0u);    // (round 1: one or the other, round_body)
+			// (round 1: one or the other, round_body -- its record is in this lane's registers already)
+			my_cnt = (r2_here ? ctl->tl_cnt[my_round][my_wg] : pre_cnt) + (my_round == 0u ? rec_stat.x : 0u);
 			if (my_cnt > kTlPer)
 				s_tl_over = 1u;
 			else if (my_cnt)
@@ -2037,13 +2111,13 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	if (carry_in < lo_idx)
 		lo_idx = carry_in;                        // this pass also covered the carried requests
 	const bool work_left = p_any_tail != 0u;      // round 2 has retagged every LOSER
-	const unsigned long long stamp1 = ctl->stamp_base;    // round-1 stamp of this pass
 	if (t == 0) {
 		s_n = 0;
 		s_undone = 0;
 		s_par = 0;
 		s_serial = 0;
 		s_viols = 0;
+		s_rviol = 0;
 		s_loose = 0;
 		s_revived = 0;
 	}
@@ -2052,7 +2126,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	// that pays -- judged by what every work-group reads alike: the rounds' flags and commit
 	// counters (final: only the kernels before this one in the stream change them).
 	if (t < 64u) {
-		uint32_t c = ctl->committed[0][t].n + ctl->committed[1][t].n;
+		uint32_t c = r2_here ? ctl->committed[0][t].n + ctl->committed[1][t].n : pre_done;
 		for (int off = 32; off > 0; off >>= 1)
 			c += __shfl_down(c, off);
 		if (t == 0)
@@ -2071,10 +2145,19 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	if (work_left && listed) {
 		MKV_PHASE(0);
 		// (the list goes into LDS as well: the work list of a short list is read from there at once)
-		for (uint32_t k = 0; k < my_cnt; k++) {
-			const uint32_t e = ctl->tl[my_round][my_wg][k];
-			glist[my_base + k] = e;
-			lkeys[my_base + k] = e;
+		// (LDS only: a listed work list always fits there -- kTlPer entries per lane of this work-group at most -- and
+		// nothing reads the global list before it is written anew; a store on its way to it made the meeting
+		// below wait a round trip)
+		static_assert(2u * kTlGroups * kTlPer <= (uint32_t)kSortCap, "a listed work list fits the LDS list");
+		if (!r2_here && my_cnt <= 2u) {
+			// (a lane's first two entries came with the counts: the usual short list costs no round trip of its own)
+			if (my_cnt > 0u)
+				lkeys[my_base] = pre_e.x;
+			if (my_cnt > 1u)
+				lkeys[my_base + 1u] = pre_e.y;
+		} else {
+			for (uint32_t k = 0; k < my_cnt; k++)
+				lkeys[my_base + k] = ctl->tl[my_round][my_wg][k];
 		}
 		if (t == 0)
 			s_n = tln;
@@ -2110,6 +2193,10 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 	tv.sorted = S;
 	tv.sorted_on = SORTED && sorted_hint != 0;      // (a constant false in the usual instantiation: the bins' code is not in it)
 	uint32_t rounds_total = 0;
+	// (flags_clean: nothing in this launch has run yet that could have recorded an order violation since the control
+	// block's word was last known to be clear -- round 1 cleared it, nobody but this launch sets it: the word need
+	// not be asked for, a round trip each time, by a launch that only replays a handful)
+	bool flags_clean = true;
 	while (work_left) {
 		const uint32_t m = s_n;
 		if (m == 0)
@@ -2124,6 +2211,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			fold.tc = lkeys + kFoldSlots;
 			fold.tk = reinterpret_cast<unsigned long long *>(lkeys + 2u * kFoldSlots);
 			static_assert(4u * kFoldSlots <= (uint32_t)kSortCap, "fold tables in the LDS of the work list");
+			flags_clean = false;
 			left = grid_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, glist, m, s_rbar, s_rmin, s_below, &s_progress,
 					&s_left, &s_dupw, kGridRoundsMax, &used, &par, grid_ticks, tv, rounds_total, fold, grid_progress);
 			if (wg != 0)
@@ -2172,13 +2260,16 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			wg_sync();
 			// a handful of requests: the in-order replay is done before a round would be
 			left = m;
-			if (m > (uint32_t)kTailReplayMax && max_rounds > 0)
+			if (m > (uint32_t)kTailReplayMax && max_rounds > 0) {
+				flags_clean = false;
 				left = tail_rounds<OP>(ctl, g, table, owner, cnt, altmin, reqc, state, keys, m, s_rbar, s_rmin, s_below, &s_progress,
 						&s_par, &s_left, &s_dupw, max_rounds, &used, tv, rounds_total, reinterpret_cast<uint32_t *>(lreg));
+			}
 		}
 		rounds_total += used;
 		MKV_PHASE(4);
-		if (left != 0 && ld_agent32(&ctl->tflags) == 0u) {
+		bool replayed_list = false;
+		if (left != 0 && (flags_clean || ld_agent32(&ctl->tflags) == 0u)) {
 			// what the rounds left: canonical order, one request at a time per closed region
 			if (!in_lds) {
 				// (the global list, finished entries marked kNone): into LDS if it fits
@@ -2205,10 +2296,18 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 			}
 			if (left <= (uint32_t)kSortCap) {
 				lds_sort(lkeys, n2);
-				replay_regions<OP>(table, g, reqc, state, lkeys, lreg, left, tv, &s_serial);
+				replay_regions<OP>(table, g, reqc, state, lkeys, lreg, left, tv, &s_serial, &s_rviol);
+				replayed_list = true;
 			} else {
+				flags_clean = false;
 				replay_pending_scan<OP>(table, g, reqc, state, glist, lkeys, lo_idx, total, tv, &s_serial);
 			}
+		}
+		// (a replay of the list alone, and none of its requests reported a violation -- the work-group has met behind
+		// it, replay_regions: everything is done, and the stores of the replay need not have arrived for the epilogue)
+		if (replayed_list && flags_clean && s_rviol == 0u) {
+			MKV_PHASE(5);
+			break;
 		}
 		wg_sync();
 		MKV_PHASE(5);
@@ -2325,7 +2424,9 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		if (t == 0) {
 			atomicExch(&ctl->tflags, 0u);
 			atomicExch(&ctl->vlist_n, 0u);
+			s_rviol = 0u;
 		}
+		flags_clean = true;
 		__syncthreads();
 		if (relisted == kNone)
 			gather_pending(state, undo, reqc, glist, &s_n, lo_idx, total, 0u, 1u, s_loose != 0u);
@@ -2334,7 +2435,7 @@ __global__ __launch_bounds__(kTailThreads) void k_tail(Ctl *ctl, DevGeom g, uint
 		wg_sync();
 		MKV_PHASE(3);
 	}
-	__syncthreads();
+	lds_sync();        // (the counts below are in LDS; what the replay stored to the table is on its way)
 	tail_epilogue<false>(ctl, phase_ticks, rounds_total, total_all, s_par, s_serial, s_undone, s_viols, first_chunk, last_chunk,
 			host_flag, s_rec);
 }
